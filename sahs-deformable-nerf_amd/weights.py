@@ -1,0 +1,149 @@
+"""Canonical parameter order and deterministic synthetic weights.
+
+The weight ABI of the hot path is the reference model's ``state_dict``
+(``eval_stage_rays.py:299-303`` builds ``AudioFaceModel(cfg)`` and calls
+``load_state_dict(checkpoint["model_state_dict"])``).  This module lists those tensors in
+``state_dict`` order (verified against the imported reference by
+``tests/golden/make_golden.py``) and concatenates them into ONE flat fp32 buffer -- the
+"canonical flat buffer" the C-ABI's ``sahs_pack_weights`` consumes.
+
+No checkpoint is available offline, so tests and ``bench.py`` use *hash-filled* weights: every
+element is a pure function of (tensor index, element index), scaled like PyTorch's default
+initialisers (Linear/Conv1d: U(+-1/sqrt(fan_in)); grid: N(0, 0.01^2), ``models.py:201``).
+The same function runs in the golden-vector generator and on the GPU box, so no weights need
+to be committed.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+# Architecture of AudioFaceModel(config/audio/*.yml).  The trunk's skip layer is 3, not the
+# YAML's 4: NeRFaceModel never forwards skip_connect_every (models.py:259-296), so NeRFMLP
+# keeps its default (modules.py:176).
+D_XYZ, D_DIR, D_AMB, D_POSE, D_DRV, D_GRID, G_RES = 63, 27, 18, 36, 76, 32, 32
+WARP_H, HYP_H, DEF_LAYERS, DEF_SKIP = 128, 64, 6, 4
+TR_H, TR_LAYERS, TR_SKIP, BR_H, N_SEG = 256, 8, 3, 128, 12
+D_DEF_IN = D_XYZ + D_DRV + D_POSE      # 175
+D_TR_IN = D_XYZ + D_AMB + D_POSE       # 117
+D_DIR_IN = TR_H + D_DIR + D_GRID       # 315
+
+# GEMM work per sample-evaluation as the reference writes it.
+MAC_PER_SAMPLE = 927_872
+FLOP_PER_SAMPLE = 2 * MAC_PER_SAMPLE
+
+
+def canonical_spec():
+    """[(state_dict key, shape)] in ``state_dict`` order."""
+    spec = [("spatial_embeddings", (1, D_GRID, G_RES, G_RES, G_RES))]
+
+    def lin(name, out, inp):
+        spec.append((name + ".weight", (out, inp)))
+        spec.append((name + ".bias", (out,)))
+
+    for i in range(DEF_LAYERS):
+        inp = D_DEF_IN if i == 0 else (WARP_H + D_DEF_IN if i == DEF_SKIP else WARP_H)
+        lin(f"warp_field_mlp.layers_xyz.{i}", WARP_H, inp)
+    lin("warp_field_mlp.fc_final", 3, WARP_H)
+    for i in range(DEF_LAYERS):
+        inp = D_DEF_IN if i == 0 else (HYP_H + D_DEF_IN if i == DEF_SKIP else HYP_H)
+        lin(f"hyper_sheep_mlp.layers_ambient.{i}", HYP_H, inp)
+    lin("hyper_sheep_mlp.fc_ambient", 2, HYP_H)
+    for lvl in ("coarse", "fine"):
+        p = f"nerf_mlps.{lvl}."
+        for i in range(TR_LAYERS):
+            inp = D_TR_IN if i == 0 else (TR_H + D_TR_IN if i == TR_SKIP else TR_H)
+            lin(p + f"layers_xyz.{i}", TR_H, inp)
+        lin(p + "fc_feat", TR_H, TR_H)
+        lin(p + "fc_alpha", 1, TR_H)
+        for i in range(4):
+            lin(p + f"layers_dir.{i}", BR_H, D_DIR_IN if i == 0 else BR_H)
+        lin(p + "fc_rgb", 3, BR_H)
+        for i in range(4):
+            lin(p + f"layers_seg.{i}", BR_H, TR_H if i == 0 else BR_H)
+        lin(p + "fc_seg", N_SEG, BR_H)
+    for idx, (co, ci) in zip((0, 2, 4, 6), ((32, 29), (32, 32), (64, 32), (64, 64))):
+        spec.append((f"audNet_head.encoder_conv.{idx}.weight", (co, ci, 3)))
+        spec.append((f"audNet_head.encoder_conv.{idx}.bias", (co,)))
+    lin("audNet_head.encoder_fc1.0", 64, 64)
+    lin("audNet_head.encoder_fc1.2", D_DRV, 64)
+    return spec
+
+
+def param_count():
+    return int(sum(int(np.prod(s)) for _, s in canonical_spec()))
+
+
+def canonical_offsets():
+    """OrderedDict key -> (offset, shape) into the flat buffer."""
+    out, off = OrderedDict(), 0
+    for k, s in canonical_spec():
+        out[k] = (off, s)
+        off += int(np.prod(s))
+    return out
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    x ^= x >> np.uint64(30)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(27)
+    x *= np.uint64(0x94D049BB133111EB)
+    x ^= x >> np.uint64(31)
+    return x
+
+
+def hash_uniform(n, stream, seed=0):
+    """n floats in [0,1): a pure function of (seed, stream, index); 24-bit mantissa."""
+    with np.errstate(over="ignore"):
+        i = np.arange(n, dtype=np.uint64)
+        key = _splitmix64(np.uint64(seed) * np.uint64(0x632BE59BD9B4E019) + np.uint64(stream))
+        x = _splitmix64(i ^ key)
+    return ((x >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
+
+
+def hash_normal(n, stream, seed=0):
+    u1 = hash_uniform(n, 2 * stream + 1_000_003, seed).astype(np.float64)
+    u2 = hash_uniform(n, 2 * stream + 1_000_004, seed).astype(np.float64)
+    r = np.sqrt(-2.0 * np.log(1.0 - u1))
+    return (r * np.cos(2.0 * np.pi * u2)).astype(np.float32)
+
+
+def hash_state_dict(seed=0, density_bias=0.0, density_gain=1.0):
+    """Deterministic synthetic ``state_dict`` (numpy fp32 arrays, state_dict order).
+
+    ``density_bias``/``density_gain`` give the *density-boosted* variant of SURVEY.md section 8(d):
+    fc_alpha.weight is multiplied by ``density_gain`` and ``density_bias`` is added to
+    fc_alpha.bias, so that rays terminate before the background sample and the composite /
+    importance-sampling stages are actually exercised.
+    """
+    sd = OrderedDict()
+    for t, (k, shape) in enumerate(canonical_spec()):
+        n = int(np.prod(shape))
+        if k == "spatial_embeddings":
+            v = hash_normal(n, t, seed) * np.float32(0.01)
+        else:
+            wshape = shape if k.endswith(".weight") else dict(canonical_spec())[k[:-5] + ".weight"]
+            fan_in = int(np.prod(wshape[1:]))
+            bound = np.float32(1.0 / np.sqrt(fan_in))
+            v = (hash_uniform(n, t, seed) * np.float32(2.0) - np.float32(1.0)) * bound
+        v = v.astype(np.float32).reshape(shape)
+        if k.endswith("fc_alpha.weight"):
+            v = v * np.float32(density_gain)
+        if k.endswith("fc_alpha.bias"):
+            v = v + np.float32(density_bias)
+        sd[k] = v
+    return sd
+
+
+def flatten_state_dict(sd):
+    """Concatenate a ``state_dict`` (numpy arrays or torch tensors) into the canonical flat buffer."""
+    parts = []
+    for k, shape in canonical_spec():
+        v = sd[k]
+        if hasattr(v, "detach"):
+            v = v.detach().cpu().numpy()
+        v = np.asarray(v, dtype=np.float32)
+        if tuple(v.shape) != tuple(shape):
+            raise ValueError(f"{k}: expected shape {shape}, got {tuple(v.shape)}")
+        parts.append(v.reshape(-1))
+    return np.concatenate(parts)

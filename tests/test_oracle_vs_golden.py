@@ -1,0 +1,144 @@
+"""Pin the CPU oracle (oracle/sahs_oracle.c) to the real reference.
+
+Every golden .npz was produced by tests/golden/make_golden.py importing the unmodified
+reference.  Tolerances: the oracle's arithmetic order is sequential fp32 while ATen's CPU kernels
+are vectorised (different summation trees, SLEEF transcendentals), so agreement is to fp32
+round-off amplified by the path's conditioning (PE frequencies up to 2^9 act on the warped
+point, see DESIGN.md "Numerics"), not bit-for-bit; sample indices must agree except where u
+falls within round-off of a cdf knot.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_rand, load_golden
+from oracle import oracle
+
+
+def close(a, b, rtol, atol, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.all(err <= tol), "%s: max abs err %.3e (tol %.3e) at %s" % (
+        what, err.max(), tol.reshape(-1)[err.argmax()], np.unravel_index(err.argmax(), err.shape))
+
+
+def test_param_count(weights_mod):
+    assert oracle.param_count() == weights_mod.param_count() == 2_775_633
+
+
+def test_get_ray_bundle():
+    g = load_golden("rays")
+    ro, rd = oracle.get_ray_bundle(int(g["H"]), int(g["W"]), g["intrinsics"], g["c2w"])
+    close(ro, g["ro"], 0, 0, "ro")
+    close(rd, g["rd"], 1e-6, 1e-7, "rd")
+
+
+def test_conditioning(flat_weights):
+    g = load_golden("cond")
+    close(oracle.audionet(flat_weights(), g["audio"]), g["driving"], 1e-5, 1e-6, "driving")
+    close(oracle.pose_encoding(g["pose"]), g["pose36"], 1e-6, 1e-6, "pose36")
+
+
+def test_positional_encoding():
+    g = load_golden("pe")
+    close(oracle.positional_encoding(g["x"], 10), g["pe_xyz"], 1e-6, 1e-6, "pe_xyz")
+    close(oracle.positional_encoding(g["x"], 4), g["pe_dir"], 1e-6, 1e-6, "pe_dir")
+    close(oracle.positional_encoding(g["w"], 4), g["pe_amb"], 1e-6, 1e-6, "pe_amb")
+    close(oracle.positional_encoding(g["x"], 3, include_input=False), g["pe_pose"], 1e-6, 1e-6, "pe_pose")
+
+
+@pytest.mark.parametrize("variant", ["default", "boosted"])
+def test_field(flat_weights, variant):
+    g = load_golden("field")
+    kw = dict(default=dict(), boosted=dict(density_bias=8.0, density_gain=30.0))[variant]
+    flat = flat_weights(**kw)
+    drv = oracle.audionet(flat, g["audio"])
+    p36 = oracle.pose_encoding(g["pose"])
+    raw_c, dx, w, grid = oracle.field_forward(flat, 0, g["x"], drv, p36, debug=True)
+    raw_f = oracle.field_forward(flat, 1, g["x"], drv, p36)
+    close(dx, g[variant + "_dx"], 1e-4, 2e-6, "dx")
+    close(w, g[variant + "_w"], 1e-4, 2e-6, "ambient w")
+    # grid features and raw see PE(512 * warped point): round-off in dx (1e-7) is amplified ~512x
+    close(grid, g[variant + "_grid_coarse"], 1e-3, 2e-6, "grid features")
+    scale = 30.0 if variant == "boosted" else 1.0
+    for lvl, raw in (("coarse", raw_c), ("fine", raw_f)):
+        close(raw[:, :15], g[variant + "_raw_" + lvl][:, :15], 1e-3, 1e-4, "raw rgb/seg " + lvl)
+        close(raw[:, 15], g[variant + "_raw_" + lvl][:, 15], 1e-3, 1e-4 * scale, "raw sigma " + lvl)
+
+
+@pytest.mark.parametrize("tag,use_bg,use_noise,white", [("bg", True, False, False), ("bg_noise", True, True, False),
+                                                       ("nobg", False, False, False), ("nobg_white", False, False, True)])
+def test_composite(tag, use_bg, use_noise, white):
+    g = load_golden("composite")
+    rgb, disp, acc, wts, depth = oracle.composite(g["raw"], g["z"], g["rd"], noise=g["noise"] if use_noise else None,
+                                                  bg=g["bg"] if use_bg else None, white_background=white)
+    close(wts, g[tag + "_weights"], 2e-5, 1e-7, "weights")
+    close(rgb, g[tag + "_rgb"], 2e-5, 2e-6, "rgb")
+    close(acc, g[tag + "_acc"], 2e-5, 1e-6, "acc")
+    close(depth, g[tag + "_depth"], 2e-5, 1e-6, "depth")
+    close(disp, g[tag + "_disp"], 5e-5, 1e-6, "disp")
+
+
+@pytest.mark.parametrize("tag", ["rand", "det"])
+def test_sample_pdf(tag):
+    g = load_golden("pdf")
+    z, w = g["z"], g["weights"]
+    u = g["u"] if tag == "rand" else None
+    zs, zsorted, inds = oracle.resample(z, w, 64, u=u)
+    ref_inds = g[tag + "_inds"]
+    mism = inds != ref_inds
+    # ATen's sum/cumsum are vectorised (different reduction tree from the oracle's sequential one),
+    # so a cdf knot can move by an ulp or two: an index may differ ONLY where u sits on a knot
+    # (det=True puts u=1.0 exactly on the last knot of every ray).
+    uu = g["u"] if tag == "rand" else np.broadcast_to(np.linspace(0.0, 1.0, 64, dtype=np.float32), inds.shape)
+    r, c = np.nonzero(mism)
+    knot = g[tag + "_cdf"][r, np.minimum(inds[r, c], ref_inds[r, c])]
+    assert np.all(np.abs(inds[r, c] - ref_inds[r, c]) == 1)
+    assert np.all(np.abs(uu[r, c] - knot) <= 1e-6), "index mismatch away from a cdf knot"
+    if tag == "rand":
+        assert mism.mean() <= 2e-4, "searchsorted index mismatches: %d of %d" % (mism.sum(), mism.size)
+    # t = (u - cdf_b) / (cdf_a - cdf_b): an ulp of cdf (6e-8) over a denominator as small as 1e-5,
+    # times the bin width (<= 0.05), bounds the legitimate difference at ~3e-4; observed 2.1e-4 (det)
+    # Where the index itself differs (u on a knot) the reference is discontinuous when the adjacent pdf
+    # bin is < 1e-5 (denom := 1, nerf_helpers.py:491-492), so those samples are excluded from the value check.
+    ok = ~mism
+    close(zs[ok], g[tag + "_samples"][ok], 1e-5, 3e-4, "z_samples")
+    rows = ~mism.any(axis=1)
+    assert rows.sum() >= 0.6 * len(rows)
+    close(zsorted[rows], g[tag + "_z_sorted"][rows], 1e-5, 3e-4, "sorted z")
+    assert np.all(np.diff(zsorted, axis=1) >= 0)
+
+
+def _chunk_rand(g, nchunks):
+    log = golden_rand(g)
+    per = len(log) // nchunks
+    keys = {4: ["t_rand", "noise_c", "u", "noise_f"], 2: ["t_rand", "u"], 0: []}[per]
+    std = float(g["noise_std"]) if "noise_std" in g else 0.1
+    out = []
+    for c in range(nchunks):
+        d = {}
+        for k, (kind, arr) in zip(keys, log[c * per:(c + 1) * per]):
+            assert kind == ("randn" if k.startswith("noise") else "rand")
+            d[k] = arr * np.float32(std) if k.startswith("noise") else arr
+        out.append(d)
+    return out
+
+
+@pytest.mark.parametrize("name,nchunks", [("e2e_default_val", 1), ("e2e_boosted_val", 1), ("e2e_boosted_val_2chunks", 2),
+                                          ("e2e_boosted_det", 1), ("e2e_boosted_train_noise", 1)])
+def test_end_to_end(flat_weights, name, nchunks):
+    g = load_golden(name)
+    flat = flat_weights(int(g["weights_seed"]), float(g["weights_density_bias"]), float(g["weights_density_gain"]))
+    ro, rd = oracle.get_ray_bundle(int(g["H"]), int(g["W"]), g["intrinsics"], g["pose"])
+    close(rd, g["rd"], 1e-6, 1e-7)
+    outs = oracle.run_one_iter_of_nerf(flat, ro, rd, float(g["near"]), float(g["far"]), int(g["num_coarse"]), int(g["num_fine"]),
+                                       g["audio"], g["pose"], background_prior=g["bg"], chunksize=int(g["chunksize"]),
+                                       rand=_chunk_rand(g, nchunks))
+    names = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"]
+    for nm, o in zip(names, outs):
+        ref = g["out_" + nm].reshape(o.shape)
+        # end-to-end: field round-off (1e-4 abs on raw) passes through sigmoid/softmax and the composite
+        close(o, ref, 2e-3, 2e-4, name + ":" + nm)
+    if "boosted" in name:
+        assert float(np.mean(g["out_w_bg"])) < 0.5, "density-boosted fixture should terminate rays before the background"
