@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- rendered rays/s of the deformable-NeRF hot path on MI355X.
+
+Workload W512 (BASELINE.json configs[1]): one 512x512 frame = 262,144 rays, 64 coarse +
+128 fine field evaluations per ray (num_coarse 64, num_fine 64 as in config/audio/person_2_auto.yml),
+8x256 radiance MLP + 6x128 warp + 6x64 hyper-sheet MLPs, validation mode (perturb on, noise off),
+background prior on, hash-filled density-boosted weights, synthetic audio/pose.  A "step" is one frame
+through the drop-in driver's launch sequence (ray bundle, conditioning fold, and per 131,072-ray chunk:
+depths, coarse field, composite, resample+sort, fine field, composite).  Inputs are resident in HBM.
+
+N GPUs: the frame's rays are split into N contiguous blocks (no exchange while rendering), then one
+all-gather of the 36 floats/ray outputs (RCCL).  Total work is fixed => "scaling": "strong".
+
+Prints ONE JSON line (rank 0).  roofline: the field kernel (99 % of the frame) against the fp32 MFMA
+peak, achieved = algorithmic FLOPs (1,855,744 per sample evaluation) / time
+of the field launches measured with HIP events on the launch stream inside the timed region.
+cpu_baseline: the CPU oracle (a port of the reference's algorithm; test infrastructure) timed on a
+64x64 crop of the same workload on this box's host cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FLOP_PER_SAMPLE = 1_855_744          # BASELINE.md section 3 (GEMM work as the reference writes it)
+PEAK_TFLOPS = {"fp32": 157.3}        # MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
+
+
+def build_inputs(pkg, dev, size, seed=42):
+    cfg = pkg.default_config()
+    W = pkg.weights
+    fw = W.flatten_state_dict(W.hash_state_dict(0, 8.0, 30.0))
+    model = pkg.AudioFaceModel(cfg).to(dev).load_flat(fw)
+    rng = np.random.default_rng(seed)
+    audio = torch.from_numpy(rng.standard_normal((16, 29)).astype(np.float32)).to(dev)
+    pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], axis=1).astype(np.float32)).to(dev)
+    intr = np.array([1200.0 * size / 512, 1200.0 * size / 512, 0.5, 0.5], np.float32)
+    R = size * size
+    bg = np.concatenate([rng.uniform(0, 1, (R, 3)), np.ones((R, 1)), np.zeros((R, 11))], axis=1).astype(np.float32)
+    return cfg, model, fw, audio, pose, intr, torch.from_numpy(bg).to(dev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512, help="frame is size x size rays")
+    ap.add_argument("--precision", default="fp32", choices=["fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, "launch with torchrun --nproc-per-node == --gpus"
+
+    pkg = importlib.import_module("sahs-deformable-nerf_amd")
+    ops = pkg.ops
+    cfg, model, fw, audio, pose, intr, bg_all = build_inputs(pkg, dev, args.size)
+    H = W = args.size
+    R = H * W
+    opt = cfg.nerf.validation
+    nc, nf, chunk = int(opt.num_coarse), int(opt.num_fine), int(opt.chunksize)
+    lo, hi = rank * R // world, (rank + 1) * R // world       # this rank's contiguous ray block
+    near, far = float(cfg.dataset.near), float(cfg.dataset.far)
+    packed, _ = model.packed()
+    torch.manual_seed(cfg.experiment.randomseed + rank)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    field_events = []
+    ws = {}
+
+    def step(record):
+        ro, rd = pkg.get_ray_bundle(H, W, intr, pose)
+        frame = model.frame(audio, pose)
+        ro, rd = ro.view(-1, 3)[lo:hi], rd.view(-1, 3)[lo:hi]
+        n = hi - lo
+        rays = torch.cat([ro, rd, torch.full((n, 1), near, device=dev), torch.full((n, 1), far, device=dev)], dim=1)
+        outs = []
+        for s in range(0, n, chunk):
+            rb = rays[s:s + chunk].contiguous()
+            bgb = bg_all[lo + s: lo + s + rb.shape[0]]
+            N = rb.shape[0]
+            # same launches, in the same order, as sahs_render_rays / predict_and_render_radiance
+            t_rand = torch.rand((N, nc), device=dev)
+            z_c = ops.stratified_depths(rb, nc, False, t_rand)
+            e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+            e0.record()
+            raw = ops.field_forward(packed, frame, 0, rb, z_c, out=ws.get(("raw", N, nc)))
+            e1.record()
+            ws[("raw", N, nc)] = raw
+            rgb_c, disp_c, acc_c, wts, _ = ops.composite_forward(raw, z_c, rb, bg=bgb)
+            u = torch.rand((N, nf), device=dev)
+            z_f = ops.resample(z_c, wts, nf, u=u)
+            e2.record()
+            raw_f = ops.field_forward(packed, frame, 1, rb, z_f, out=ws.get(("raw", N, nc + nf)))
+            e3.record()
+            ws[("raw", N, nc + nf)] = raw_f
+            rgb_f, disp_f, acc_f, wts_f, depth_f = ops.composite_forward(raw_f, z_f, rb, bg=bgb)
+            outs.append(torch.cat([rgb_c, disp_c[:, None], acc_c[:, None], rgb_f, disp_f[:, None], acc_f[:, None],
+                                   wts_f[:, -1:], depth_f[:, None]], dim=1))       # 36 floats / ray
+            if record:
+                field_events.append((e0, e1, N * nc))
+                field_events.append((e2, e3, N * (nc + nf)))
+        mine = torch.cat(outs, dim=0)
+        if world > 1:
+            full = torch.empty(world * mine.shape[0], 36, device=dev)
+            dist.all_gather_into_tensor(full, mine)
+            return full
+        return mine
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(True)
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(out).all())
+
+    field_ms = sum(a.elapsed_time(b) for a, b, _ in field_events)
+    field_flop = sum(p for _, _, p in field_events) * FLOP_PER_SAMPLE
+    achieved = field_flop / (field_ms * 1e-3) / 1e12
+    launches = len(field_events)
+
+    result = {
+        "metric": "rendered rays/sec (coarse64+fine128, 8x256 MLP)", "value": R * args.steps / dt, "unit": "rays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "W512: %dx%d rays, 64 coarse + 128 fine evaluations/ray, deform(6x128+6x64)+radiance(8x256) MLPs, "
+                               "validation mode (perturb on), bg prior, hash-filled density-boosted weights" % (H, W),
+                   "rays_per_step": R, "ray_chunk": chunk, "parallelism": "rays x%d" % world, "precision": args.precision},
+        "roofline": {"bound": "mfma", "kernel": "field_forward_f32_kernel", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision],
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": None,
+                     "launches": launches, "avg_launch_ms": field_ms / launches, "flop_per_sample": FLOP_PER_SAMPLE,
+                     "field_time_share": field_ms * 1e-3 / dt},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle   # cpu_baseline leg only: the oracle is the thing timed here, never the product path
+        cs = 64
+        ro, rd = pkg.get_ray_bundle(H, W, intr, pose)
+        c0 = (H - cs) // 2
+        ro_c = ro[c0:c0 + cs, c0:c0 + cs].reshape(-1, 3).cpu().numpy()
+        rd_c = rd[c0:c0 + cs, c0:c0 + cs].reshape(-1, 3).cpu().numpy()
+        rng = np.random.default_rng(1)
+        rnd = [dict(t_rand=rng.uniform(0, 1, (cs * cs, nc)).astype(np.float32), u=rng.uniform(0, 1, (cs * cs, nf)).astype(np.float32))]
+        bg_c = bg_all.view(H, W, 15)[c0:c0 + cs, c0:c0 + cs].reshape(-1, 15).cpu().numpy()
+        t0 = time.perf_counter()
+        oracle.run_one_iter_of_nerf(fw, ro_c, rd_c, near, far, nc, nf, audio.cpu().numpy(), pose.cpu().numpy(), background_prior=bg_c, rand=rnd)
+        cdt = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": cs * cs / cdt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+                                  "sample": "central %dx%d ray crop of the same frame (same weights, 64+128 evaluations/ray), "
+                                            "C oracle with OpenMP over points, %.1f s" % (cs, cs, cdt)}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+/*
+ * sahs_nerf.h -- C ABI of the MI355X-native deformable-NeRF volume-rendering hot path.
+ *
+ * The reference (jematy/SAHS-Deformable-Nerf) has no native boundary: its operator API for this
+ * path is three Python seams.  Each entry point below cites the reference
+ * interface it replaces; the Python side (sahs-deformable-nerf_amd/{train_utils,models,
+ * volume_rendering_utils,nerf_helpers}.py) mirrors those seams one to one and calls down here.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 unless stated; the library never allocates,
+ *    never synchronises and launches only on the given stream (hipStream_t passed as void*),
+ *    so a caller may capture any sequence of calls in a hipGraph;
+ *  - return 0 on success; non-zero = error, text via sahs_last_error() (thread-local);
+ *  - "rays" is the reference's packed ray table, row = [ro3, rd3, near, far, ...] with
+ *    `ray_stride` floats per row (train_utils.py:255-261 builds it with stride 20);
+ *  - precision: SAHS_F32 = exact fp32 (f32 MFMA), SAHS_BF16 = bf16 MFMA operands, fp32 accumulate.
+ */
+#ifndef SAHS_NERF_H
+#define SAHS_NERF_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAHS_ABI_VERSION 1
+#define SAHS_F32 0
+#define SAHS_BF16 1
+
+int sahs_abi_version(void);
+const char *sahs_last_error(void);
+
+/* Number of fp32 values in the canonical flat parameter buffer = the model's state_dict
+ * (eval_stage_rays.py:299-303), tensors concatenated in state_dict order: 2,775,633. */
+long sahs_param_count(void);
+/* Size (in floats / 4-byte words) of the packed weight buffer and of the per-frame buffer. */
+long sahs_packed_words(int precision);
+long sahs_frame_words(void);
+
+/* state_dict -> kernel layout.  Call after every parameter update (eval: once).
+ * Replaces nothing in the reference (it keeps nn.Linear weights); feeds sahs_field_forward. */
+int sahs_pack_weights(const float *flat_params, void *packed, int precision, void *stream);
+
+/* Per-frame conditioning.  Replaces AudioNet (modules.py:43-73), rot_to_euler /
+ * pose_to_euler_trans (models.py:482-504), encode_pose_fn (models.py:203-207) and the
+ * per-point .repeat() of both (models.py:518,521), which every point-chunk of the reference
+ * recomputes.  audio: (16,29); pose: 3x4 (or 4x4) row-major with row stride pose_ld.
+ * frame[0:76] = driving, frame[80:116] = pose encoding, then the folded biases. */
+int sahs_fold_conditioning(const float *flat_params, const float *audio, const float *pose, int pose_ld, float *frame,
+                           void *stream);
+
+/* get_ray_bundle (nerf_helpers.py:178-233). intrinsics = [fx, fy, cx, cy] (cx, cy relative);
+ * c2w device pointer, row stride ld; ro, rd: (H, W, 3). */
+int sahs_get_ray_bundle(int H, int W, float fx, float fy, float cx, float cy, const float *c2w, int ld, float *ro, float *rd,
+                        void *stream);
+
+/* Coarse depths (train_utils.py:93-113). t_rand (N,S) uniform draws or NULL (perturb off). z: (N,S). */
+int sahs_stratified_depths(long N, int S, const float *rays, int ray_stride, int lindisp, const float *t_rand, float *z,
+                           void *stream);
+
+/* run_network + model forward (train_utils.py:9-50 -> models.py:514-528) for level 0 (coarse)
+ * or 1 (fine), including pts = ro + rd*z (train_utils.py:115,168).  z: (N,S); raw: (N,S,16) =
+ * [rgb3, seg12, sigma].  dbg: NULL, or N*S*40 floats receiving [N*S x 8: dx3, w2, pad][N*S x 32:
+ * grid features] (test seam). */
+int sahs_field_forward(const void *packed, const float *frame, int level, long N, int S, const float *rays, int ray_stride,
+                       const float *z, float *raw, float *dbg, int precision, void *stream);
+
+/* volume_render_radiance_field (volume_rendering_utils.py:7-78) with the caller's background
+ * overwrite (train_utils.py:135-136,184-185) when bg != NULL.  noise: (N,S) already scaled by
+ * radiance_field_noise_std, or NULL.  Outputs rgb (N,15), disp (N), acc (N), weights (N,S), depth (N). */
+int sahs_composite_forward(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride,
+                           const float *noise, const float *bg, int white_background, float *rgb, float *disp, float *acc,
+                           float *weights, float *depth, void *stream);
+
+/* z_vals_mid + sample_pdf_2 + cat + sort (train_utils.py:157-166, nerf_helpers.py:454-497).
+ * weights: the full (N,S) composite weights (the [1:-1] slice is taken inside).  u: (N,nf) uniform
+ * draws or NULL (det=True).  z_samples (N,nf) and inds (N,nf) int64 may be NULL; z_out: (N,S+nf). */
+int sahs_resample(long N, int S, int nf, const float *z, const float *weights, const float *u, float *z_samples,
+                  float *z_out, int64_t *inds, void *stream);
+
+/* sample_pdf_2 alone (nerf_helpers.py:454-497): bins (N,nb), weights (N,nb-1), u (N,ns) or NULL (det=True)
+ * -> samples (N,ns); inds (N,ns) int64 optional. */
+int sahs_sample_pdf(long N, int nb, int ns, const float *bins, const float *weights, const float *u, float *samples,
+                    int64_t *inds, void *stream);
+
+/* predict_and_render_radiance (train_utils.py:72-206) for one ray chunk: the six launches above
+ * in sequence.  Workspace (caller-owned): z_c (N,Sc), z_f (N,Sc+nf), raw (N,Sc+nf,16),
+ * weights (N,Sc+nf).  Random draws in the reference's order (any may be NULL): t_rand (N,Sc),
+ * noise_c (N,Sc), u (N,nf), noise_f (N,Sc+nf).  Outputs as the reference's 8-tuple:
+ * rgb_c (N,15), disp_c, acc_c, rgb_f (N,15), disp_f, acc_f, w_bg (N) = weights_f[:, -1], depth_f. */
+int sahs_render_rays(const void *packed, const float *frame, int precision, long N, const float *rays, int ray_stride, int Sc,
+                     int nf, int lindisp, int white_background, const float *bg, const float *t_rand, const float *noise_c,
+                     const float *u, const float *noise_f, float *z_c, float *z_f, float *raw, float *weights, float *rgb_c,
+                     float *disp_c, float *acc_c, float *rgb_f, float *disp_f, float *acc_f, float *w_bg, float *depth_f,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAHS_NERF_H */

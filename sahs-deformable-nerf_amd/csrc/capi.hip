@@ -1,0 +1,162 @@
+// capi.hip -- the extern "C" boundary declared in include/sahs_nerf.h: argument validation,
+// error text, and the chained predict_and_render_radiance launch sequence.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include "../../include/sahs_nerf.h"
+#include "sahs_layout.hpp"
+
+using namespace sahs;
+
+extern "C" {
+int sahs_pack_weights_f32_launch(const float *flat, float *packed, hipStream_t stream);
+int sahs_fold_conditioning_launch(const float *flat, const float *audio, const float *pose, int pose_ld, float *frame, hipStream_t stream);
+int sahs_field_forward_f32_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
+                                  const float *zvals, float *raw, float *dbg, int num_cu, hipStream_t stream);
+int sahs_ray_bundle_launch(int H, int W, float fx, float fy, float cx, float cy, const float *c2w, int ld, float *ro, float *rd,
+                           hipStream_t stream);
+int sahs_stratified_depths_launch(long N, int S, const float *rays, int ray_stride, int lindisp, const float *t_rand, float *z,
+                                  hipStream_t stream);
+int sahs_composite_forward_launch(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
+                                  const float *bg, int white_bkgd, float *rgb_map, float *disp, float *acc_map, float *weights,
+                                  float *depth, float *w_last, hipStream_t stream);
+int sahs_resample_launch(long N, int S, int nf, int from_z, const float *z, const float *weights, const float *u, float *z_samples,
+                         float *z_out, long long *inds, hipStream_t stream);
+}
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, const char *a = "", long b = 0)
+{
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return code;
+}
+static int hip_fail(const char *what, int e)
+{
+    snprintf(g_err, sizeof(g_err), "%s: HIP error %d (%s)", what, e, hipGetErrorString((hipError_t)e));
+    return 100 + e;
+}
+#define REQUIRE(cond, name) do { if (!(cond)) return fail(1, "%s: invalid argument (%ld)", name, (long)__LINE__); } while (0)
+#define ALIGNED16(p) ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)
+
+static int num_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+extern "C" {
+
+int sahs_abi_version(void) { return SAHS_ABI_VERSION; }
+const char *sahs_last_error(void) { return g_err; }
+long sahs_param_count(void) { return kFlat.total; }
+long sahs_packed_words(int precision) { return precision == SAHS_F32 ? PACK_FLOATS : -1; }
+long sahs_frame_words(void) { return FRAME_FLOATS; }
+
+int sahs_pack_weights(const float *flat_params, void *packed, int precision, void *stream)
+{
+    REQUIRE(flat_params && packed, "sahs_pack_weights");
+    REQUIRE(ALIGNED16(packed), "sahs_pack_weights(packed alignment)");
+    if (precision != SAHS_F32) return fail(2, "sahs_pack_weights: precision %s%ld not built", "", precision);
+    int e = sahs_pack_weights_f32_launch(flat_params, (float *)packed, (hipStream_t)stream);
+    return e ? hip_fail("sahs_pack_weights", e) : 0;
+}
+
+int sahs_fold_conditioning(const float *flat_params, const float *audio, const float *pose, int pose_ld, float *frame, void *stream)
+{
+    REQUIRE(flat_params && audio && pose && frame && pose_ld >= 4, "sahs_fold_conditioning");
+    REQUIRE(ALIGNED16(frame), "sahs_fold_conditioning(frame alignment)");
+    int e = sahs_fold_conditioning_launch(flat_params, audio, pose, pose_ld, frame, (hipStream_t)stream);
+    return e ? hip_fail("sahs_fold_conditioning", e) : 0;
+}
+
+int sahs_get_ray_bundle(int H, int W, float fx, float fy, float cx, float cy, const float *c2w, int ld, float *ro, float *rd, void *stream)
+{
+    REQUIRE(H > 0 && W > 0 && c2w && ro && rd && ld >= 4, "sahs_get_ray_bundle");
+    int e = sahs_ray_bundle_launch(H, W, fx, fy, cx, cy, c2w, ld, ro, rd, (hipStream_t)stream);
+    return e ? hip_fail("sahs_get_ray_bundle", e) : 0;
+}
+
+int sahs_stratified_depths(long N, int S, const float *rays, int ray_stride, int lindisp, const float *t_rand, float *z, void *stream)
+{
+    REQUIRE(N >= 0 && S >= 1 && rays && z && ray_stride >= 8, "sahs_stratified_depths");
+    int e = sahs_stratified_depths_launch(N, S, rays, ray_stride, lindisp, t_rand, z, (hipStream_t)stream);
+    return e ? hip_fail("sahs_stratified_depths", e) : 0;
+}
+
+int sahs_field_forward(const void *packed, const float *frame, int level, long N, int S, const float *rays, int ray_stride,
+                       const float *z, float *raw, float *dbg, int precision, void *stream)
+{
+    REQUIRE(packed && frame && rays && z && raw, "sahs_field_forward");
+    REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_field_forward(shape)");
+    REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_field_forward(alignment)");
+    if (precision != SAHS_F32) return fail(2, "sahs_field_forward: precision %s%ld not built", "", precision);
+    int e = sahs_field_forward_f32_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(),
+                                          (hipStream_t)stream);
+    return e ? hip_fail("sahs_field_forward", e) : 0;
+}
+
+int sahs_composite_forward(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
+                           const float *bg, int white_background, float *rgb, float *disp, float *acc, float *weights, float *depth,
+                           void *stream)
+{
+    REQUIRE(raw && z && rays && rgb && disp && acc && weights && depth && ray_stride >= 6, "sahs_composite_forward");
+    REQUIRE(N >= 0 && S >= 1 && S <= 256 && ALIGNED16(raw), "sahs_composite_forward(shape: 1 <= S <= 256)");
+    int e = sahs_composite_forward_launch(N, S, raw, z, rays, ray_stride, noise, bg, white_background, rgb, disp, acc, weights, depth,
+                                          nullptr, (hipStream_t)stream);
+    return e ? hip_fail("sahs_composite_forward", e) : 0;
+}
+
+int sahs_resample(long N, int S, int nf, const float *z, const float *weights, const float *u, float *z_samples, float *z_out,
+                  int64_t *inds, void *stream)
+{
+    REQUIRE(z && weights && z_out, "sahs_resample");
+    REQUIRE(N >= 0 && S >= 3 && S <= 256 && nf >= 1 && nf <= 256, "sahs_resample(shape: 3 <= S <= 256, 1 <= nf <= 256)");
+    int e = sahs_resample_launch(N, S, nf, 1, z, weights, u, z_samples, z_out, (long long *)inds, (hipStream_t)stream);
+    return e ? hip_fail("sahs_resample", e) : 0;
+}
+
+int sahs_sample_pdf(long N, int nb, int ns, const float *bins, const float *weights, const float *u, float *samples, int64_t *inds,
+                    void *stream)
+{
+    REQUIRE(bins && weights && samples, "sahs_sample_pdf");
+    REQUIRE(N >= 0 && nb >= 2 && nb < 256 && ns >= 1 && ns <= 256, "sahs_sample_pdf(shape: 2 <= nb < 256, 1 <= ns <= 256)");
+    int e = sahs_resample_launch(N, nb + 1, ns, 0, bins, weights, u, samples, nullptr, (long long *)inds, (hipStream_t)stream);
+    return e ? hip_fail("sahs_sample_pdf", e) : 0;
+}
+
+int sahs_render_rays(const void *packed, const float *frame, int precision, long N, const float *rays, int ray_stride, int Sc, int nf,
+                     int lindisp, int white_background, const float *bg, const float *t_rand, const float *noise_c, const float *u,
+                     const float *noise_f, float *z_c, float *z_f, float *raw, float *weights, float *rgb_c, float *disp_c,
+                     float *acc_c, float *rgb_f, float *disp_f, float *acc_f, float *w_bg, float *depth_f, void *stream)
+{
+    REQUIRE(packed && frame && rays && z_c && raw && weights && rgb_c && disp_c && acc_c && w_bg && depth_f, "sahs_render_rays");
+    REQUIRE(nf == 0 || (z_f && rgb_f && disp_f && acc_f), "sahs_render_rays(fine outputs)");
+    hipStream_t st = (hipStream_t)stream;
+    int e;
+    if ((e = sahs_stratified_depths(N, Sc, rays, ray_stride, lindisp, t_rand, z_c, stream))) return e;
+    if ((e = sahs_field_forward(packed, frame, 0, N, Sc, rays, ray_stride, z_c, raw, nullptr, precision, stream))) return e;
+    REQUIRE(Sc <= 256, "sahs_render_rays(Sc <= 256)");
+    // depth_f doubles as the coarse depth scratch when there is no fine pass (the reference returns depth_fine only)
+    e = sahs_composite_forward_launch(N, Sc, raw, z_c, rays, ray_stride, noise_c, bg, white_background, rgb_c, disp_c, acc_c, weights,
+                                      depth_f, nf == 0 ? w_bg : nullptr, st);
+    if (e) return hip_fail("sahs_render_rays(composite coarse)", e);
+    if (nf > 0) {
+        const int Sf = Sc + nf;
+        REQUIRE(Sf <= 256, "sahs_render_rays(Sc + nf <= 256)");
+        if ((e = sahs_resample(N, Sc, nf, z_c, weights, u, nullptr, z_f, nullptr, stream))) return e;
+        if ((e = sahs_field_forward(packed, frame, 1, N, Sf, rays, ray_stride, z_f, raw, nullptr, precision, stream))) return e;
+        e = sahs_composite_forward_launch(N, Sf, raw, z_f, rays, ray_stride, noise_f, bg, white_background, rgb_f, disp_f, acc_f,
+                                          weights, depth_f, w_bg, st);
+        if (e) return hip_fail("sahs_render_rays(composite fine)", e);
+    }
+    return 0;
+}
+
+}  // extern "C"

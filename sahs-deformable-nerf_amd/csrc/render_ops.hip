@@ -1,0 +1,293 @@
+// render_ops.hip -- the HBM-bound stages around the field kernel: ray generation, stratified
+// depths, alpha compositing, importance resampling + merge-sort.  Each is one pass over its
+// input with coalesced rows; none of them is on the critical path (<1 % of a frame), so they are
+// written for exact, order-defined arithmetic first (sequential transmittance product, sequential
+// pdf sum / cumsum -- the same orders the CPU oracle uses) and bandwidth second.
+#include <hip/hip_runtime.h>
+#include "sahs_common.hpp"
+#include "sahs_layout.hpp"
+
+namespace sahs {
+
+// ---- get_ray_bundle: nerf_helpers.py:178-233 -------------------------------------------------
+__global__ void ray_bundle_kernel(int H, int W, float fx, float fy, float cx, float cy, const float *__restrict__ c2w, int ld,
+                                  float *__restrict__ ro, float *__restrict__ rd)
+{
+    const long n = (long)H * W;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(e / W), w = (int)(e % W);
+        const float d0 = ((float)w - (float)W * cx) / fx;
+        const float d1 = -((float)h - (float)H * cy) / fy;
+        const float d2 = -1.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float s = d0 * c2w[i * ld + 0];
+            s = s + d1 * c2w[i * ld + 1];
+            s = s + d2 * c2w[i * ld + 2];
+            rd[e * 3 + i] = s;
+            ro[e * 3 + i] = c2w[i * ld + 3];
+        }
+    }
+}
+
+// ---- coarse depths: train_utils.py:93-113 ----------------------------------------------------
+__device__ __forceinline__ float linspace01(int i, int n)   // torch.linspace(0, 1, n)[i]
+{
+    if (n == 1) return 0.0f;
+    const float step = 1.0f / (float)(n - 1);
+    return (i < n / 2) ? step * (float)i : 1.0f - step * (float)(n - 1 - i);
+}
+
+__global__ void stratified_depths_kernel(long N, int S, const float *__restrict__ rays, int ray_stride, int lindisp,
+                                         const float *__restrict__ t_rand, float *__restrict__ z)
+{
+    const long total = N * S;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / S; const int i = (int)(e % S);
+        const float nr = rays[r * ray_stride + 6], fr = rays[r * ray_stride + 7];
+        auto zat = [&](int k) {
+            const float t = linspace01(k, S);
+            return lindisp ? 1.0f / (1.0f / nr * (1.0f - t) + 1.0f / fr * t) : nr * (1.0f - t) + fr * t;
+        };
+        float v = zat(i);
+        if (t_rand != nullptr) {
+            const float upper = (i + 1 < S) ? 0.5f * (zat(i + 1) + v) : v;
+            const float lower = (i > 0) ? 0.5f * (v + zat(i - 1)) : v;
+            v = lower + (upper - lower) * t_rand[e];
+        }
+        z[e] = v;
+    }
+}
+
+// ---- volume_render_radiance_field: volume_rendering_utils.py:7-78 ------------------------------
+// One wave per ray, lane <-> sample (s = 64*i + lane).  Colour/alpha per sample in parallel; the
+// exclusive transmittance product runs in the reference's order (cumprod: ((1*f0)*f1)*...), one
+// step per sample with the factor broadcast from its lane; the 17 weighted sums use a wave
+// butterfly.  bg != null: last sample's 15 colour channels are the prior (train_utils.py:135-136).
+constexpr int COMP_MAX_I = 4;   // S <= 256
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) composite_forward_kernel(long N, int S, const float *__restrict__ raw, const float *__restrict__ z,
+                                                                const float *__restrict__ rays, int ray_stride,
+                                                                const float *__restrict__ noise, const float *__restrict__ bg,
+                                                                int white_bkgd, float *__restrict__ rgb_map, float *__restrict__ disp,
+                                                                float *__restrict__ acc_map, float *__restrict__ weights,
+                                                                float *__restrict__ depth, float *__restrict__ w_last)
+{
+    const int lane = threadIdx.x & 63;
+    const long ray0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * (blockDim.x >> 6);
+    const int NI = (S + 63) >> 6;
+    for (long ray = ray0; ray < N; ray += stride) {
+        const float *rp = rays + ray * ray_stride;
+        const float nrm = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+        float out[15];
+#pragma unroll
+        for (int c = 0; c < 15; ++c) out[c] = 0.0f;
+        float dsum = 0.0f, asum = 0.0f, T = 1.0f;
+        for (int i = 0; i < NI; ++i) {
+            const int s = i * 64 + lane;
+            const bool valid = s < S;
+            const int sc = valid ? s : S - 1;
+            const float *q = raw + (ray * S + sc) * D_RAW;
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const f32x4 *>(q)[k];
+            float col[15];
+            const bool last = (sc == S - 1);
+            if (bg != nullptr) {
+                float seg[12];
+#pragma unroll
+                for (int c = 0; c < 12; ++c) seg[c] = v[(3 + c) >> 2][(3 + c) & 3];
+                float mx = seg[0];
+#pragma unroll
+                for (int c = 1; c < 12; ++c) mx = seg[c] > mx ? seg[c] : mx;
+                float es = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 12; ++c) { seg[c] = expf(seg[c] - mx); es += seg[c]; }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) col[c] = 1.0f / (1.0f + expf(-v[0][c]));
+#pragma unroll
+                for (int c = 0; c < 12; ++c) col[3 + c] = seg[c] / es;
+                if (last) {
+#pragma unroll
+                    for (int c = 0; c < 15; ++c) col[c] = bg[ray * 15 + c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 15; ++c) col[c] = 1.0f / (1.0f + expf(-v[c >> 2][c & 3]));
+            }
+            const float zs = z[ray * S + sc];
+            float dist = last ? 1e10f : (z[ray * S + sc + 1] - zs);
+            dist = dist * nrm;
+            float sg = v[3][3] + (noise != nullptr ? noise[ray * S + sc] : 0.0f);
+            sg = sg > 0.0f ? sg : 0.0f;
+            if (last) sg += 1e-6f;
+            const float alpha = 1.0f - expf(-sg * dist);
+            const float f = (1.0f - alpha) + 1e-10f;
+            // exclusive cumprod in sample order
+            float myT = 1.0f;
+            const int cnt = (S - i * 64) < 64 ? (S - i * 64) : 64;
+            for (int k = 0; k < cnt; ++k) {   // k is wave-uniform: v_readlane broadcasts lane k's factor
+                if (lane == k) myT = T;
+                T = T * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), k));
+            }
+            const float w = valid ? alpha * myT : 0.0f;
+            if (valid) weights[ray * S + s] = w;
+            if (valid && last && w_last != nullptr) w_last[ray] = w;
+#pragma unroll
+            for (int c = 0; c < 15; ++c) out[c] += w * col[c];
+            dsum += w * zs;
+            asum += w;
+        }
+#pragma unroll
+        for (int c = 0; c < 15; ++c) out[c] = wave_sum(out[c]);
+        dsum = wave_sum(dsum);
+        asum = wave_sum(asum);
+        if (white_bkgd) {
+#pragma unroll
+            for (int c = 0; c < 15; ++c) out[c] = out[c] + (1.0f - asum);
+        }
+        if (lane < 15) {
+            float o = out[0];
+#pragma unroll
+            for (int c = 1; c < 15; ++c) o = (lane == c) ? out[c] : o;
+            rgb_map[ray * 15 + lane] = o;
+        }
+        if (lane == 0) {
+            depth[ray] = dsum;
+            acc_map[ray] = asum;
+            const float dd = dsum / asum;
+            disp[ray] = (dd != dd) ? dd : 1.0f / (dd > 1e-10f ? dd : 1e-10f);
+        }
+    }
+}
+
+// ---- sample_pdf_2 + cat + sort: nerf_helpers.py:454-497, train_utils.py:157-166 -----------------
+// One wave per ray.  LDS per wave: cdf[S-1], bins[S-1], merge buffer[S+nf].
+constexpr int RS_MAX = 256;           // S, nf <= 256
+constexpr int RS_WAVES = 4;
+
+// from_z = 1: z (N,S), weights (N,S) are the coarse depths / composite weights; bins = mids(z),
+//             pdf weights = weights[:, 1:-1]; z_out (N,S+nf) = sort(cat(z, samples)).
+// from_z = 0: plain sample_pdf_2 seam: z is bins (N,S-1 columns used as nb = S-1), weights is (N,nb-1); no merge.
+__global__ void __launch_bounds__(RS_WAVES * 64) resample_kernel(long N, int S, int nf, int from_z, const float *__restrict__ z,
+                                                                 const float *__restrict__ weights, const float *__restrict__ u_in,
+                                                                 float *__restrict__ z_samples, float *__restrict__ z_out,
+                                                                 long long *__restrict__ inds_out)
+{
+    __shared__ float s_cdf[RS_WAVES][RS_MAX], s_bins[RS_WAVES][RS_MAX], s_val[RS_WAVES][2 * RS_MAX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *cdf = s_cdf[wv], *bins = s_bins[wv], *val = s_val[wv];
+    const int nb = S - 1;                     // bins; pdf has nb-1 entries
+    const long stride = (long)gridDim.x * RS_WAVES;
+    for (long ray = (long)blockIdx.x * RS_WAVES + wv; ray < N; ray += stride) {
+        if (from_z) {
+            const float *zr = z + ray * S, *wr = weights + ray * S;
+            for (int i = lane; i < S; i += 64) val[i] = zr[i];
+            for (int i = lane; i < nb; i += 64) bins[i] = 0.5f * (zr[i + 1] + zr[i]);
+            for (int i = lane; i < nb - 1; i += 64) cdf[i + 1] = wr[i + 1] + 1e-5f;     // stash w' in cdf[1..]
+        } else {
+            const float *br = z + ray * nb, *wr = weights + ray * (nb - 1);
+            for (int i = lane; i < nb; i += 64) bins[i] = br[i];
+            for (int i = lane; i < nb - 1; i += 64) cdf[i + 1] = wr[i] + 1e-5f;
+        }
+        __builtin_amdgcn_wave_barrier();      // LDS ops of one wave execute in order; this only pins the compiler
+        // sum and cumsum in index order (every lane redundantly; LDS broadcast reads)
+        float sum = 0.0f;
+        for (int i = 1; i < nb; ++i) sum += cdf[i];
+        float c = 0.0f;
+        for (int base = 1; base < nb; base += 64) {
+            const int cnt = (nb - base) < 64 ? (nb - base) : 64;
+            float keep = 0.0f;
+            for (int t = 0; t < cnt; ++t) {
+                c += cdf[base + t] / sum;
+                if (t == lane) keep = c;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < cnt) cdf[base + lane] = keep;   // positions already consumed as w'
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) cdf[0] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < nf; j += 64) {
+            const float u = (u_in != nullptr) ? u_in[ray * nf + j] : linspace01(j, nf);
+            int lo = 0, hi = nb;                   // searchsorted(right=True): first idx with cdf[idx] > u
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+            const int below = lo - 1 > 0 ? lo - 1 : 0;
+            const int above = lo < nb - 1 ? lo : nb - 1;
+            float denom = cdf[above] - cdf[below];
+            if (denom < 1e-5f) denom = 1.0f;
+            const float t = (u - cdf[below]) / denom;
+            const float smp = bins[below] + t * (bins[above] - bins[below]);
+            val[S + j] = smp;
+            if (z_samples != nullptr) z_samples[ray * nf + j] = smp;
+            if (inds_out != nullptr) inds_out[ray * nf + j] = lo;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // rank sort of the S+nf values (ascending; equal values keep index order)
+        const int M = from_z ? S + nf : 0;
+        for (int a = lane; a < M; a += 64) {
+            const float v = val[a];
+            int rank = 0;
+            for (int b = 0; b < M; ++b) {
+                const float o = val[b];
+                rank += (o < v || (o == v && b < a)) ? 1 : 0;
+            }
+            z_out[ray * M + rank] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace sahs
+
+using namespace sahs;
+
+static inline int blocks_for(long n, int per_block, int cap = 4096)
+{
+    long b = (n + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+extern "C" int sahs_ray_bundle_launch(int H, int W, float fx, float fy, float cx, float cy, const float *c2w, int ld, float *ro,
+                                      float *rd, hipStream_t stream)
+{
+    ray_bundle_kernel<<<blocks_for((long)H * W, 256), 256, 0, stream>>>(H, W, fx, fy, cx, cy, c2w, ld, ro, rd);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sahs_stratified_depths_launch(long N, int S, const float *rays, int ray_stride, int lindisp, const float *t_rand,
+                                             float *z, hipStream_t stream)
+{
+    if (N <= 0) return 0;
+    stratified_depths_kernel<<<blocks_for(N * S, 256), 256, 0, stream>>>(N, S, rays, ray_stride, lindisp, t_rand, z);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sahs_composite_forward_launch(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride,
+                                             const float *noise, const float *bg, int white_bkgd, float *rgb_map, float *disp,
+                                             float *acc_map, float *weights, float *depth, float *w_last, hipStream_t stream)
+{
+    if (N <= 0) return 0;
+    if (S < 1 || S > 64 * COMP_MAX_I) return -2;
+    composite_forward_kernel<<<blocks_for(N, 4, 8192), 256, 0, stream>>>(N, S, raw, z, rays, ray_stride, noise, bg, white_bkgd,
+                                                                        rgb_map, disp, acc_map, weights, depth, w_last);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sahs_resample_launch(long N, int S, int nf, int from_z, const float *z, const float *weights, const float *u,
+                                    float *z_samples, float *z_out, long long *inds, hipStream_t stream)
+{
+    if (N <= 0) return 0;
+    if (S < 3 || S > RS_MAX || nf < 1 || nf > RS_MAX) return -2;
+    resample_kernel<<<blocks_for(N, RS_WAVES, 8192), RS_WAVES * 64, 0, stream>>>(N, S, nf, from_z, z, weights, u, z_samples, z_out,
+                                                                                 inds);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,240 @@
+// sahs_layout.hpp -- static description of the per-point network as the field kernels execute it.
+//
+// The reference evaluates, per sample point (models.py:514-528 -> modules.py:371-390, 444-462,
+// 254-295): WarpFieldMLP, HyperSheetMLP, a trilinear feature-grid lookup and NeRFMLP.  The field
+// kernels run these as ONE fixed sequence of dense layers ("layer program") whose activations
+// never leave registers: a layer's MFMA output tile (16 features x 16 points) is, register for
+// register, the B operand of the next layer's MFMA (see field_f32.hip).  This header is the
+// single source of truth for that program: which state_dict tensor feeds each layer, how its
+// columns map onto 16-feature k-blocks, where its bias lives, and how it is cut into the LDS
+// chunks the kernel streams.  pack.hip (weight packer, conditioning fold) and field_*.hip are
+// all generated from this table, so they cannot disagree.
+//
+// Per-frame constants (driving[76] from AudioNet, pose36) are NOT network inputs here: the
+// reference concatenates them to every point (models.py:518,521); we fold W[:, const]*c into the
+// bias once per frame (fold_conditioning in pack.hip), which removes 6.6 % of the MACs and all
+// of the replication traffic.  Algorithmic FLOPs are still counted as the reference writes them.
+#pragma once
+#include <cstdint>
+
+namespace sahs {
+
+// ---- architecture (AudioFaceModel, config/audio/person_2_auto.yml) ----
+constexpr int D_XYZ = 63, D_DIR = 27, D_AMB = 18, D_POSE = 36, D_DRV = 76, D_GRID = 32, G_RES = 32;
+constexpr int WARP_H = 128, HYP_H = 64, TR_H = 256, BR_H = 128, N_SEG = 12, D_RAW = 16;
+constexpr int D_DEF_IN = D_XYZ + D_DRV + D_POSE;   // 175
+constexpr int D_TR_IN = D_XYZ + D_AMB + D_POSE;    // 117
+constexpr int D_DIR_IN = TR_H + D_DIR + D_GRID;    // 315
+constexpr long GRID_FLOATS = (long)D_GRID * G_RES * G_RES * G_RES;
+
+// ---- canonical flat-buffer offsets (state_dict order; must equal weights.py::canonical_spec) ----
+struct FlatOffsets {
+    long grid;
+    long warp_w[6], warp_b[6], warp_fw, warp_fb;
+    long hyp_w[6], hyp_b[6], hyp_fw, hyp_fb;
+    struct Lvl {
+        long xyz_w[8], xyz_b[8], feat_w, feat_b, alpha_w, alpha_b;
+        long dir_w[4], dir_b[4], rgb_w, rgb_b, seg_w[4], seg_b[4], segout_w, segout_b;
+    } lvl[2];
+    long conv_w[4], conv_b[4], fc_w[2], fc_b[2];
+    long total;
+};
+
+constexpr FlatOffsets make_flat_offsets()
+{
+    FlatOffsets f{};
+    long p = 0;
+    f.grid = p; p += GRID_FLOATS;
+    for (int i = 0; i < 6; ++i) {
+        int in = (i == 0) ? D_DEF_IN : (i == 4 ? WARP_H + D_DEF_IN : WARP_H);
+        f.warp_w[i] = p; p += (long)WARP_H * in; f.warp_b[i] = p; p += WARP_H;
+    }
+    f.warp_fw = p; p += 3 * WARP_H; f.warp_fb = p; p += 3;
+    for (int i = 0; i < 6; ++i) {
+        int in = (i == 0) ? D_DEF_IN : (i == 4 ? HYP_H + D_DEF_IN : HYP_H);
+        f.hyp_w[i] = p; p += (long)HYP_H * in; f.hyp_b[i] = p; p += HYP_H;
+    }
+    f.hyp_fw = p; p += 2 * HYP_H; f.hyp_fb = p; p += 2;
+    for (int l = 0; l < 2; ++l) {
+        for (int i = 0; i < 8; ++i) {
+            int in = (i == 0) ? D_TR_IN : (i == 3 ? TR_H + D_TR_IN : TR_H);
+            f.lvl[l].xyz_w[i] = p; p += (long)TR_H * in; f.lvl[l].xyz_b[i] = p; p += TR_H;
+        }
+        f.lvl[l].feat_w = p; p += TR_H * TR_H; f.lvl[l].feat_b = p; p += TR_H;
+        f.lvl[l].alpha_w = p; p += TR_H; f.lvl[l].alpha_b = p; p += 1;
+        for (int i = 0; i < 4; ++i) {
+            int in = (i == 0) ? D_DIR_IN : BR_H;
+            f.lvl[l].dir_w[i] = p; p += (long)BR_H * in; f.lvl[l].dir_b[i] = p; p += BR_H;
+        }
+        f.lvl[l].rgb_w = p; p += 3 * BR_H; f.lvl[l].rgb_b = p; p += 3;
+        for (int i = 0; i < 4; ++i) {
+            int in = (i == 0) ? TR_H : BR_H;
+            f.lvl[l].seg_w[i] = p; p += (long)BR_H * in; f.lvl[l].seg_b[i] = p; p += BR_H;
+        }
+        f.lvl[l].segout_w = p; p += N_SEG * BR_H; f.lvl[l].segout_b = p; p += N_SEG;
+    }
+    constexpr int cin[4] = {29, 32, 32, 64}, cout[4] = {32, 32, 64, 64};
+    for (int i = 0; i < 4; ++i) { f.conv_w[i] = p; p += (long)cout[i] * cin[i] * 3; f.conv_b[i] = p; p += cout[i]; }
+    f.fc_w[0] = p; p += 64 * 64; f.fc_b[0] = p; p += 64;
+    f.fc_w[1] = p; p += D_DRV * 64; f.fc_b[1] = p; p += D_DRV;
+    f.total = p;
+    return f;
+}
+constexpr FlatOffsets kFlat = make_flat_offsets();
+static_assert(kFlat.total == 2775633, "flat parameter count must match the reference state_dict");
+
+// ---- layer program -------------------------------------------------------------------------
+// A layer consumes up to 2 input segments (each a whole number of 16-feature k-blocks, zero
+// padded) and produces NT 16-row output tiles.  Source columns that are per-frame constants are
+// listed separately (folded into the bias by fold_conditioning).
+//
+// Skip layers are split in two so that every wide layer has the same shape: the "B" part
+// multiplies the re-injected input (PE blocks) and carries the bias (+ fold), leaving
+// pre-activations in registers; the "A" part multiplies the hidden state and accumulates onto
+// them, then applies the activation.  Same for the colour branch's first layer (D0B: dirPE+grid,
+// D0A: feat).  ALPHA/RGB/SEG all accumulate into ONE 16-row tile = raw[0:16] = [rgb3|seg12|sigma].
+struct Seg { int blocks; int src_col; int valid; };          // k-blocks, first source column, #valid columns
+struct Fold { int src_col; int count; int which; };          // which: 0 = driving[76], 1 = pose36
+enum LayerId {   // enum order == execution order == stream order
+    L_W0, L_W1, L_W2, L_W3, L_W4B, L_W4A, L_W5, L_WF,
+    L_H0, L_H1, L_H2, L_H3, L_H4B, L_H4A, L_H5, L_HF,
+    L_T0, L_T1, L_T2, L_T3B, L_T3A, L_T4, L_T5, L_T6, L_T7, L_FEAT, L_ALPHA,
+    L_D0B, L_D0A, L_D1, L_D2, L_D3, L_RGB,
+    L_S0, L_S1, L_S2, L_S3, L_SEG,
+    NUM_LAYERS
+};
+struct Layer {
+    long w_off[2];     // offset of the weight tensor in the flat buffer, per level
+    long b_off[2];     // offset of the bias tensor (unused when !has_bias)
+    int src_ld;        // row length (in_features) of the source tensor
+    int src_rows;      // out_features of the source tensor
+    int row_shift;     // source row r lands on output row r + row_shift (FINAL tile packing)
+    int NT;            // 16-row output tiles
+    int KB;            // total k-blocks (sum of seg blocks)
+    int G;             // tiles per LDS chunk
+    int nseg; Seg seg[2];
+    int nfold; Fold fold[2];
+    int has_bias;      // 0: accumulates onto the previous layer's pre-activations
+    int bias_off;      // offset (floats) into the per-level bias array
+    int bias_shared;   // 1: writes its rows of the shared FINAL bias slot
+    long stream_off;   // offset (floats) of the layer's first chunk in the per-level weight stream
+    int first_chunk;   // index of its first chunk in the chunk table
+};
+
+constexpr int CHUNK_FLOATS_MAX = 8192;   // 32 KB LDS staging buffer
+constexpr int pick_G(int KB, int NT)
+{
+    int g = CHUNK_FLOATS_MAX / (KB * 256);
+    if (g > NT) g = NT;
+    while (NT % g) --g;   // largest divisor of NT not above g
+    return g;
+}
+
+struct Program {
+    Layer layer[NUM_LAYERS];
+    int bias_floats;       // per level
+    long stream_floats;    // per level
+    int num_chunks;        // per level
+};
+
+struct Src { long w0, w1, b0, b1; int ld, rows; };
+
+constexpr Layer mk(Src s, int has_bias, int shift, int NT, Seg s0, Seg s1 = {0, 0, 0}, Fold f0 = {0, 0, 0}, Fold f1 = {0, 0, 0})
+{
+    Layer L{};
+    L.w_off[0] = s.w0; L.w_off[1] = s.w1; L.b_off[0] = s.b0; L.b_off[1] = s.b1;
+    L.src_ld = s.ld; L.src_rows = s.rows; L.row_shift = shift; L.NT = NT; L.has_bias = has_bias;
+    L.seg[0] = s0; L.seg[1] = s1;
+    L.nseg = 1 + (s1.blocks > 0);
+    L.KB = s0.blocks + s1.blocks;
+    L.fold[0] = f0; L.fold[1] = f1;
+    L.nfold = (f0.count > 0) + (f1.count > 0);
+    L.G = pick_G(L.KB, NT);
+    return L;
+}
+
+constexpr Program make_program()
+{
+    Program P{};
+    const FlatOffsets &f = kFlat;
+    Layer *L = P.layer;
+    // deformation nets (shared by both levels).  Source columns: [PE63 | driving76 | pose36],
+    // skip layer 4: [h | PE63 | driving76 | pose36]  (modules.py:372-387, 445-459)
+    auto warp = [&](int i, int ld) { return Src{f.warp_w[i], f.warp_w[i], f.warp_b[i], f.warp_b[i], ld, WARP_H}; };
+    auto hyp = [&](int i, int ld) { return Src{f.hyp_w[i], f.hyp_w[i], f.hyp_b[i], f.hyp_b[i], ld, HYP_H}; };
+    L[L_W0] = mk(warp(0, D_DEF_IN), 1, 0, 8, {4, 0, 63}, {0, 0, 0}, {63, 76, 0}, {139, 36, 1});
+    L[L_W1] = mk(warp(1, WARP_H), 1, 0, 8, {8, 0, 128});
+    L[L_W2] = mk(warp(2, WARP_H), 1, 0, 8, {8, 0, 128});
+    L[L_W3] = mk(warp(3, WARP_H), 1, 0, 8, {8, 0, 128});
+    L[L_W4B] = mk(warp(4, WARP_H + D_DEF_IN), 1, 0, 8, {4, 128, 63}, {0, 0, 0}, {191, 76, 0}, {267, 36, 1});
+    L[L_W4A] = mk(warp(4, WARP_H + D_DEF_IN), 0, 0, 8, {8, 0, 128});
+    L[L_W5] = mk(warp(5, WARP_H), 1, 0, 8, {8, 0, 128});
+    L[L_WF] = mk(Src{f.warp_fw, f.warp_fw, f.warp_fb, f.warp_fb, WARP_H, 3}, 1, 0, 1, {8, 0, 128});
+    L[L_H0] = mk(hyp(0, D_DEF_IN), 1, 0, 4, {4, 0, 63}, {0, 0, 0}, {63, 76, 0}, {139, 36, 1});
+    L[L_H1] = mk(hyp(1, HYP_H), 1, 0, 4, {4, 0, 64});
+    L[L_H2] = mk(hyp(2, HYP_H), 1, 0, 4, {4, 0, 64});
+    L[L_H3] = mk(hyp(3, HYP_H), 1, 0, 4, {4, 0, 64});
+    L[L_H4B] = mk(hyp(4, HYP_H + D_DEF_IN), 1, 0, 4, {4, 64, 63}, {0, 0, 0}, {127, 76, 0}, {203, 36, 1});
+    L[L_H4A] = mk(hyp(4, HYP_H + D_DEF_IN), 0, 0, 4, {4, 0, 64});
+    L[L_H5] = mk(hyp(5, HYP_H), 1, 0, 4, {4, 0, 64});
+    L[L_HF] = mk(Src{f.hyp_fw, f.hyp_fw, f.hyp_fb, f.hyp_fb, HYP_H, 2}, 1, 0, 1, {4, 0, 64});
+    // radiance trunk.  Source columns: [PE63(x') | PE18(w) | pose36]; skip layer 3: [h | same]
+    // (modules.py:255-273; skip index is NeRFMLP's default 3, models.py never forwards the YAML's 4)
+    const FlatOffsets::Lvl &c = f.lvl[0], &n = f.lvl[1];
+    auto tr = [&](int i, int ld) { return Src{c.xyz_w[i], n.xyz_w[i], c.xyz_b[i], n.xyz_b[i], ld, TR_H}; };
+    L[L_T0] = mk(tr(0, D_TR_IN), 1, 0, 16, {4, 0, 63}, {2, 63, 18}, {81, 36, 1});
+    L[L_T1] = mk(tr(1, TR_H), 1, 0, 16, {16, 0, 256});
+    L[L_T2] = mk(tr(2, TR_H), 1, 0, 16, {16, 0, 256});
+    L[L_T3B] = mk(tr(3, TR_H + D_TR_IN), 1, 0, 16, {4, 256, 63}, {2, 319, 18}, {337, 36, 1});
+    L[L_T3A] = mk(tr(3, TR_H + D_TR_IN), 0, 0, 16, {16, 0, 256});
+    for (int i = 4; i < 8; ++i) L[L_T4 + (i - 4)] = mk(tr(i, TR_H), 1, 0, 16, {16, 0, 256});
+    L[L_FEAT] = mk(Src{c.feat_w, n.feat_w, c.feat_b, n.feat_b, TR_H, TR_H}, 1, 0, 16, {16, 0, 256});
+    L[L_ALPHA] = mk(Src{c.alpha_w, n.alpha_w, c.alpha_b, n.alpha_b, TR_H, 1}, 1, 15, 1, {16, 0, 256});
+    // colour branch: [feat256 | dirPE27 | grid32] (modules.py:276-287)
+    auto dir = [&](int i, int ld) { return Src{c.dir_w[i], n.dir_w[i], c.dir_b[i], n.dir_b[i], ld, BR_H}; };
+    L[L_D0B] = mk(dir(0, D_DIR_IN), 1, 0, 8, {2, 256, 27}, {2, 283, 32});
+    L[L_D0A] = mk(dir(0, D_DIR_IN), 0, 0, 8, {16, 0, 256});
+    for (int i = 1; i < 4; ++i) L[L_D0A + i] = mk(dir(i, BR_H), 1, 0, 8, {8, 0, 128});
+    L[L_RGB] = mk(Src{c.rgb_w, n.rgb_w, c.rgb_b, n.rgb_b, BR_H, 3}, 1, 0, 1, {8, 0, 128});
+    // seg branch (modules.py:289-294)
+    auto sg = [&](int i, int ld) { return Src{c.seg_w[i], n.seg_w[i], c.seg_b[i], n.seg_b[i], ld, BR_H}; };
+    L[L_S0] = mk(sg(0, TR_H), 1, 0, 8, {16, 0, 256});
+    for (int i = 1; i < 4; ++i) L[L_S0 + i] = mk(sg(i, BR_H), 1, 0, 8, {8, 0, 128});
+    L[L_SEG] = mk(Src{c.segout_w, n.segout_w, c.segout_b, n.segout_b, BR_H, N_SEG}, 1, 3, 1, {8, 0, 128});
+
+    int boff = 0; long soff = 0; int chunk = 0;
+    int final_bias = -1;
+    for (int i = 0; i < NUM_LAYERS; ++i) {
+        const bool fin = (i == L_ALPHA || i == L_RGB || i == L_SEG);
+        if (fin) {
+            if (final_bias < 0) { final_bias = boff; boff += 16; }
+            L[i].bias_off = final_bias; L[i].bias_shared = 1;
+        } else if (L[i].has_bias) {
+            L[i].bias_off = boff; boff += L[i].NT * 16;
+        } else {
+            L[i].bias_off = -1;
+        }
+        L[i].stream_off = soff; L[i].first_chunk = chunk;
+        soff += (long)L[i].NT * L[i].KB * 256;
+        chunk += L[i].NT / L[i].G;
+    }
+    P.bias_floats = boff; P.stream_floats = soff; P.num_chunks = chunk;
+    return P;
+}
+constexpr Program kProg = make_program();
+
+constexpr int BIAS_FLOATS = kProg.bias_floats;             // per level
+constexpr long STREAM_FLOATS = kProg.stream_floats;        // per level
+constexpr int NUM_CHUNKS = kProg.num_chunks;
+
+// ---- device buffers -------------------------------------------------------------------------
+// packed (f32): [grid channel-last: G_RES^3 x 32 floats][level0 stream][level1 stream][chunk table: (NUM_CHUNKS+1) uint32 float-offsets]
+constexpr long PACK_GRID_OFF = 0;
+constexpr long PACK_STREAM_OFF = GRID_FLOATS;
+constexpr long PACK_TABLE_OFF = PACK_STREAM_OFF + 2 * STREAM_FLOATS;
+constexpr long PACK_FLOATS = PACK_TABLE_OFF + ((NUM_CHUNKS + 1 + 3) / 4) * 4;
+// frame: [driving 76 (pad 80)][pose36 (pad 48)][bias level0 BIAS_FLOATS][bias level1]
+constexpr int FRAME_DRV_OFF = 0, FRAME_POSE_OFF = 80, FRAME_BIAS_OFF = 128;
+constexpr int FRAME_FLOATS = FRAME_BIAS_OFF + 2 * BIAS_FLOATS;
+
+}  // namespace sahs

@@ -1,0 +1,137 @@
+"""Drop-in for the field model of ``nerf/models.py`` (AudioFaceModel over NeRFaceModel).
+
+Same constructor-from-config, same ``state_dict`` keys and shapes (the weight
+ABI: ``eval_stage_rays.py:299-303`` does ``getattr(models, cfg.models.mask.type)(cfg)`` followed by
+``load_state_dict``), same call protocol ``model(level, x, audio, pose, pose_c, latent_code=None)``
+-> (P, 16) (``train_utils.py:34``, ``models.py:514``).  The parameters live in ordinary
+``nn.Linear`` / ``nn.Conv1d`` holders so optimisers and checkpoints work unchanged, but nothing is
+evaluated through them: ``forward`` packs them for the HIP field kernel.
+"""
+import torch
+from torch import nn
+
+from . import ops, weights as W
+
+
+def _holder(out_f, in_f):
+    return nn.Linear(in_f, out_f)
+
+
+class _DeformMLP(nn.Module):
+    def __init__(self, list_name, final_name, hidden, out_dim, num_layers, skip):
+        super().__init__()
+        layers = nn.ModuleList()
+        for i in range(num_layers):
+            inp = W.D_DEF_IN if i == 0 else (hidden + W.D_DEF_IN if i == skip else hidden)
+            layers.append(_holder(hidden, inp))
+        setattr(self, list_name, layers)
+        setattr(self, final_name, _holder(out_dim, hidden))
+
+
+class _RadianceMLP(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.layers_xyz = nn.ModuleList()
+        for i in range(W.TR_LAYERS):
+            inp = W.D_TR_IN if i == 0 else (W.TR_H + W.D_TR_IN if i == W.TR_SKIP else W.TR_H)
+            self.layers_xyz.append(_holder(W.TR_H, inp))
+        self.fc_feat = _holder(W.TR_H, W.TR_H)
+        self.fc_alpha = _holder(1, W.TR_H)
+        self.layers_dir = nn.ModuleList([_holder(W.BR_H, W.D_DIR_IN if i == 0 else W.BR_H) for i in range(4)])
+        self.fc_rgb = _holder(3, W.BR_H)
+        self.layers_seg = nn.ModuleList([_holder(W.BR_H, W.TR_H if i == 0 else W.BR_H) for i in range(4)])
+        self.fc_seg = _holder(W.N_SEG, W.BR_H)
+
+
+class _AudioNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        act = lambda: nn.LeakyReLU(0.02, True)   # placeholders keep the Sequential indices 0,2,4,6 / 0,2
+        self.encoder_conv = nn.Sequential(nn.Conv1d(29, 32, 3, 2, 1), act(), nn.Conv1d(32, 32, 3, 2, 1), act(),
+                                          nn.Conv1d(32, 64, 3, 2, 1), act(), nn.Conv1d(64, 64, 3, 2, 1), act())
+        self.encoder_fc1 = nn.Sequential(nn.Linear(64, 64), act(), nn.Linear(64, W.D_DRV))
+
+
+def _check_cfg(cfg):
+    """The kernels are specialised to the architecture every config/audio/*.yml describes."""
+    m = cfg.models
+    want = [(m.warp.use_warp, True), (m.warp.num_layers, 6), (m.warp.hidden_size, 128), (m.warp.skip_connect_every, 4),
+            (m.warp.num_encoding_fn_xyz, 10), (m.hyper.use_ambient, True), (m.hyper.slice_method, "bendy_sheet"),
+            (m.hyper.ambient_coord_dim, 2), (m.hyper.num_layers, 6), (m.hyper.hidden_size, 64), (m.hyper.skip_connect_every, 4),
+            (m.hyper.num_encoding_fn_ambient, 4), (m.hyper.include_input_ambient, True), (m.hyper.include_driving, True),
+            (m.coarse.num_layers, 8), (m.coarse.hidden_size, 256), (m.coarse.num_encoding_fn_xyz, 10), (m.coarse.include_input_xyz, True),
+            (m.coarse.num_encoding_fn_dir, 4), (m.coarse.include_input_dir, True), (m.coarse.use_viewdirs, True),
+            (m.coarse.use_spatial_embeddings, True), (m.coarse.use_pose, True), (m.coarse.include_driving, False)]
+    bad = [(a, b) for a, b in want if a != b]
+    if bad or not hasattr(m, "fine"):
+        raise NotImplementedError("this build covers the AudioFaceModel architecture of config/audio/*.yml; the expression "
+                                  "(NeRFaceModel) variants are SURVEY.md section 8(f)-3. Mismatches: %r" % (bad,))
+
+
+class AudioFaceModel(nn.Module):
+    def __init__(self, cfg, precision="fp32"):
+        super().__init__()
+        _check_cfg(cfg)
+        self.num_coarse = cfg.nerf.train.num_coarse
+        self.num_fine = cfg.nerf.train.num_fine
+        self.precision = ops.PRECISIONS[precision]
+        self.spatial_embeddings = nn.Parameter(torch.randn(1, W.D_GRID, W.G_RES, W.G_RES, W.G_RES) * 0.01)   # models.py:199-201
+        self.warp_field_mlp = _DeformMLP("layers_xyz", "fc_final", W.WARP_H, 3, W.DEF_LAYERS, W.DEF_SKIP)
+        self.hyper_sheep_mlp = _DeformMLP("layers_ambient", "fc_ambient", W.HYP_H, 2, W.DEF_LAYERS, W.DEF_SKIP)
+        self.nerf_mlps = nn.ModuleDict({"coarse": _RadianceMLP(), "fine": _RadianceMLP()})
+        self.audNet_head = _AudioNet()
+        keys = [k for k, _ in W.canonical_spec()]
+        assert list(self.state_dict().keys()) == keys, "state_dict layout drifted from the reference's"
+        self._cache = {}
+
+    # ---- weight plumbing ----
+    def flat_params(self):
+        sd = dict(self.named_parameters())
+        return torch.cat([sd[k].reshape(-1) for k, _ in W.canonical_spec()]).detach().float().contiguous()
+
+    def load_flat(self, flat):
+        off = 0
+        with torch.no_grad():
+            sd = dict(self.named_parameters())
+            for k, shape in W.canonical_spec():
+                n = sd[k].numel()
+                sd[k].copy_(torch.as_tensor(flat[off:off + n]).reshape(shape))
+                off += n
+        return self
+
+    def packed(self, precision=None):
+        """Packed weight stream for the HIP field kernel; re-packed when any parameter changed."""
+        precision = self.precision if precision is None else precision
+        params = list(self.parameters())
+        key = (precision, params[0].device, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        hit = self._cache.get("packed")
+        if hit is None or hit[0] != key:
+            flat = self.flat_params()
+            hit = (key, ops.pack_weights(flat, precision), flat)
+            self._cache["packed"] = hit
+        return hit[1], hit[2]
+
+    def frame(self, audio, pose):
+        """Per-frame conditioning buffer (AudioNet + pose encoding + folded biases): models.py:517-521."""
+        _, flat = self.packed()
+        return ops.fold_conditioning(flat, audio.to(torch.float32), pose.to(torch.float32))
+
+    # ---- B2 seam ----
+    def forward(self, level, x, audio=None, pose=None, pose_c=None, latent_code=None, **kwargs):
+        """models.py:514-528: x (P, >=6) rows [xyz, raw ray direction, ...] -> (P, 16) [rgb3, seg12, sigma]."""
+        if latent_code is not None:
+            raise NotImplementedError("latent codes are not used by the shipped audio configs (latent_code_dim=0)")
+        ops._no_grad_needed(x, audio, *self.parameters())
+        packed, _ = self.packed()
+        frame = self.frame(audio, pose)
+        P = x.shape[0]
+        # a point is a zero-length ray: ro = xyz, z = 0  =>  ro + rd*0 == xyz exactly
+        rays = torch.zeros(P, 8, dtype=torch.float32, device=x.device)
+        rays[:, :6] = x[:, :6]
+        z = torch.zeros(P, 1, dtype=torch.float32, device=x.device)
+        raw = ops.field_forward(packed, frame, 0 if level == "coarse" else 1, rays, z, precision=self.precision)
+        return raw.view(P, 16)
+
+
+# The reference builds the model with getattr(models, cfg.models.mask.type)(cfg); NeRFaceModel
+# (expression-driven, different widths) is the next scope row and is not provided here.

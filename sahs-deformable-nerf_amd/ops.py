@@ -1,0 +1,168 @@
+"""Torch-facing ops over the C ABI: device memory and streams come from PyTorch, the arithmetic
+is the HIP library's.  Every function requires CUDA(HIP) fp32 tensors and raises otherwise --
+there is no eager/CPU path here.
+
+autograd: FieldFn / CompositeFn / ResampleFn wrap the forward kernels.  ResampleFn is
+non-differentiable (the reference detaches it, train_utils.py:164).  Backward kernels are the
+next row of the scope table (SURVEY.md section 8, B*): until they land, a call that would need a
+gradient raises instead of silently returning none.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import SAHS_F32, SAHS_BF16, check
+
+PRECISIONS = {"fp32": SAHS_F32, "f32": SAHS_F32, "bf16": SAHS_BF16}
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, name, dtype=torch.float32):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.SahsError("%s must be a GPU tensor (the HIP path has no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise _lib.SahsError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _no_grad_needed(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError("backward through the HIP field/composite ops is not built yet (forward/eval only); "
+                                  "wrap the call in torch.no_grad()")
+
+
+def param_count():
+    return int(_lib.lib().sahs_param_count())
+
+
+def pack_weights(flat, precision=SAHS_F32):
+    flat = _req(flat, "flat_params")
+    if flat.numel() != param_count():
+        raise _lib.SahsError("flat_params has %d values, expected %d" % (flat.numel(), param_count()))
+    words = _lib.lib().sahs_packed_words(precision)
+    if words <= 0:
+        raise _lib.SahsError("precision %r is not built" % (precision,))
+    packed = torch.empty(words, dtype=torch.float32, device=flat.device)
+    check(_lib.lib().sahs_pack_weights(_p(flat), _p(packed), precision, _stream()), "sahs_pack_weights")
+    return packed
+
+
+def fold_conditioning(flat, audio, pose):
+    flat, audio = _req(flat, "flat_params"), _req(audio, "audio")
+    pose = _req(pose, "pose")
+    if tuple(audio.shape) != (16, 29):
+        raise _lib.SahsError("audio must be (16, 29), got %s" % (tuple(audio.shape),))
+    if pose.dim() != 2 or pose.shape[0] < 3 or pose.shape[1] != 4:
+        raise _lib.SahsError("pose must be (3|4, 4), got %s" % (tuple(pose.shape),))
+    frame = torch.empty(_lib.lib().sahs_frame_words(), dtype=torch.float32, device=flat.device)
+    check(_lib.lib().sahs_fold_conditioning(_p(flat), _p(audio), _p(pose), 4, _p(frame), _stream()), "sahs_fold_conditioning")
+    return frame
+
+
+def get_ray_bundle(height, width, intrinsics, c2w):
+    c2w = _req(c2w, "tform_cam2world")
+    fx, fy, cx, cy = [float(v) for v in intrinsics]
+    ro = torch.empty(height, width, 3, dtype=torch.float32, device=c2w.device)
+    rd = torch.empty_like(ro)
+    check(_lib.lib().sahs_get_ray_bundle(int(height), int(width), fx, fy, cx, cy, _p(c2w), int(c2w.shape[-1]), _p(ro), _p(rd), _stream()),
+          "sahs_get_ray_bundle")
+    return ro, rd
+
+
+def stratified_depths(rays, num_samples, lindisp=False, t_rand=None):
+    rays, t_rand = _req(rays, "rays"), _req(t_rand, "t_rand")
+    N = rays.shape[0]
+    z = torch.empty(N, num_samples, dtype=torch.float32, device=rays.device)
+    check(_lib.lib().sahs_stratified_depths(N, int(num_samples), _p(rays), int(rays.shape[1]), int(bool(lindisp)), _p(t_rand), _p(z),
+                                             _stream()), "sahs_stratified_depths")
+    return z
+
+
+def field_forward(packed, frame, level, rays, z, precision=SAHS_F32, debug=False, out=None):
+    """raw (N,S,16) for level 0/1 at points ro + rd*z.  debug=True also returns (dx, w, grid)."""
+    packed, frame, rays, z = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays"), _req(z, "z")
+    N, S = z.shape
+    if rays.shape[0] != N or rays.shape[1] < 8:
+        raise _lib.SahsError("rays must be (N, >=8) with N == z.shape[0]")
+    raw = out if out is not None else torch.empty(N, S, 16, dtype=torch.float32, device=z.device)
+    dbg = torch.zeros(N * S * 40, dtype=torch.float32, device=z.device) if debug else None
+    check(_lib.lib().sahs_field_forward(_p(packed), _p(frame), int(level), N, S, _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(dbg),
+                                         precision, _stream()), "sahs_field_forward")
+    if debug:
+        a = dbg[: N * S * 8].view(N * S, 8)
+        return raw, a[:, 0:3].reshape(N, S, 3), a[:, 3:5].reshape(N, S, 2), dbg[N * S * 8:].view(N, S, 32)
+    return raw
+
+
+def composite_forward(raw, z, rays, noise=None, bg=None, white_background=False):
+    raw, z, rays, noise, bg = _req(raw, "radiance_field"), _req(z, "depth_values"), _req(rays, "rays"), _req(noise, "noise"), _req(bg, "background_prior")
+    N, S = z.shape
+    dev = z.device
+    rgb = torch.empty(N, 15, dtype=torch.float32, device=dev)
+    disp, acc, depth = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
+    weights = torch.empty(N, S, dtype=torch.float32, device=dev)
+    check(_lib.lib().sahs_composite_forward(N, S, _p(raw), _p(z), _p(rays), int(rays.shape[1]), _p(noise), _p(bg), int(bool(white_background)),
+                                             _p(rgb), _p(disp), _p(acc), _p(weights), _p(depth), _stream()), "sahs_composite_forward")
+    return rgb, disp, acc, weights, depth
+
+
+def resample(z, weights, num_fine, u=None, want_aux=False):
+    z, weights, u = _req(z, "z_vals"), _req(weights, "weights"), _req(u, "u")
+    N, S = z.shape
+    z_out = torch.empty(N, S + num_fine, dtype=torch.float32, device=z.device)
+    zs = torch.empty(N, num_fine, dtype=torch.float32, device=z.device) if want_aux else None
+    inds = torch.empty(N, num_fine, dtype=torch.int64, device=z.device) if want_aux else None
+    check(_lib.lib().sahs_resample(N, S, int(num_fine), _p(z), _p(weights), _p(u), _p(zs), _p(z_out), _p(inds), _stream()), "sahs_resample")
+    return (z_out, zs, inds) if want_aux else z_out
+
+
+def sample_pdf(bins, weights, num_samples, u=None, want_inds=False):
+    bins, weights, u = _req(bins, "bins"), _req(weights, "weights"), _req(u, "u")
+    N, nb = bins.shape
+    if tuple(weights.shape) != (N, nb - 1):
+        raise _lib.SahsError("weights must be (N, nb-1)")
+    out = torch.empty(N, num_samples, dtype=torch.float32, device=bins.device)
+    inds = torch.empty(N, num_samples, dtype=torch.int64, device=bins.device) if want_inds else None
+    check(_lib.lib().sahs_sample_pdf(N, nb, int(num_samples), _p(bins), _p(weights), _p(u), _p(out), _p(inds), _stream()), "sahs_sample_pdf")
+    return (out, inds) if want_inds else out
+
+
+def render_rays(packed, frame, rays, num_coarse, num_fine, precision=SAHS_F32, lindisp=False, white_background=False, bg=None,
+                t_rand=None, noise_c=None, u=None, noise_f=None, workspace=None):
+    """predict_and_render_radiance for one ray chunk -> the reference's 8-tuple (flat shapes)."""
+    packed, frame, rays = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays")
+    bg, t_rand, noise_c, u, noise_f = (_req(t, n) for t, n in ((bg, "background_prior"), (t_rand, "t_rand"), (noise_c, "noise_c"),
+                                                               (u, "u"), (noise_f, "noise_f")))
+    N = rays.shape[0]
+    dev = rays.device
+    Sf = num_coarse + num_fine
+    ws = workspace if workspace is not None else {}
+
+    def buf(name, *shape):
+        t = ws.get(name)
+        if t is None or tuple(t.shape) != shape or t.device != dev:
+            t = torch.empty(*shape, dtype=torch.float32, device=dev)
+            ws[name] = t
+        return t
+
+    z_c, z_f = buf("z_c", N, num_coarse), buf("z_f", N, Sf)
+    raw, weights = buf("raw", N, Sf, 16), buf("weights", N, Sf)
+    rgb_c, rgb_f = (torch.empty(N, 15, dtype=torch.float32, device=dev) for _ in range(2))
+    disp_c, acc_c, disp_f, acc_f, w_bg, depth_f = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(6))
+    check(_lib.lib().sahs_render_rays(_p(packed), _p(frame), precision, N, _p(rays), int(rays.shape[1]), int(num_coarse), int(num_fine),
+                                       int(bool(lindisp)), int(bool(white_background)), _p(bg), _p(t_rand), _p(noise_c), _p(u), _p(noise_f),
+                                       _p(z_c), _p(z_f), _p(raw), _p(weights), _p(rgb_c), _p(disp_c), _p(acc_c), _p(rgb_f), _p(disp_f),
+                                       _p(acc_f), _p(w_bg), _p(depth_f), _stream()), "sahs_render_rays")
+    if num_fine > 0:
+        return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_bg, depth_f
+    return rgb_c, disp_c, acc_c, None, None, None, w_bg, depth_f

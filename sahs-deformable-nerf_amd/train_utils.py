@@ -1,0 +1,98 @@
+"""Drop-in for the render driver ``nerf/train_utils.py`` (seam B1 of SURVEY.md section 8b).
+
+``run_one_iter_of_nerf`` has the reference's signature and return convention
+(train_utils.py:209-321).  Differences are internal: points, encodings and hidden activations
+are never materialised -- each ray chunk is six kernel launches (depths, coarse field,
+composite, resample+sort, fine field, composite) -- and the per-frame conditioning is
+computed once per call instead of once per 131072-point chunk.  Random draws are made with
+torch.rand/torch.randn in the reference's order and shapes per ray chunk, so a
+seeded generator on the same device gives the same stream.
+"""
+import torch
+
+from . import ops
+from .nerf_helpers import get_minibatches
+
+
+def run_network(level, network_fn, pts, ray_batch, chunksize, use_viewdirs, driving=None, pose=None, pose_c=None,
+                latent_code=None, spatial_embeddings=None):
+    """train_utils.py:9-50: evaluate the field at explicit points pts (N,S,3) -> (N,S,16)."""
+    if not use_viewdirs:
+        raise NotImplementedError("the shipped configs set nerf.use_viewdirs: True")
+    flat = pts.reshape((-1, pts.shape[-1]))
+    dirs = ray_batch[..., None, 3:6].expand(pts[..., :3].shape).reshape((-1, 3))
+    x = torch.cat((flat, dirs), dim=-1)
+    out = network_fn(level, x, driving, pose, pose_c, latent_code=latent_code)   # no python chunk loop: the kernel is grid-stride
+    return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])
+
+
+def predict_and_render_radiance(ray_batch, model, options, mode="train", driving=None, pose=None, pose_c=None,
+                                background_prior=None, latent_code=None, spatial_embeddings=None, ray_dirs_fake=None,
+                                _frame=None, _workspace=None):
+    """train_utils.py:72-206 for one ray chunk -> the 8-tuple
+    (rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine, weights_fine[:, -1], depth_fine)."""
+    if latent_code is not None:
+        raise NotImplementedError("latent codes are not used by the shipped audio configs")
+    opt = getattr(options.nerf, mode)
+    ops._no_grad_needed(ray_batch, driving, background_prior, *model.parameters())
+    rays = ray_batch.to(torch.float32)
+    if not rays.is_contiguous():
+        rays = rays.contiguous()
+    N, dev = rays.shape[0], rays.device
+    packed, _ = model.packed()
+    frame = _frame if _frame is not None else model.frame(driving, pose)
+    noise_std = float(opt.radiance_field_noise_std)
+    nc, nf = int(opt.num_coarse), int(opt.num_fine)
+    # draw order of the reference: rand(N,nc) [perturb] -> randn(N,nc) [noise] -> rand(N,nf) [perturb] -> randn(N,nc+nf) [noise]
+    t_rand = torch.rand((N, nc), dtype=torch.float32, device=dev) if opt.perturb else None
+    noise_c = torch.randn((N, nc), dtype=torch.float32, device=dev) * noise_std if noise_std > 0.0 else None
+    u = torch.rand((N, nf), dtype=torch.float32, device=dev) if (nf > 0 and opt.perturb != 0.0) else None
+    noise_f = torch.randn((N, nc + nf), dtype=torch.float32, device=dev) * noise_std if (nf > 0 and noise_std > 0.0) else None
+    bg = None
+    if background_prior is not None:
+        if background_prior.shape[-1] != 15:
+            raise NotImplementedError("background_prior must have 15 channels (rgb3 + seg12)")
+        bg = background_prior.to(torch.float32)
+    return ops.render_rays(packed, frame, rays, nc, nf, precision=model.precision, lindisp=bool(opt.lindisp),
+                           white_background=bool(opt.white_background), bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f,
+                           workspace=_workspace)
+
+
+def run_one_iter_of_nerf(height, width, focal_length, model, ray_origins, ray_directions, options, mode="train", driving=None,
+                         pose=None, pose_c=None, background_prior=None, latent_code=None, ray_directions_ablation=None,
+                         spatial_embeddings=None, inHead=None):
+    """train_utils.py:209-321.  height/width/focal_length are unused when dataset.no_ndc is True (as there)."""
+    if options.dataset.no_ndc is False:
+        raise NotImplementedError("NDC rays: the reference's own no_ndc=False branch is dead (NameError at train_utils.py:263)")
+    ro = ray_origins.reshape((-1, 3))
+    rd = ray_directions.reshape((-1, 3))
+    near = options.dataset.near * torch.ones_like(rd[..., :1])
+    far = options.dataset.far * torch.ones_like(rd[..., :1])
+    parts = [ro, rd, near, far]
+    if inHead is not None:
+        parts.append(inHead.reshape((-1, inHead.shape[-1])).to(ro.dtype))   # carried for layout parity; the model never reads it (models.py:516)
+    rays = torch.cat(parts, dim=-1)
+    chunk = int(getattr(options.nerf, mode).chunksize)
+    batches = get_minibatches(rays, chunksize=chunk)
+    bgs = get_minibatches(background_prior, chunksize=chunk) if background_prior is not None else None
+    frame = model.frame(driving, pose)          # once per call (the reference recomputes it per point-chunk)
+    workspace = {}
+    pred = [predict_and_render_radiance(b, model, options, mode, driving=driving, pose=pose, pose_c=pose_c,
+                                        background_prior=bgs[i] if bgs is not None else None, latent_code=latent_code,
+                                        _frame=frame, _workspace=workspace if len(batches) == 1 or b.shape[0] == chunk else None)
+            for i, b in enumerate(batches)]
+    images = [torch.cat(im, dim=0) if im[0] is not None else None for im in zip(*pred)]
+    if mode == "validation":
+        shape3, shape2 = tuple(ray_directions.shape), tuple(ray_directions.shape[:-1])
+        shapes = [shape3, shape2, shape2]
+        if hasattr(options.models, "fine"):
+            shapes = shapes + shapes + [shape2, shape2]
+        if options.models.mask.use_mask and images[0].shape[-1] == 15:
+            shapes[0] = shape2 + (15,)
+            if len(shapes) > 3:
+                shapes[3] = shape2 + (15,)
+        images = [im.view(s) if im is not None else None for im, s in zip(images, shapes)]
+        if hasattr(options.models, "fine"):
+            return tuple(images)
+        return tuple(images + [None, None, None])
+    return tuple(images)
