@@ -60,8 +60,8 @@ int sahs_stratified_depths(long N, int S, const float *rays, int ray_stride, int
 
 /* run_network + model forward (train_utils.py:9-50 -> models.py:514-528) for level 0 (coarse)
  * or 1 (fine), including pts = ro + rd*z (train_utils.py:115,168).  z: (N,S); raw: (N,S,16) =
- * [rgb3, seg12, sigma].  dbg: NULL, or N*S*40 floats receiving [N*S x 8: dx3, w2, pad][N*S x 32:
- * grid features] (test seam). */
+ * [rgb3, seg12, sigma].  dbg: NULL, or N*S*88 floats receiving [N*S x 56: dx3, w2, first feature of
+ * selected hidden layers][N*S x 32: grid features] (test seam). */
 int sahs_field_forward(const void *packed, const float *frame, int level, long N, int S, const float *rays, int ray_stride,
                        const float *z, float *raw, float *dbg, int precision, void *stream);
 

@@ -29,6 +29,7 @@ namespace sahs {
 constexpr int F32_THREADS = 512;
 constexpr int F32_PTS_PER_WAVE = 16;
 constexpr int F32_PTS_PER_WG = (F32_THREADS / WAVE) * F32_PTS_PER_WAVE;   // 128
+constexpr int DBG_STRIDE = 56;   // test seam: [dx3, w2, T0[0], trunk layers 1..8 [0], D0[0], D3[0], S0[0], S3[0], pad]
 constexpr int LDS_BUF_FLOATS = CHUNK_FLOATS_MAX;                           // 32 KB each, two of them
 constexpr int LDS_BIAS_OFF = 2 * LDS_BUF_FLOATS;
 constexpr int LDS_FLOATS = LDS_BIAS_OFF + ((BIAS_FLOATS + 3) / 4) * 4;
@@ -45,15 +46,16 @@ struct Ctx {
     const uint32_t *table;    // chunk start offsets (floats), NUM_CHUNKS + 1 entries
     float *lds;               // dynamic LDS base
     int chunk;                // index of the chunk currently resident (uniform)
+    int buf;                  // LDS buffer (0/1) holding it; toggles per chunk (NUM_CHUNKS is odd, the stream wraps)
     int lane, q, wave;
 
-    // async copy of chunk c into buffer c&1: global_load_lds writes LDS at (wave-uniform base + lane*16)
-    __device__ __forceinline__ void issue(int c)
+    // async copy of chunk c into buffer b: global_load_lds writes LDS at (wave-uniform base + lane*16)
+    __device__ __forceinline__ void issue(int c, int b)
     {
         const uint32_t o0 = table[c], o1 = table[c + 1];
         const int n16 = (int)(o1 - o0) >> 2;
         const f32x4 *src = reinterpret_cast<const f32x4 *>(stream + o0);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(lds + (c & 1) * LDS_BUF_FLOATS);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(lds + b * LDS_BUF_FLOATS);
         for (int base = wave * WAVE; base < n16; base += F32_THREADS)
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + base + lane), (lds_ptr_t)(dst + base), 16, 0, 0);
     }
@@ -61,14 +63,15 @@ struct Ctx {
     {
         int nxt = chunk + 1;
         if (nxt == NUM_CHUNKS) nxt = 0;
-        issue(nxt);
+        issue(nxt, buf ^ 1);
     }
     __device__ __forceinline__ void end_chunk()
     {
         __syncthreads();   // drains the in-flight global_load_lds (vmcnt(0)) and orders buffer reuse
         chunk = (chunk + 1 == NUM_CHUNKS) ? 0 : chunk + 1;
+        buf ^= 1;
     }
-    __device__ __forceinline__ const f32x4 *cur() const { return reinterpret_cast<const f32x4 *>(lds + (chunk & 1) * LDS_BUF_FLOATS); }
+    __device__ __forceinline__ const f32x4 *cur() const { return reinterpret_cast<const f32x4 *>(lds + buf * LDS_BUF_FLOATS); }
     __device__ __forceinline__ f32x4 bias4(int off) const   // off: float offset of a 16-row tile's bias
     {
         return *reinterpret_cast<const f32x4 *>(lds + LDS_BIAS_OFF + off + 4 * q);
@@ -206,6 +209,7 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
     cx.table = reinterpret_cast<const uint32_t *>(packed + PACK_TABLE_OFF);
     cx.lds = lds;
     cx.chunk = 0;
+    cx.buf = 0;
     cx.lane = threadIdx.x & 63;
     cx.q = cx.lane >> 4;
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -215,7 +219,7 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
     {   // per-level biases (static + folded conditioning) -> LDS, first weight chunk -> buffer 0
         const float *bsrc = frame + FRAME_BIAS_OFF + level * BIAS_FLOATS;
         for (int i = threadIdx.x; i < BIAS_FLOATS; i += F32_THREADS) lds[LDS_BIAS_OFF + i] = bsrc[i];
-        cx.issue(0);
+        cx.issue(0, 0);
         __syncthreads();
     }
     constexpr const Layer *Ly = kProg.layer;
@@ -276,10 +280,9 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
             amb[0] = bcast16(o[0][0], cx.lane);
             amb[1] = bcast16(o[0][1], cx.lane);
         }
-        if (dbg != nullptr && q == 0 && p_raw < P) {
-            float *d = dbg + p * 8;
-            d[0] = xw[0] - x[0]; d[1] = xw[1] - x[1]; d[2] = xw[2] - x[2]; d[3] = amb[0]; d[4] = amb[1];
-        }
+        const bool dump = dbg != nullptr && q == 0 && p_raw < P;   // lanes holding feature 0 of tile 0
+        float *dsl = dbg + p * DBG_STRIDE;
+        if (dump) { dsl[0] = xw[0] - x[0]; dsl[1] = xw[1] - x[1]; dsl[2] = xw[2] - x[2]; dsl[3] = amb[0]; dsl[4] = amb[1]; }
 
         // ---- radiance trunk (modules.py:254-275) ----
         f32x4 fin[1];      // FINAL tile: raw[4q..4q+3] of this lane's point
@@ -290,12 +293,14 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
             pe_blocks<2, 4, 2>(amb, q, in_tr + 4);
             f32x4 h[16];
             dense<4, 2, 16>(cx, in_tr, in_tr + 4, h, Ly[L_T0].bias_off, false, 0.01f);
+            if (dump) dsl[5] = h[0][0];
             // T1, T2, [T3B], T3A, T4..T7, FEAT: eight 256x256 layers
 #pragma unroll 1
             for (int l = 1; l <= 8; ++l) {
                 if (l == 3) dense<4, 2, 16>(cx, in_tr, in_tr + 4, feat, Ly[L_T3B].bias_off, false, 1.0f);
                 const int boff = (l < 3) ? Ly[L_T1].bias_off + 256 * (l - 1) : (l == 3 ? 0 : Ly[L_T4].bias_off + 256 * (l - 4));
                 dense<16, 0, 16>(cx, h, nullptr, feat, boff, l == 3, l == 8 ? 1.0f : 0.01f);
+                if (dump) dsl[5 + l] = feat[0][0];
                 if (l < 8) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) h[i] = feat[i];
@@ -303,37 +308,43 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
             }
         }
         dense<16, 0, 1>(cx, feat, nullptr, fin, Ly[L_ALPHA].bias_off, false, 1.0f);
+        if (dbg != nullptr && p_raw < P) *reinterpret_cast<f32x4 *>(dsl + 24 + 4 * q) = fin[0];
         // ---- colour branch (modules.py:276-287) ----
         {
             f32x4 in_d[4];
             pe_blocks<3, 4, 2>(rd, q, in_d);                          // models.py:340 (raw, un-normalised direction)
             grid_blocks(grid, xw[0], xw[1], xw[2], q, in_d + 2);      // models.py:525
             if (dbg != nullptr && p_raw < P) {
-                float *d = dbg + P * 8 + p * 32;
+                float *d = dbg + P * DBG_STRIDE + p * 32;
                 *reinterpret_cast<f32x4 *>(d + 4 * q) = in_d[2];
                 *reinterpret_cast<f32x4 *>(d + 16 + 4 * q) = in_d[3];
             }
             f32x4 c[8], cn[8];
             dense<2, 2, 8>(cx, in_d, in_d + 2, c, Ly[L_D0B].bias_off, false, 1.0f);
             dense<16, 0, 8>(cx, feat, nullptr, c, 0, true, 0.01f);
+            if (dump) dsl[14] = c[0][0];
 #pragma unroll 1
             for (int l = 0; l < 3; ++l) {
                 dense<8, 0, 8>(cx, c, nullptr, cn, Ly[L_D1].bias_off + 128 * l, false, 0.01f);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) c[i] = cn[i];
             }
+            if (dump) dsl[15] = c[0][0];
             dense<8, 0, 1>(cx, c, nullptr, fin, 0, true, 1.0f);
+            if (dbg != nullptr && p_raw < P) *reinterpret_cast<f32x4 *>(dsl + 40 + 4 * q) = fin[0];
         }
         // ---- seg branch (modules.py:289-294) ----
         {
             f32x4 s[8], sn[8];
             dense<16, 0, 8>(cx, feat, nullptr, s, Ly[L_S0].bias_off, false, 0.01f);
+            if (dump) dsl[16] = s[0][0];
 #pragma unroll 1
             for (int l = 0; l < 3; ++l) {
                 dense<8, 0, 8>(cx, s, nullptr, sn, Ly[L_S1].bias_off + 128 * l, false, 0.01f);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s[i] = sn[i];
             }
+            if (dump) dsl[17] = s[0][0];
             dense<8, 0, 1>(cx, s, nullptr, fin, 0, true, 1.0f);
         }
         if (p_raw < P) *reinterpret_cast<f32x4 *>(raw + p * D_RAW + 4 * q) = fin[0];   // cat((rgb, seg, alpha)) modules.py:295
@@ -344,7 +355,7 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
 
 using namespace sahs;
 
-// dbg (optional, may be null): [P x 8: dx3, w2, pad3][P x 32: grid features]
+// dbg (optional, may be null): [P x 24: see DBG_STRIDE][P x 32: grid features]
 extern "C" int sahs_field_forward_f32_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays,
                                              int ray_stride, const float *zvals, float *raw, float *dbg, int num_cu,
                                              hipStream_t stream)

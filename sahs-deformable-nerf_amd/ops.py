@@ -95,12 +95,14 @@ def field_forward(packed, frame, level, rays, z, precision=SAHS_F32, debug=False
     if rays.shape[0] != N or rays.shape[1] < 8:
         raise _lib.SahsError("rays must be (N, >=8) with N == z.shape[0]")
     raw = out if out is not None else torch.empty(N, S, 16, dtype=torch.float32, device=z.device)
-    dbg = torch.zeros(N * S * 40, dtype=torch.float32, device=z.device) if debug else None
+    dbg = torch.zeros(N * S * 88, dtype=torch.float32, device=z.device) if debug else None
     check(_lib.lib().sahs_field_forward(_p(packed), _p(frame), int(level), N, S, _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(dbg),
                                          precision, _stream()), "sahs_field_forward")
+    if debug == "full":
+        return raw, dbg[: N * S * 56].view(N * S, 56), dbg[N * S * 56:].view(N * S, 32)
     if debug:
-        a = dbg[: N * S * 8].view(N * S, 8)
-        return raw, a[:, 0:3].reshape(N, S, 3), a[:, 3:5].reshape(N, S, 2), dbg[N * S * 8:].view(N, S, 32)
+        a = dbg[: N * S * 56].view(N * S, 56)
+        return raw, a[:, 0:3].reshape(N, S, 3), a[:, 3:5].reshape(N, S, 2), dbg[N * S * 56:].view(N, S, 32)
     return raw
 
 
