@@ -77,7 +77,7 @@ def main():
     R = H * W
     opt = cfg.nerf.validation
     nc, nf, chunk = int(opt.num_coarse), int(opt.num_fine), int(opt.chunksize)
-    lo, hi = rank * R // world, (rank + 1) * R // world       # this rank's contiguous ray block
+    lo, hi = pkg.distributed.shard_bounds(R, world, rank)     # this rank's contiguous ray block
     near, far = float(cfg.dataset.near), float(cfg.dataset.far)
     packed, _ = model.packed()
     torch.manual_seed(cfg.experiment.randomseed + rank)
@@ -118,11 +118,7 @@ def main():
                 field_events.append((e0, e1, N * nc))
                 field_events.append((e2, e3, N * (nc + nf)))
         mine = torch.cat(outs, dim=0)
-        if world > 1:
-            full = torch.empty(world * mine.shape[0], 36, device=dev)
-            dist.all_gather_into_tensor(full, mine)
-            return full
-        return mine
+        return pkg.distributed.all_gather_rows(mine, R) if world > 1 else mine   # RCCL all-gather of 36 floats/ray
 
     def barrier():
         if world > 1:

@@ -1,0 +1,59 @@
+"""Ray sharding across GPUs (one process per GPU, torch.distributed: backend "nccl" = RCCL on ROCm).
+
+Rays are independent: rank r of N renders the contiguous block
+[r*R/N, (r+1)*R/N) of the flattened ray list with replicated weights and per-frame conditioning,
+nothing is exchanged while rendering, and ONE all-gather of the per-ray outputs (36 floats/ray:
+the reference's 8-tuple) assembles the frame on every rank.  On a fully connected xGMI node the
+all-gather moves 4.7 MB per rank per 512x512 frame -- microseconds against the render.
+The functions are backend-agnostic (the CPU tests run them over gloo).
+"""
+import torch
+import torch.distributed as dist
+
+OUT_COLUMNS = 36   # rgb_c 15, disp_c, acc_c, rgb_f 15, disp_f, acc_f, w_bg, depth_f
+
+
+def shard_bounds(num_rays, world, rank):
+    """Contiguous, balanced, order-preserving: concatenating shards 0..world-1 restores the ray order."""
+    return rank * num_rays // world, (rank + 1) * num_rays // world
+
+
+def pack_outputs(outs):
+    """8-tuple (flat shapes) -> (n, 36) rows."""
+    cols = [o if o.dim() == 2 else o[:, None] for o in outs]
+    return torch.cat(cols, dim=1)
+
+
+def unpack_outputs(rows):
+    """(n, 36) rows -> the reference's 8-tuple (flat shapes)."""
+    r = rows
+    return (r[:, 0:15], r[:, 15], r[:, 16], r[:, 17:32], r[:, 32], r[:, 33], r[:, 34], r[:, 35])
+
+
+def all_gather_rows(rows, num_rays, group=None):
+    """Gather per-rank row blocks (shard_bounds order) into the full (num_rays, C) tensor on every rank."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return rows
+    sizes = [shard_bounds(num_rays, world, r)[1] - shard_bounds(num_rays, world, r)[0] for r in range(world)]
+    if len(set(sizes)) == 1:
+        full = torch.empty(num_rays, rows.shape[1], dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(full, rows.contiguous(), group=group)
+        return full
+    mx = max(sizes)   # ragged: pad to the largest shard, gather, trim
+    pad = torch.zeros(mx, rows.shape[1], dtype=rows.dtype, device=rows.device)
+    pad[: rows.shape[0]] = rows
+    full = torch.empty(world * mx, rows.shape[1], dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(full, pad, group=group)
+    return torch.cat([full[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
+
+
+def render_sharded(render_fn, num_rays, group=None):
+    """render_fn(lo, hi) -> 8-tuple for rays [lo, hi); returns the full-frame 8-tuple on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(num_rays, world, rank)
+    rows = pack_outputs(render_fn(lo, hi))
+    if world > 1:
+        rows = all_gather_rows(rows, num_rays, group)
+    return unpack_outputs(rows)

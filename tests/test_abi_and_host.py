@@ -1,0 +1,119 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/sahs_nerf.h declares
+(no compute calls without a GPU), the host logic, and that the product has no CPU/oracle fallback."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, pkg
+
+
+def header_functions():
+    text = open(os.path.join(REPO, "include", "sahs_nerf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sahs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = pkg("_lib")
+    names = header_functions()
+    assert len(names) >= 14
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for n in names:
+        assert hasattr(so, n), "libsahs_nerf.so lacks %s" % n
+    assert sorted(lib.SIGNATURES) == names, "ctypes SIGNATURES and the header disagree"
+    L = lib.lib()
+    assert L.sahs_abi_version() == 1
+    assert L.sahs_param_count() == 2_775_633
+    assert L.sahs_packed_words(lib.SAHS_F32) > L.sahs_param_count()
+    assert L.sahs_frame_words() > 4000
+
+
+def test_no_cpu_fallback():
+    ops, lib = pkg("ops"), pkg("_lib")
+    z = torch.zeros(4, 8)
+    with pytest.raises(lib.SahsError):
+        ops.composite_forward(torch.zeros(4, 8, 16), z, torch.zeros(4, 8))
+    with pytest.raises(lib.SahsError):
+        ops.pack_weights(torch.zeros(2_775_633))
+
+
+def test_product_never_touches_the_oracle():
+    root = os.path.join(REPO, "sahs-deformable-nerf_amd")
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, os.path.join(dp, f)
+    for f in ("bench.py",):
+        src = open(os.path.join(REPO, f)).read()
+        assert src.count("from oracle import") == 1, "bench.py may use the oracle only in its cpu_baseline leg"
+
+
+def test_model_state_dict_is_the_reference_layout(weights_mod):
+    sahs = pkg()
+    m = sahs.AudioFaceModel(sahs.default_config())
+    sd = m.state_dict()
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(k, tuple(s)) for k, s in weights_mod.canonical_spec()]
+    flat = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(3))
+    m.load_flat(flat)
+    assert np.array_equal(m.flat_params().numpy(), flat)
+    # a reference-style checkpoint round-trips through load_state_dict
+    m2 = sahs.AudioFaceModel(sahs.default_config())
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in weights_mod.hash_state_dict(3).items()})
+    assert torch.equal(m2.flat_params(), m.flat_params())
+
+
+def test_unsupported_architecture_is_rejected():
+    sahs = pkg()
+    cfg = sahs.default_config()
+    cfg.models.warp.hidden_size = 64
+    with pytest.raises(NotImplementedError):
+        sahs.AudioFaceModel(cfg)
+
+
+def test_cfgnode():
+    sahs = pkg()
+    cfg = sahs.default_config()
+    assert cfg.nerf.validation.num_coarse == 64 and getattr(cfg.nerf, "train").radiance_field_noise_std == 0.1
+    assert hasattr(cfg.models, "fine") and not hasattr(cfg.models, "nope")
+    c2 = cfg.clone()
+    c2.nerf.train.num_fine = 7
+    assert cfg.nerf.train.num_fine == 64
+    assert abs(cfg.dataset.near - 0.483771014213562) < 1e-15
+
+
+def test_hash_weights_are_deterministic(weights_mod):
+    a = weights_mod.hash_state_dict(0)
+    b = weights_mod.hash_state_dict(0)
+    c = weights_mod.hash_state_dict(1)
+    k = "nerf_mlps.fine.layers_xyz.3.weight"
+    assert np.array_equal(a[k], b[k]) and not np.array_equal(a[k], c[k])
+    assert abs(float(a[k].max()) - 1 / np.sqrt(373)) < 2e-3 and a[k].shape == (256, 373)
+    boosted = weights_mod.hash_state_dict(0, 8.0, 30.0)
+    assert np.allclose(boosted["nerf_mlps.coarse.fc_alpha.bias"], a["nerf_mlps.coarse.fc_alpha.bias"] + 8.0)
+
+
+def test_masked_losses_match_their_definition():
+    """nerf_helpers.py:14-62 (caller side of config[4])."""
+    H = pkg("nerf_helpers")
+    g = torch.Generator().manual_seed(0)
+    n = 50
+    mask = torch.zeros(n, 12)
+    mask[torch.arange(n), torch.randint(0, 11, (n,), generator=g)] = 1.0    # class 11 never occurs: count clamps to 1
+    a, b = torch.rand(n, 3, generator=g), torch.rand(n, 3, generator=g)
+    glob, per, wper = H.MaskMSELoss()(mask, a, b)
+    d = ((a - b) ** 2).sum(-1)
+    assert torch.allclose(glob, d.mean())
+    for c in range(12):
+        cnt = max(1.0, float(mask[:, c].sum()))
+        assert torch.allclose(per[c], (d * mask[:, c]).sum() / cnt)
+    assert float(per[11]) == 0.0 and torch.equal(per, wper)
+    p = torch.softmax(torch.rand(n, 12, generator=g), -1)
+    glob, per, _ = H.MaskCrossEntropyLoss()(mask, p, mask)
+    ce = -(mask * torch.log(p + 1e-10)).sum(-1)
+    assert torch.allclose(glob, ce.mean()) and torch.allclose(per[3], (ce * mask[:, 3]).sum() / max(1.0, float(mask[:, 3].sum())))
+    assert abs(H.mse2psnr(0.01) - 20.0) < 1e-12 and H.mse2psnr(0) == 50.0
