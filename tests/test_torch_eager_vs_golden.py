@@ -1,0 +1,85 @@
+"""Pin the torch-eager restatement (oracle/torch_eager.py: gradient oracle + "reference PyTorch path" baseline)
+to the real reference's golden vectors: forward seams, end-to-end renders and parameter gradients."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_rand, load_golden
+from oracle import torch_eager as TE
+
+
+def sd_torch(weights_mod, seed, bias, gain, requires_grad=False):
+    sd = {k: torch.from_numpy(v.copy()) for k, v in weights_mod.hash_state_dict(seed, bias, gain).items()}
+    if requires_grad:
+        for v in sd.values():
+            v.requires_grad_(True)
+    return sd
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    err = np.abs(a.astype(np.float64) - np.asarray(b, np.float64))
+    tol = atol + rtol * np.abs(np.asarray(b, np.float64))
+    assert a.shape == np.asarray(b).shape, (what, a.shape, np.asarray(b).shape)
+    assert np.all(err <= tol), "%s: max err %.3e" % (what, err.max())
+
+
+@pytest.mark.parametrize("variant,kw", [("default", (0, 0.0, 1.0)), ("boosted", (0, 8.0, 30.0))])
+def test_field(weights_mod, variant, kw):
+    g = load_golden("field")
+    f = TE.EagerField(sd_torch(weights_mod, *kw))
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        for lvl in ("coarse", "fine"):
+            out = f.forward(lvl, x, torch.from_numpy(g["audio"]), torch.from_numpy(g["pose"]))
+            close(out, g[variant + "_raw_" + lvl], 1e-4, 1e-5 * (30 if variant == "boosted" else 1), "raw " + lvl)
+
+
+def _rand_chunks(g, nchunks):
+    log = golden_rand(g)
+    per = len(log) // nchunks
+    keys = {4: ["t_rand", "noise_c", "u", "noise_f"], 2: ["t_rand", "u"], 0: []}[per]
+    std = float(g["noise_std"]) if "noise_std" in g else 0.1
+    return [{k: torch.from_numpy(arr) * (std if k.startswith("noise") else 1.0) for k, (_, arr) in zip(keys, log[c * per:(c + 1) * per])}
+            for c in range(nchunks)]
+
+
+@pytest.mark.parametrize("name,nchunks", [("e2e_boosted_val", 1), ("e2e_boosted_val_2chunks", 2), ("e2e_boosted_det", 1),
+                                          ("e2e_boosted_train_noise", 1)])
+def test_end_to_end(weights_mod, name, nchunks):
+    g = load_golden(name)
+    f = TE.EagerField(sd_torch(weights_mod, int(g["weights_seed"]), float(g["weights_density_bias"]), float(g["weights_density_gain"])))
+    with torch.no_grad():
+        outs = TE.run_one_iter(f, torch.from_numpy(g["ro"]), torch.from_numpy(g["rd"]), float(g["near"]), float(g["far"]),
+                               torch.from_numpy(g["audio"]), torch.from_numpy(g["pose"]), chunksize=int(g["chunksize"]),
+                               bg=torch.from_numpy(g["bg"]), rand=_rand_chunks(g, nchunks), perturb=bool(g["perturb"]),
+                               noise_std=float(g["noise_std"]))
+    for nm, o in zip(["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"], outs):
+        close(o, g["out_" + nm].reshape(o.shape), 1e-4, 2e-5, name + ":" + nm)
+
+
+def test_gradients(weights_mod):
+    """config[4] semantics: train mode, noise 0.1, loss = <rgb_c,A> + <rgb_f,B> + 0.1*sum(depth_f)."""
+    g = load_golden("train_grads")
+    sd = sd_torch(weights_mod, 0, 8.0, 30.0, requires_grad=True)
+    f = TE.EagerField(sd)
+    audio = torch.from_numpy(g["audio"]).requires_grad_(True)
+    mask = torch.zeros(32, 12)
+    mask[:, 0] = 1.0
+    log = golden_rand(g)
+    rand = [dict(t_rand=torch.from_numpy(log[0][1]), noise_c=torch.from_numpy(log[1][1]) * 0.1, u=torch.from_numpy(log[2][1]),
+                 noise_f=torch.from_numpy(log[3][1]) * 0.1)]
+    outs = TE.run_one_iter(f, torch.from_numpy(g["ro"]), torch.from_numpy(g["rd"]), float(g["near"]), float(g["far"]), audio,
+                           torch.from_numpy(g["pose"]), bg=torch.from_numpy(g["bg"]), rand=rand, perturb=True, noise_std=0.1, mask=mask)
+    loss = (outs[0] * torch.from_numpy(g["A"])).sum() + (outs[3] * torch.from_numpy(g["B"])).sum() + outs[7].sum() * 0.1
+    assert abs(loss.item() - float(g["loss"])) < 1e-3 * abs(float(g["loss"])) + 1e-4
+    loss.backward()
+    names = [str(n) for n in g["grad_names"]]
+    norms = g["grad_norms"]
+    for k, ref_norm in zip(names, norms):
+        gr = sd[k].grad
+        n = 0.0 if gr is None else float(gr.double().norm())
+        assert abs(n - ref_norm) <= 2e-3 * ref_norm + 1e-7, (k, n, ref_norm)
+        if "grad_" + k in g.keys():
+            close(gr, g["grad_" + k], 5e-3, 2e-3 * float(np.abs(g["grad_" + k]).max()) + 1e-9, "grad " + k)
+    close(audio.grad, g["grad_audio"], 5e-3, 2e-3 * float(np.abs(g["grad_audio"]).max()), "grad audio")
