@@ -31,14 +31,16 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FLOP_PER_SAMPLE = 1_855_744          # BASELINE.md section 3 (GEMM work as the reference writes it)
-PEAK_TFLOPS = {"fp32": 157.3}        # MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
+PEAK_TFLOPS = {"fp32": 157.3,        # MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
+               "bf16": 2500.0}       # dense BF16 MFMA peak (never the 2:1-sparse figure)
+KERNEL = {"fp32": "field_forward_f32_kernel", "bf16": "field_forward_bf16_kernel"}
 
 
-def build_inputs(pkg, dev, size, seed=42):
+def build_inputs(pkg, dev, size, precision, seed=42):
     cfg = pkg.default_config()
     W = pkg.weights
     fw = W.flatten_state_dict(W.hash_state_dict(0, 8.0, 30.0))
-    model = pkg.AudioFaceModel(cfg).to(dev).load_flat(fw)
+    model = pkg.AudioFaceModel(cfg, precision=precision).to(dev).load_flat(fw)
     rng = np.random.default_rng(seed)
     audio = torch.from_numpy(rng.standard_normal((16, 29)).astype(np.float32)).to(dev)
     pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], axis=1).astype(np.float32)).to(dev)
@@ -54,7 +56,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512, help="frame is size x size rays")
-    ap.add_argument("--precision", default="fp32", choices=["fp32"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = configs[1] (exact, headline); bf16 = configs[2] (bf16 MFMA operands, fp32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -72,7 +75,8 @@ def main():
 
     pkg = importlib.import_module("sahs-deformable-nerf_amd")
     ops = pkg.ops
-    cfg, model, fw, audio, pose, intr, bg_all = build_inputs(pkg, dev, args.size)
+    cfg, model, fw, audio, pose, intr, bg_all = build_inputs(pkg, dev, args.size, args.precision)
+    prec = model.precision
     H = W = args.size
     R = H * W
     opt = cfg.nerf.validation
@@ -101,14 +105,14 @@ def main():
             z_c = ops.stratified_depths(rb, nc, False, t_rand)
             e0, e1, e2, e3 = ev(), ev(), ev(), ev()
             e0.record()
-            raw = ops.field_forward(packed, frame, 0, rb, z_c, out=ws.get(("raw", N, nc)))
+            raw = ops.field_forward(packed, frame, 0, rb, z_c, precision=prec, out=ws.get(("raw", N, nc)))
             e1.record()
             ws[("raw", N, nc)] = raw
             rgb_c, disp_c, acc_c, wts, _ = ops.composite_forward(raw, z_c, rb, bg=bgb)
             u = torch.rand((N, nf), device=dev)
             z_f = ops.resample(z_c, wts, nf, u=u)
             e2.record()
-            raw_f = ops.field_forward(packed, frame, 1, rb, z_f, out=ws.get(("raw", N, nc + nf)))
+            raw_f = ops.field_forward(packed, frame, 1, rb, z_f, precision=prec, out=ws.get(("raw", N, nc + nf)))
             e3.record()
             ws[("raw", N, nc + nf)] = raw_f
             rgb_f, disp_f, acc_f, wts_f, depth_f = ops.composite_forward(raw_f, z_f, rb, bg=bgb)
@@ -148,11 +152,11 @@ def main():
     result = {
         "metric": "rendered rays/sec (coarse64+fine128, 8x256 MLP)", "value": R * args.steps / dt, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
         "config": {"workload": "W512: %dx%d rays, 64 coarse + 128 fine evaluations/ray, deform(6x128+6x64)+radiance(8x256) MLPs, "
                                "validation mode (perturb on), bg prior, hash-filled density-boosted weights" % (H, W),
                    "rays_per_step": R, "ray_chunk": chunk, "parallelism": "rays x%d" % world, "precision": args.precision},
-        "roofline": {"bound": "mfma", "kernel": "field_forward_f32_kernel", "achieved": achieved, "peak": PEAK_TFLOPS[args.precision],
+        "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": achieved, "peak": PEAK_TFLOPS[args.precision],
                      "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": None,
                      "launches": launches, "avg_launch_ms": field_ms / launches, "flop_per_sample": FLOP_PER_SAMPLE,
                      "field_time_share": field_ms * 1e-3 / dt},

@@ -1,0 +1,377 @@
+// field_bf16.hip -- the per-sample field with bf16 MFMA operands and fp32 accumulation
+// (BASELINE.json configs[2]).  Same structure as field_f32.hip, re-tiled for
+// v_mfma_f32_32x32x16_bf16:
+//  * one wave owns 32 samples (MFMA columns); lane = 32*h + j holds sample j.  A 32x32 fp32
+//    accumulator tile (lane: rows (r&3) + 8(r>>2) + 4h, r = 0..15) becomes the next layer's B operand
+//    by converting registers 8s..8s+7 to a bf16x8 fragment for k-step s -- no lane movement, no LDS
+//    (the weights are packed in the matching k order, sahs_layout.hpp).  Activations are rounded to
+//    bf16 once per layer; accumulation, biases, positional encodings, the grid interpolation and the
+//    final [rgb|seg|sigma] tile are fp32.
+//  * 8 waves x 32 samples = 256 samples per workgroup tile share each weight chunk (<= 64 KB,
+//    LDS-DMA double buffered): 1 ds_read_b128 per MFMA per wave = 128 B/clk/CU (half the LDS rate).
+//  * skip layers are not split here: a tile's accumulator runs over [hidden | re-injected encoding].
+// Roofline: MFMA-bound against the dense bf16 peak (~2.5 PFLOP/s).
+#include <hip/hip_runtime.h>
+#include "sahs_common.hpp"
+#include "sahs_layout.hpp"
+
+namespace sahs {
+namespace hb {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct Blk { bf16x8 s[2]; };   // 32 features of this lane's sample, as the two k-step B fragments
+
+constexpr int H_THREADS = 512;
+constexpr int H_PTS_PER_WAVE = 32;
+constexpr int H_PTS_PER_WG = (H_THREADS / WAVE) * H_PTS_PER_WAVE;   // 256
+constexpr int LDS_BUF_BYTES = CHUNK_HW_MAX * 2;                       // 64 KB each, two of them
+constexpr int LDS_BIAS_BYTE_OFF = 2 * LDS_BUF_BYTES;
+constexpr int LDS_BYTES = LDS_BIAS_BYTE_OFF + ((BIAS_FLOATS + 3) / 4) * 16;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int DBG_STRIDE_H = 56;
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+
+struct CtxH {
+    const unsigned short *stream;   // this level's packed bf16 stream
+    const uint32_t *table;          // chunk start offsets (halfwords)
+    char *lds;
+    int chunk, buf;
+    int lane, h, wave;
+
+    __device__ __forceinline__ void issue(int c, int b)
+    {
+        const uint32_t o0 = table[c], o1 = table[c + 1];
+        const int n16 = (int)(o1 - o0) >> 3;                       // 16-byte pieces
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(stream + o0);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(lds + b * LDS_BUF_BYTES);
+        for (int base = wave * WAVE; base < n16; base += H_THREADS)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + base + lane), (lds_ptr_t)(dst + base), 16, 0, 0);
+    }
+    __device__ __forceinline__ void begin_chunk()
+    {
+        int nxt = chunk + 1;
+        if (nxt == NUM_CHUNKS_H) nxt = 0;
+        issue(nxt, buf ^ 1);
+    }
+    __device__ __forceinline__ void end_chunk()
+    {
+        __syncthreads();
+        chunk = (chunk + 1 == NUM_CHUNKS_H) ? 0 : chunk + 1;
+        buf ^= 1;
+    }
+    __device__ __forceinline__ const bf16x8 *cur() const { return reinterpret_cast<const bf16x8 *>(lds + buf * LDS_BUF_BYTES); }
+    // bias of a 32-row tile in accumulator order: reg r <-> row (r&3) + 8(r>>2) + 4h
+    __device__ __forceinline__ f32x16 bias16(int off) const
+    {
+        const float *b = reinterpret_cast<const float *>(lds + LDS_BIAS_BYTE_OFF) + off + 4 * h;
+        f32x16 v;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(b + 8 * g);
+            v[4 * g + 0] = t[0]; v[4 * g + 1] = t[1]; v[4 * g + 2] = t[2]; v[4 * g + 3] = t[3];
+        }
+        return v;
+    }
+    // 16-row layers (WF, HF, FINAL) occupy rows 0..15 of a 32-row tile: rows 16..31 (regs 8..15) carry no bias
+    __device__ __forceinline__ f32x16 bias16_half(int off) const
+    {
+        const float *b = reinterpret_cast<const float *>(lds + LDS_BIAS_BYTE_OFF) + off + 4 * h;
+        f32x16 v;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(b + 8 * g);
+            v[4 * g + 0] = t[0]; v[4 * g + 1] = t[1]; v[4 * g + 2] = t[2]; v[4 * g + 3] = t[3];
+        }
+#pragma unroll
+        for (int r = 8; r < 16; ++r) v[r] = 0.0f;
+        return v;
+    }
+};
+
+__device__ __forceinline__ Blk pack_act(const f32x16 acc, float slope)
+{
+    Blk o;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = acc[8 * s + j];
+            o.s[s][j] = (__bf16)(v > 0.0f ? v : v * slope);
+        }
+    return o;
+}
+
+template <int K0, int K1, int K2>
+__device__ __forceinline__ f32x16 tile_mac(const bf16x8 *A, const Blk *in0, const Blk *in1, const Blk *in2, f32x16 acc)
+{
+    constexpr int KB = K0 + K1 + K2;
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+        const Blk &x = (b < K0) ? in0[b] : ((b < K0 + K1) ? in1[b - K0] : in2[b - K0 - K1]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(b * 2 + s) * 64], x.s[s], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// hidden layer: NT32 output tiles, activation, bf16 repack
+template <int K0, int K1, int K2, int NT32>
+__device__ __forceinline__ void dense_h(CtxH &cx, const Blk *in0, const Blk *in1, const Blk *in2, Blk *out, int bias_off, float slope)
+{
+    constexpr int KB = K0 + K1 + K2;
+    constexpr int G = pick_G32(KB, NT32);
+#pragma unroll
+    for (int c = 0; c < NT32 / G; ++c) {
+        cx.begin_chunk();
+        const bf16x8 *A = cx.cur() + cx.lane;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int t = c * G + g;
+            f32x16 acc = cx.bias16(bias_off + 32 * t);
+            acc = tile_mac<K0, K1, K2>(A + g * KB * 128, in0, in1, in2, acc);
+            out[t] = pack_act(acc, slope);
+        }
+        cx.end_chunk();
+    }
+}
+
+// 16-row output layer accumulated in fp32: init = bias (first) or the running tile (ALPHA -> RGB -> SEG)
+template <int K0>
+__device__ __forceinline__ void dense_h_out(CtxH &cx, const Blk *in0, f32x16 &acc, int bias_off, bool first)
+{
+    cx.begin_chunk();
+    const bf16x8 *A = cx.cur() + cx.lane;
+    if (first) acc = cx.bias16_half(bias_off);
+    acc = tile_mac<K0, 0, 0>(A, in0, nullptr, nullptr, acc);
+    cx.end_chunk();
+}
+
+template <int D, int L>
+__device__ __forceinline__ float pe_feature_h(const float *v, int f)
+{
+    constexpr int W = D + 2 * D * L;
+    float r = 0.0f;
+    if (f < D) {
+        r = (f == 0) ? v[0] : ((f == 1) ? v[1] : v[D > 2 ? 2 : 0]);
+    } else if (f < W) {
+        const int g = f - D;
+        const int k = g / (2 * D), rem = g % (2 * D);
+        const int fn = rem / D, ax = rem % D;
+        const float x = (ax == 0) ? v[0] : ((ax == 1) ? v[1] : v[D > 2 ? 2 : 0]);
+        float s, c;
+        sincosf(x * (float)(1 << k), &s, &c);
+        r = fn ? c : s;
+    }
+    return r;
+}
+
+template <int D, int L, int NB>
+__device__ __forceinline__ void pe_blocks_h(const float *v, int h, Blk *out)
+{
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[b].s[s][j] = (__bf16)pe_feature_h<D, L>(v, 32 * b + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3));
+}
+
+// trilinear lookup (fp32, ATen corner order, zeros padding); this lane takes channels 16s + 8g + 4h + 0..3
+__device__ __forceinline__ void grid_block_h(const float *__restrict__ grid, float x, float y, float z, int h, Blk &out, float *dbg)
+{
+    const float R1 = (float)(G_RES - 1);
+    const float ix = ((x + 1.0f) / 2.0f) * R1, iy = ((y + 1.0f) / 2.0f) * R1, iz = ((z + 1.0f) / 2.0f) * R1;
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const float wx[2] = {(fx + 1.0f) - ix, ix - fx}, wy[2] = {(fy + 1.0f) - iy, iy - fy}, wz[2] = {(fz + 1.0f) - iz, iz - fz};
+    const bool ok = fx >= -1.0f && fx <= (float)G_RES && fy >= -1.0f && fy <= (float)G_RES && fz >= -1.0f && fz <= (float)G_RES;
+    const int xi = ok ? (int)fx : -2, yi = ok ? (int)fy : -2, zi = ok ? (int)fz : -2;
+    f32x4 a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int cx = xi + (n & 1), cy = yi + ((n >> 1) & 1), cz = zi + (n >> 2);
+        const bool inb = cx >= 0 && cx < G_RES && cy >= 0 && cy < G_RES && cz >= 0 && cz < G_RES;
+        const float wt = (wx[n & 1] * wy[(n >> 1) & 1]) * wz[n >> 2];
+        const long vox = inb ? (((long)cz * G_RES + cy) * G_RES + cx) : 0;
+        const f32x4 *g = reinterpret_cast<const f32x4 *>(grid + vox * D_GRID) + h;   // channels 4h.., 8+4h.., 16+4h.., 24+4h..
+        if (inb) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 gv = g[2 * k];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[k][r] = a[k][r] + gv[r] * wt;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out.s[s][j] = (__bf16)a[2 * s + (j >> 2)][j & 3];
+    if (dbg != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4 *>(dbg + 8 * k + 4 * h) = a[k];
+    }
+}
+
+__device__ __forceinline__ float bcast32(float v, int lane) { return __shfl(v, lane & 31, WAVE); }
+
+__global__ void __launch_bounds__(H_THREADS, 2)
+field_forward_bf16_kernel(const float *__restrict__ packed, const float *__restrict__ frame, int level, long P, int S,
+                          const float *__restrict__ rays, int ray_stride, const float *__restrict__ zvals,
+                          float *__restrict__ raw, float *__restrict__ dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_h[];
+    CtxH cx;
+    cx.stream = reinterpret_cast<const unsigned short *>(packed + PACKH_STREAM_OFF) + (long)level * STREAM_HW;
+    cx.table = reinterpret_cast<const uint32_t *>(packed + PACKH_TABLE_OFF);
+    cx.lds = lds_h;
+    cx.chunk = 0;
+    cx.buf = 0;
+    cx.lane = threadIdx.x & 63;
+    cx.h = cx.lane >> 5;
+    cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float *grid = packed + PACKH_GRID_OFF;
+    const int h = cx.h;
+    {
+        const float *bsrc = frame + FRAME_BIAS_OFF + level * BIAS_FLOATS;
+        float *bl = reinterpret_cast<float *>(lds_h + LDS_BIAS_BYTE_OFF);
+        for (int i = threadIdx.x; i < BIAS_FLOATS; i += H_THREADS) bl[i] = bsrc[i];
+        cx.issue(0, 0);
+        __syncthreads();
+    }
+    constexpr const LayerH *Ly = kProgH.layer;
+
+    const long ntiles = (P + H_PTS_PER_WG - 1) / H_PTS_PER_WG;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long p_raw = tile * H_PTS_PER_WG + cx.wave * H_PTS_PER_WAVE + (cx.lane & 31);
+        const long p = p_raw < P ? p_raw : P - 1;
+        const long ray = p / S;
+        const float *rp = rays + ray * ray_stride;
+        const float z = zvals[p];
+        float rd[3] = {rp[3], rp[4], rp[5]};
+        float x[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) x[i] = rp[i] + rd[i] * z;
+
+        Blk pe_x[2];
+        pe_blocks_h<3, 10, 2>(x, h, pe_x);
+        float xw[3], amb[2];
+        {   // warp field
+            Blk hh[4], hn[4];
+            dense_h<2, 0, 0, 4>(cx, pe_x, nullptr, nullptr, hh, Ly[H_W0].bias_off, 0.0f);
+#pragma unroll 1
+            for (int l = 0; l < 3; ++l) {
+                dense_h<4, 0, 0, 4>(cx, hh, nullptr, nullptr, hn, Ly[H_W1].bias_off + 128 * l, 0.0f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hh[i] = hn[i];
+            }
+            dense_h<4, 2, 0, 4>(cx, hh, pe_x, nullptr, hn, Ly[H_W4].bias_off, 0.0f);
+            dense_h<4, 0, 0, 4>(cx, hn, nullptr, nullptr, hh, Ly[H_W5].bias_off, 0.0f);
+            f32x16 o;
+            dense_h_out<4>(cx, hh, o, Ly[H_WF].bias_off, true);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xw[i] = x[i] + tanhf(bcast32(o[i], cx.lane));
+        }
+        {   // hyper sheet
+            Blk hh[2], hn[2];
+            dense_h<2, 0, 0, 2>(cx, pe_x, nullptr, nullptr, hh, Ly[H_H0].bias_off, 0.0f);
+#pragma unroll 1
+            for (int l = 0; l < 3; ++l) {
+                dense_h<2, 0, 0, 2>(cx, hh, nullptr, nullptr, hn, Ly[H_H1].bias_off + 64 * l, 0.0f);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) hh[i] = hn[i];
+            }
+            dense_h<2, 2, 0, 2>(cx, hh, pe_x, nullptr, hn, Ly[H_H4].bias_off, 0.0f);
+            dense_h<2, 0, 0, 2>(cx, hn, nullptr, nullptr, hh, Ly[H_H5].bias_off, 0.0f);
+            f32x16 o;
+            dense_h_out<2>(cx, hh, o, Ly[H_HF].bias_off, true);
+            amb[0] = bcast32(o[0], cx.lane);
+            amb[1] = bcast32(o[1], cx.lane);
+        }
+        float *dsl = dbg + p * DBG_STRIDE_H;
+        if (dbg != nullptr && h == 0 && p_raw < P) {
+            dsl[0] = xw[0] - x[0]; dsl[1] = xw[1] - x[1]; dsl[2] = xw[2] - x[2]; dsl[3] = amb[0]; dsl[4] = amb[1];
+        }
+        // radiance trunk
+        Blk feat[8];
+        f32x16 fin;
+        {
+            Blk in_tr[3];
+            pe_blocks_h<3, 10, 2>(xw, h, in_tr);
+            pe_blocks_h<2, 4, 1>(amb, h, in_tr + 2);
+            Blk hh[8];
+            dense_h<2, 1, 0, 8>(cx, in_tr, in_tr + 2, nullptr, hh, Ly[H_T0].bias_off, 0.01f);
+#pragma unroll 1
+            for (int l = 1; l <= 8; ++l) {
+                if (l == 3) {
+                    dense_h<8, 2, 1, 8>(cx, hh, in_tr, in_tr + 2, feat, Ly[H_T3].bias_off, 0.01f);
+                } else {
+                    const int boff = (l < 3) ? Ly[H_T1].bias_off + 256 * (l - 1) : Ly[H_T4].bias_off + 256 * (l - 4);
+                    dense_h<8, 0, 0, 8>(cx, hh, nullptr, nullptr, feat, boff, l == 8 ? 1.0f : 0.01f);
+                }
+                if (l < 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) hh[i] = feat[i];
+                }
+            }
+        }
+        dense_h_out<8>(cx, feat, fin, Ly[H_ALPHA].bias_off, true);
+        {   // colour branch
+            Blk in_d[2];
+            pe_blocks_h<3, 4, 1>(rd, h, in_d);
+            grid_block_h(grid, xw[0], xw[1], xw[2], h, in_d[1], (dbg != nullptr && p_raw < P) ? dbg + P * DBG_STRIDE_H + p * 32 : nullptr);
+            Blk c[4], cn[4];
+            dense_h<8, 1, 1, 4>(cx, feat, in_d, in_d + 1, c, Ly[H_D0].bias_off, 0.01f);
+#pragma unroll 1
+            for (int l = 0; l < 3; ++l) {
+                dense_h<4, 0, 0, 4>(cx, c, nullptr, nullptr, cn, Ly[H_D1].bias_off + 128 * l, 0.01f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = cn[i];
+            }
+            dense_h_out<4>(cx, c, fin, 0, false);
+        }
+        {   // seg branch
+            Blk s[4], sn[4];
+            dense_h<8, 0, 0, 4>(cx, feat, nullptr, nullptr, s, Ly[H_S0].bias_off, 0.01f);
+#pragma unroll 1
+            for (int l = 0; l < 3; ++l) {
+                dense_h<4, 0, 0, 4>(cx, s, nullptr, nullptr, sn, Ly[H_S1].bias_off + 128 * l, 0.01f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] = sn[i];
+            }
+            dense_h_out<4>(cx, s, fin, 0, false);
+        }
+        if (p_raw < P) {   // rows 4h..4h+3 and 8+4h..8+4h+3 of [rgb3 | seg12 | sigma]
+            *reinterpret_cast<f32x4 *>(raw + p * D_RAW + 4 * h) = f32x4{fin[0], fin[1], fin[2], fin[3]};
+            *reinterpret_cast<f32x4 *>(raw + p * D_RAW + 8 + 4 * h) = f32x4{fin[4], fin[5], fin[6], fin[7]};
+        }
+    }
+}
+
+}  // namespace hb
+}  // namespace sahs
+
+using namespace sahs;
+using namespace sahs::hb;
+
+extern "C" int sahs_field_forward_bf16_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays,
+                                              int ray_stride, const float *zvals, float *raw, float *dbg, int num_cu,
+                                              hipStream_t stream)
+{
+    if (P <= 0) return 0;
+    const long ntiles = (P + H_PTS_PER_WG - 1) / H_PTS_PER_WG;
+    const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_bf16_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    field_forward_bf16_kernel<<<grid, H_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg);
+    return (int)hipGetLastError();
+}

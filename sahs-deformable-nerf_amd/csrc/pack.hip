@@ -71,6 +71,69 @@ __global__ void pack_table_kernel(float *__restrict__ packed)
     }
 }
 
+// ---- bf16 stream (field_bf16.hip): one thread per lane-fragment of 8 halfwords ----
+__device__ const hb::ProgramH dProgH = hb::make_program_h();
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f)
+{
+    return __builtin_bit_cast(unsigned short, (__bf16)f);   // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+}
+
+__global__ void pack_stream_bf16_kernel(const float *__restrict__ flat, float *__restrict__ packed)
+{
+    using namespace hb;
+    unsigned short *out = reinterpret_cast<unsigned short *>(packed + PACKH_STREAM_OFF);
+    const long total = 2 * STREAM_HW / 8;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long hw = e * 8;
+        const int level = (int)(hw / STREAM_HW);
+        const long sidx = hw - (long)level * STREAM_HW;
+        int li = 0;
+        while (li + 1 < NUM_LAYERS_H && dProgH.layer[li + 1].stream_off <= sidx) ++li;
+        const LayerH &L = dProgH.layer[li];
+        const long w = sidx - L.stream_off;
+        const int per_tile = L.KB32 * 1024;
+        const int t = (int)(w / per_tile);
+        const int rem = (int)(w - (long)t * per_tile);
+        const int b = rem >> 10, st = (rem >> 9) & 1, lane = (rem & 511) >> 3;
+        const int i = lane & 31, h = lane >> 5;
+        const int row = 32 * t + i - L.row_shift;
+        int bb = b, seg = -1;
+        for (int sg = 0; sg < L.nseg; ++sg) {
+            if (bb < L.seg[sg].blocks) { seg = sg; break; }
+            bb -= L.seg[sg].blocks;
+        }
+        unsigned short v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 32 * bb + 16 * st + 8 * (j >> 2) + 4 * h + (j & 3);
+            float x = 0.0f;
+            if (seg >= 0 && c < L.seg[seg].valid && row >= 0 && row < L.src_rows)
+                x = flat[L.w_off[level] + (long)row * L.src_ld + L.seg[seg].src_col + c];
+            v[j] = f32_to_bf16_rne(x);
+        }
+        uint4 q;
+        q.x = v[0] | ((unsigned)v[1] << 16); q.y = v[2] | ((unsigned)v[3] << 16);
+        q.z = v[4] | ((unsigned)v[5] << 16); q.w = v[6] | ((unsigned)v[7] << 16);
+        *reinterpret_cast<uint4 *>(out + hw) = q;
+    }
+}
+
+__global__ void pack_table_bf16_kernel(float *__restrict__ packed)
+{
+    using namespace hb;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(packed + PACKH_TABLE_OFF);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int c = 0;
+        for (int li = 0; li < NUM_LAYERS_H; ++li) {
+            const LayerH &L = dProgH.layer[li];
+            const int chunk = L.G32 * L.KB32 * 1024;
+            for (int k = 0; k < L.NT32 / L.G32; ++k) tab[c++] = (uint32_t)(L.stream_off + (long)k * chunk);
+        }
+        tab[c] = (uint32_t)STREAM_HW;
+    }
+}
+
 // ---- per-frame conditioning ---------------------------------------------------------------
 __device__ __forceinline__ float lrelu02(float x) { return x > 0.0f ? x : x * 0.02f; }
 
@@ -162,6 +225,14 @@ extern "C" int sahs_pack_weights_f32_launch(const float *flat, float *packed, hi
     pack_stream_f32_kernel<<<2048, 256, 0, stream>>>(flat, packed);
     pack_grid_f32_kernel<<<1024, 256, 0, stream>>>(flat, packed);
     pack_table_kernel<<<1, 64, 0, stream>>>(packed);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sahs_pack_weights_bf16_launch(const float *flat, float *packed, hipStream_t stream)
+{
+    pack_stream_bf16_kernel<<<1024, 256, 0, stream>>>(flat, packed);
+    pack_grid_f32_kernel<<<1024, 256, 0, stream>>>(flat, packed);    // grid stays fp32, channel-last, at the same offset
+    pack_table_bf16_kernel<<<1, 64, 0, stream>>>(packed);
     return (int)hipGetLastError();
 }
 

@@ -238,3 +238,106 @@ constexpr int FRAME_DRV_OFF = 0, FRAME_POSE_OFF = 80, FRAME_BIAS_OFF = 128;
 constexpr int FRAME_FLOATS = FRAME_BIAS_OFF + 2 * BIAS_FLOATS;
 
 }  // namespace sahs
+
+// =============================================================================================
+// bf16 program (field_bf16.hip).  Same network, same bias array (the per-frame fold is shared), but
+// the MFMA is v_mfma_f32_32x32x16_bf16: tiles are 32 rows, k-blocks are 32 features (= one D tile
+// = two MFMA k-steps), and skip layers are NOT split (the accumulator of a tile simply runs over
+// all input segments), so a layer has up to three input segments.
+// Stream (bf16 halfwords): [layer][tile32][block32][step 0/1][lane 64][8]; lane = 32*h + i holds
+// W[32t+i][32b + 16s + 8(j>>2) + 4h + (j&3)], j = 0..7: the k order in which a 32x32 accumulator
+// tile turns into the next MFMA's B operand without moving between lanes.
+// =============================================================================================
+namespace sahs {
+namespace hb {
+
+enum LayerIdH {
+    H_W0, H_W1, H_W2, H_W3, H_W4, H_W5, H_WF,
+    H_H0, H_H1, H_H2, H_H3, H_H4, H_H5, H_HF,
+    H_T0, H_T1, H_T2, H_T3, H_T4, H_T5, H_T6, H_T7, H_FEAT, H_ALPHA,
+    H_D0, H_D1, H_D2, H_D3, H_RGB,
+    H_S0, H_S1, H_S2, H_S3, H_SEG,
+    NUM_LAYERS_H
+};
+struct LayerH {
+    long w_off[2];
+    int src_ld, src_rows, row_shift;
+    int NT32, KB32, G32;
+    int nseg; Seg seg[3];          // Seg.blocks in units of 32 features here
+    int bias_off;                  // into the shared per-level bias array (floats)
+    long stream_off;               // halfwords
+    int first_chunk;
+};
+constexpr int CHUNK_HW_MAX = 32768;          // 64 KB LDS staging buffer
+constexpr int pick_G32(int KB32, int NT32)
+{
+    int g = CHUNK_HW_MAX / (KB32 * 1024);
+    if (g > NT32) g = NT32;
+    while (NT32 % g) --g;
+    return g;
+}
+struct ProgramH {
+    LayerH layer[NUM_LAYERS_H];
+    long stream_hw;
+    int num_chunks;
+};
+constexpr Seg half_seg(Seg s) { return Seg{s.blocks / 2, s.src_col, s.valid}; }
+constexpr LayerH from1(const Layer &a)     // plain layer
+{
+    LayerH h{};
+    h.w_off[0] = a.w_off[0]; h.w_off[1] = a.w_off[1];
+    h.src_ld = a.src_ld; h.src_rows = a.src_rows; h.row_shift = a.row_shift;
+    h.NT32 = (a.NT + 1) / 2;
+    h.nseg = a.nseg;
+    h.seg[0] = half_seg(a.seg[0]); h.seg[1] = half_seg(a.seg[1]);
+    h.KB32 = h.seg[0].blocks + h.seg[1].blocks;
+    h.bias_off = a.bias_off;
+    return h;
+}
+constexpr LayerH from2(const Layer &b, const Layer &a)   // split pair: hidden part (A) first, then the injected part (B)
+{
+    LayerH h = from1(a);
+    h.seg[1] = half_seg(b.seg[0]); h.seg[2] = half_seg(b.seg[1]);
+    h.nseg = 1 + b.nseg;
+    h.KB32 = h.seg[0].blocks + h.seg[1].blocks + h.seg[2].blocks;
+    h.bias_off = b.bias_off;
+    return h;
+}
+constexpr ProgramH make_program_h()
+{
+    ProgramH P{};
+    const Layer *L = kProg.layer;
+    LayerH *H = P.layer;
+    H[H_W0] = from1(L[L_W0]); H[H_W1] = from1(L[L_W1]); H[H_W2] = from1(L[L_W2]); H[H_W3] = from1(L[L_W3]);
+    H[H_W4] = from2(L[L_W4B], L[L_W4A]); H[H_W5] = from1(L[L_W5]); H[H_WF] = from1(L[L_WF]);
+    H[H_H0] = from1(L[L_H0]); H[H_H1] = from1(L[L_H1]); H[H_H2] = from1(L[L_H2]); H[H_H3] = from1(L[L_H3]);
+    H[H_H4] = from2(L[L_H4B], L[L_H4A]); H[H_H5] = from1(L[L_H5]); H[H_HF] = from1(L[L_HF]);
+    H[H_T0] = from1(L[L_T0]); H[H_T1] = from1(L[L_T1]); H[H_T2] = from1(L[L_T2]);
+    H[H_T3] = from2(L[L_T3B], L[L_T3A]);
+    H[H_T4] = from1(L[L_T4]); H[H_T5] = from1(L[L_T5]); H[H_T6] = from1(L[L_T6]); H[H_T7] = from1(L[L_T7]);
+    H[H_FEAT] = from1(L[L_FEAT]); H[H_ALPHA] = from1(L[L_ALPHA]);
+    H[H_D0] = from2(L[L_D0B], L[L_D0A]); H[H_D1] = from1(L[L_D1]); H[H_D2] = from1(L[L_D2]); H[H_D3] = from1(L[L_D3]);
+    H[H_RGB] = from1(L[L_RGB]);
+    H[H_S0] = from1(L[L_S0]); H[H_S1] = from1(L[L_S1]); H[H_S2] = from1(L[L_S2]); H[H_S3] = from1(L[L_S3]);
+    H[H_SEG] = from1(L[L_SEG]);
+    long soff = 0; int chunk = 0;
+    for (int i = 0; i < NUM_LAYERS_H; ++i) {
+        H[i].G32 = pick_G32(H[i].KB32, H[i].NT32);
+        H[i].stream_off = soff; H[i].first_chunk = chunk;
+        soff += (long)H[i].NT32 * H[i].KB32 * 1024;
+        chunk += H[i].NT32 / H[i].G32;
+    }
+    P.stream_hw = soff; P.num_chunks = chunk;
+    return P;
+}
+constexpr ProgramH kProgH = make_program_h();
+constexpr long STREAM_HW = kProgH.stream_hw;      // per level, halfwords
+constexpr int NUM_CHUNKS_H = kProgH.num_chunks;
+// packed (bf16), in 4-byte words: [grid channel-last fp32][level0 stream][level1 stream][chunk table: halfword offsets / 8]
+constexpr long PACKH_GRID_OFF = 0;
+constexpr long PACKH_STREAM_OFF = GRID_FLOATS;                       // words
+constexpr long PACKH_TABLE_OFF = PACKH_STREAM_OFF + STREAM_HW;       // 2 levels * STREAM_HW halfwords = STREAM_HW words
+constexpr long PACKH_WORDS = PACKH_TABLE_OFF + ((NUM_CHUNKS_H + 1 + 3) / 4) * 4;
+
+}  // namespace hb
+}  // namespace sahs

@@ -1,0 +1,97 @@
+"""bf16 MFMA path (BASELINE.json configs[2]) on the MI355X: error against the CPU oracle at the field seam and
+the PSNR protocol of SURVEY.md section 8d on the full W512 frame, with the exact fp32 HIP path (itself checked against
+the oracle and the reference's golden outputs in test_gpu_parity.py) as the image reference.
+bf16 tolerances are statistical: every layer rounds its activations to 8 significant bits."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden, pkg
+
+pytestmark = pytest.mark.gpu
+from oracle import oracle  # noqa: E402  (checker only)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def psnr(a, b):
+    mse = float(torch.mean((a.clamp(0, 1) - b.clamp(0, 1)) ** 2))
+    return 99.0 if mse == 0 else -10.0 * np.log10(mse)
+
+
+def test_bf16_field_vs_oracle(flat_weights):
+    ops, lib = pkg("ops"), pkg("_lib")
+    g = load_golden("cond")
+    fw = flat_weights(density_bias=8.0, density_gain=30.0)
+    flat = T(fw)
+    packed = ops.pack_weights(flat, lib.SAHS_BF16)
+    frame = ops.fold_conditioning(flat, T(g["audio"]), T(g["pose"]))
+    rng = np.random.default_rng(11)
+    N, S = 61, 64     # ragged: 3904 samples, not a multiple of the 256-sample tile
+    rays = np.zeros((N, 8), np.float32)
+    rays[:, 0:3] = rng.normal(0, 0.05, (N, 3)) + np.array([0, 0, 0.8])
+    rays[:, 3:6] = rng.normal(0, 0.15, (N, 3)) + np.array([0, 0, -1.0])
+    z = np.sort(rng.uniform(0.48, 1.08, (N, S)).astype(np.float32), axis=1)
+    x6 = np.concatenate([rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None], np.broadcast_to(rays[:, None, 3:6], (N, S, 3))], -1).reshape(-1, 6)
+    drv, p36 = oracle.audionet(fw, g["audio"]), oracle.pose_encoding(g["pose"])
+    stats = {}
+    for level in (0, 1):
+        ref, rdx, rw, rgrid = oracle.field_forward(fw, level, x6.astype(np.float32), drv, p36, debug=True)
+        raw, dx, w, grid = ops.field_forward(packed, frame, level, T(rays), T(z), precision=lib.SAHS_BF16, debug=True)
+        raw = raw.view(-1, 16).cpu().numpy()
+        e_dx = np.abs(dx.view(-1, 3).cpu().numpy() - rdx)
+        e_w = np.abs(w.view(-1, 2).cpu().numpy() - rw)
+        e_col = np.abs(raw[:, :15] - ref[:, :15])
+        e_sig = np.abs(raw[:, 15] - ref[:, 15])
+        stats[level] = dict(dx_max=float(e_dx.max()), dx_rms=float(np.sqrt((e_dx ** 2).mean())), w_max=float(e_w.max()),
+                            col_max=float(e_col.max()), col_rms=float(np.sqrt((e_col ** 2).mean())), sig_max=float(e_sig.max()),
+                            sig_rms=float(np.sqrt((e_sig ** 2).mean())), sig_scale=float(np.abs(ref[:, 15]).mean()),
+                            grid_max=float(np.abs(grid.view(-1, 32).cpu().numpy() - rgrid).max()))
+        assert np.isfinite(raw).all()
+        assert stats[level]["dx_max"] < 2e-2 and stats[level]["col_rms"] < 2e-2, stats[level]
+        assert stats[level]["sig_rms"] < 0.05 * stats[level]["sig_scale"] + 0.5, stats[level]
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    json.dump(stats, open(os.path.join(REPO, "gpurun_out", "bf16_field_stats.json"), "w"), indent=1)
+    print(json.dumps(stats))
+
+
+def test_bf16_full_frame_psnr(weights_mod):
+    sahs = pkg()
+    cfg = sahs.default_config()
+    H = W = 512
+    R = H * W
+    fw = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 8.0, 30.0))
+    fw_t = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(1, 8.0, 30.0))      # pseudo-target: a different network
+    m32 = sahs.AudioFaceModel(cfg, precision="fp32").to(dev()).load_flat(fw)
+    m16 = sahs.AudioFaceModel(cfg, precision="bf16").to(dev()).load_flat(fw)
+    mt = sahs.AudioFaceModel(cfg, precision="fp32").to(dev()).load_flat(fw_t)
+    rng = np.random.default_rng(42)
+    audio, pose = T(rng.standard_normal((16, 29)).astype(np.float32)), T(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32))
+    intr = np.array([1200.0, 1200.0, 0.5, 0.5], np.float32)
+    bg = torch.cat([torch.rand(R, 3, device=dev()), torch.ones(R, 1, device=dev()), torch.zeros(R, 11, device=dev())], 1)
+    ro, rd = sahs.get_ray_bundle(H, W, intr, pose)
+
+    def render(model):
+        torch.manual_seed(7)   # same random draws for every model
+        with torch.no_grad():
+            return sahs.run_one_iter_of_nerf(H, W, intr, model, ro, rd, cfg, mode="validation", driving=audio, pose=pose, background_prior=bg)
+
+    o32, o16, ot = render(m32), render(m16), render(mt)
+    rgb32, rgb16, rgbt = o32[3][..., :3], o16[3][..., :3], ot[3][..., :3]
+    res = dict(psnr_bf16_vs_fp32=psnr(rgb16, rgb32), psnr_fp32_vs_target=psnr(rgb32, rgbt), psnr_bf16_vs_target=psnr(rgb16, rgbt),
+               max_abs_rgb=float((rgb16 - rgb32).abs().max()), seg_max_abs=float((o16[3][..., 3:] - o32[3][..., 3:]).abs().max()),
+               depth_max_abs=float((o16[7] - o32[7]).abs().max()), acc_max_abs=float((o16[5] - o32[5]).abs().max()))
+    res["delta_psnr"] = abs(res["psnr_bf16_vs_target"] - res["psnr_fp32_vs_target"])
+    json.dump(res, open(os.path.join(REPO, "gpurun_out", "bf16_psnr.json"), "w"), indent=1)
+    print(json.dumps(res))
+    assert res["delta_psnr"] <= 0.05, res      # north_star: PSNR within 0.05 dB of the reference
+    assert res["psnr_bf16_vs_fp32"] > 35.0, res
