@@ -91,51 +91,73 @@ struct CtxH {
     }
 };
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// activation (slope in [0,1]: leaky relu == max(x, slope*x)) and fp32 -> bf16 pairs (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ Blk pack_act(const f32x16 acc, float slope)
 {
     Blk o;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
+        uint32_t w[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float v = acc[8 * s + j];
-            o.s[s][j] = (__bf16)(v > 0.0f ? v : v * slope);
+        for (int jp = 0; jp < 4; ++jp) {
+            const float v0 = acc[8 * s + 2 * jp], v1 = acc[8 * s + 2 * jp + 1];
+            const f32x2 a = {fmaxf(v0, v0 * slope), fmaxf(v1, v1 * slope)};
+            w[jp] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
         }
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        o.s[s] = __builtin_bit_cast(bf16x8, (u32x4){w[0], w[1], w[2], w[3]});
+    }
     return o;
 }
 
-template <int K0, int K1, int K2>
-__device__ __forceinline__ f32x16 tile_mac(const bf16x8 *A, const Blk *in0, const Blk *in1, const Blk *in2, f32x16 acc)
-{
-    constexpr int KB = K0 + K1 + K2;
-#pragma unroll
-    for (int b = 0; b < KB; ++b) {
-        const Blk &x = (b < K0) ? in0[b] : ((b < K0 + K1) ? in1[b - K0] : in2[b - K0 - K1]);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[(b * 2 + s) * 64], x.s[s], acc, 0, 0, 0);
-    }
-    return acc;
-}
+constexpr int A_PREFETCH = 4;   // A fragments (ds_read_b128 each) kept in flight ahead of the MFMA that consumes them
 
-// hidden layer: NT32 output tiles, activation, bf16 repack
+// hidden layer: NT32 output tiles, activation, bf16 repack.  A chunk is one flat run of G*KB*2 MFMAs;
+// the A-fragment reads run A_PREFETCH steps ahead, across tile boundaries.
 template <int K0, int K1, int K2, int NT32>
 __device__ __forceinline__ void dense_h(CtxH &cx, const Blk *in0, const Blk *in1, const Blk *in2, Blk *out, int bias_off, float slope)
 {
     constexpr int KB = K0 + K1 + K2;
     constexpr int G = pick_G32(KB, NT32);
+    constexpr int STEPS = KB * 2, TOTAL = G * STEPS;
 #pragma unroll
     for (int c = 0; c < NT32 / G; ++c) {
         cx.begin_chunk();
         const bf16x8 *A = cx.cur() + cx.lane;
+        bf16x8 a[A_PREFETCH];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int t = c * G + g;
-            f32x16 acc = cx.bias16(bias_off + 32 * t);
-            acc = tile_mac<K0, K1, K2>(A + g * KB * 128, in0, in1, in2, acc);
-            out[t] = pack_act(acc, slope);
+        for (int i = 0; i < A_PREFETCH; ++i) a[i] = A[i * 64];
+        f32x16 acc = cx.bias16(bias_off + 32 * (c * G));
+#pragma unroll
+        for (int i = 0; i < TOTAL; ++i) {
+            const int g = i / STEPS, k = i % STEPS, b = k >> 1, st = k & 1;
+            const Blk &x = (b < K0) ? in0[b] : ((b < K0 + K1) ? in1[b - K0] : in2[b - K0 - K1]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % A_PREFETCH], x.s[st], acc, 0, 0, 0);
+            if (i + A_PREFETCH < TOTAL) a[i % A_PREFETCH] = A[(i + A_PREFETCH) * 64];
+            if (k == STEPS - 1) {
+                out[c * G + g] = pack_act(acc, slope);
+                if (g + 1 < G) acc = cx.bias16(bias_off + 32 * (c * G + g + 1));
+            }
         }
         cx.end_chunk();
     }
+}
+
+template <int K0>
+__device__ __forceinline__ f32x16 tile_mac(const bf16x8 *A, const Blk *in0, f32x16 acc)
+{
+    bf16x8 a[A_PREFETCH];
+#pragma unroll
+    for (int i = 0; i < A_PREFETCH; ++i) a[i] = A[i * 64];
+#pragma unroll
+    for (int i = 0; i < K0 * 2; ++i) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % A_PREFETCH], in0[i >> 1].s[i & 1], acc, 0, 0, 0);
+        if (i + A_PREFETCH < K0 * 2) a[i % A_PREFETCH] = A[(i + A_PREFETCH) * 64];
+    }
+    return acc;
 }
 
 // 16-row output layer accumulated in fp32: init = bias (first) or the running tile (ALPHA -> RGB -> SEG)
@@ -145,38 +167,55 @@ __device__ __forceinline__ void dense_h_out(CtxH &cx, const Blk *in0, f32x16 &ac
     cx.begin_chunk();
     const bf16x8 *A = cx.cur() + cx.lane;
     if (first) acc = cx.bias16_half(bias_off);
-    acc = tile_mac<K0, 0, 0>(A, in0, nullptr, nullptr, acc);
+    acc = tile_mac<K0>(A, in0, acc);
     cx.end_chunk();
 }
 
+// ---- positional encoding for the bf16 path ------------------------------------------------------
+// Features are rounded to bf16 (8 significant bits) right after, so the hardware sine is ample:
+// v_sin_f32 takes its argument in revolutions, sin(2^k x) = v_sin(fract(2^k * x/2pi)), cos = sin(. + 1/4).
+// The power-of-two scaling is exact; the error is that of x/2pi (6e-8 relative, i.e. <= 2e-5 rad at the
+// top octave for |x| < 1) plus the instruction's ~1e-6.  The fp32 kernel keeps ocml's sincosf.
+struct PeSlot { float scale; float phase; int axis; int kind; };   // kind: 0 zero pad, 1 raw input, 2 sinusoid
 template <int D, int L>
-__device__ __forceinline__ float pe_feature_h(const float *v, int f)
+constexpr PeSlot pe_slot(int f)
 {
     constexpr int W = D + 2 * D * L;
-    float r = 0.0f;
-    if (f < D) {
-        r = (f == 0) ? v[0] : ((f == 1) ? v[1] : v[D > 2 ? 2 : 0]);
-    } else if (f < W) {
-        const int g = f - D;
-        const int k = g / (2 * D), rem = g % (2 * D);
-        const int fn = rem / D, ax = rem % D;
-        const float x = (ax == 0) ? v[0] : ((ax == 1) ? v[1] : v[D > 2 ? 2 : 0]);
-        float s, c;
-        sincosf(x * (float)(1 << k), &s, &c);
-        r = fn ? c : s;
-    }
-    return r;
+    if (f >= W) return PeSlot{0.0f, 0.0f, 0, 0};
+    if (f < D) return PeSlot{1.0f, 0.0f, f, 1};
+    const int g = f - D, k = g / (2 * D), rem = g % (2 * D);
+    return PeSlot{(float)(1 << k), (rem / D) ? 0.25f : 0.0f, rem % D, 2};
 }
 
 template <int D, int L, int NB>
 __device__ __forceinline__ void pe_blocks_h(const float *v, int h, Blk *out)
 {
+    float rev[3];
+#pragma unroll
+    for (int i = 0; i < D; ++i) rev[i] = v[i] * 0.15915494309189535f;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) out[b].s[s][j] = (__bf16)pe_feature_h<D, L>(v, 32 * b + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3));
+            for (int j = 0; j < 8; ++j) {
+                const int f0 = 32 * b + 16 * s + 8 * (j >> 2) + (j & 3);
+                constexpr PeSlot Z{0.0f, 0.0f, 0, 0};
+                const PeSlot a = pe_slot<D, L>(f0), c = pe_slot<D, L>(f0 + 4);   // lane half 0 / 1
+                float r;
+                if (a.kind == 0 && c.kind == 0) {
+                    r = 0.0f;
+                } else {
+                    const float xa = (a.kind == 1) ? v[a.axis] : rev[a.axis], xc = (c.kind == 1) ? v[c.axis] : rev[c.axis];
+                    const float x = h ? xc : xa;
+                    const float t = x * (h ? c.scale : a.scale) + (h ? c.phase : a.phase);
+                    const float sn = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t));
+                    const int kind = h ? c.kind : a.kind;
+                    r = (kind == 2) ? sn : ((kind == 1) ? x : 0.0f);
+                }
+                (void)Z;
+                out[b].s[s][j] = (__bf16)r;
+            }
 }
 
 // trilinear lookup (fp32, ATen corner order, zeros padding); this lane takes channels 16s + 8g + 4h + 0..3
