@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsahs_nerf.so")
+LIB_PATH = os.environ.get("SAHS_NERF_LIB") or os.path.join(_HERE, "libsahs_nerf.so")   # override: ablation builds (tools/ablate.py)
 SAHS_F32, SAHS_BF16 = 0, 1
 
 _P = ctypes.c_void_p

@@ -24,7 +24,11 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, defines=(), out=None):
+    """defines/out: ablation variants (tools/ablate.py) -- extra -D flags, separate output .so."""
+    global LIB
+    if out is not None:
+        LIB, force = out, True
     if not (force or _stale()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -32,10 +36,10 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     procs = []
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(HERE, "build", (os.path.basename(out) + "." if out else "") + src.replace(".hip", ".o"))
         objs.append(obj)
         extra = FIELD_FLAGS if src.startswith("field_") else []
-        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + extra + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))

@@ -27,7 +27,9 @@ constexpr int H_PTS_PER_WAVE = 32;
 constexpr int H_PTS_PER_WG = (H_THREADS / WAVE) * H_PTS_PER_WAVE;   // 256
 constexpr int LDS_BUF_BYTES = CHUNK_HW_MAX * 2;                       // 64 KB each, two of them
 constexpr int LDS_BIAS_BYTE_OFF = 2 * LDS_BUF_BYTES;
-constexpr int LDS_BYTES = LDS_BIAS_BYTE_OFF + ((BIAS_FLOATS + 3) / 4) * 16;
+constexpr int LDS_STASH_BYTE_OFF = LDS_BIAS_BYTE_OFF + ((BIAS_FLOATS + 3) / 4) * 16;
+constexpr int STASH_FLOATS = 8;                                       // per sample: x'[3], w[2] (+pad): cold across the trunk
+constexpr int LDS_BYTES = LDS_STASH_BYTE_OFF + H_PTS_PER_WG * STASH_FLOATS * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr int DBG_STRIDE_H = 56;
 
@@ -41,36 +43,60 @@ struct CtxH {
     int chunk, buf;
     int lane, h, wave;
 
-    __device__ __forceinline__ void issue(int c, int b)
+    // LDS-DMA of chunk c into buffer b, cut into pieces of 8 KB (one 1-KB global_load_lds per wave).
+    // A piece costs the issuing wave ~100+ cycles of issue time, so the pieces of the NEXT chunk are spread
+    // between the MFMAs of the current one (issue_piece) instead of being issued back to back.
+    // The chunk sequence is static, so offsets are tracked arithmetically (no table loads on the critical path):
+    // off = halfword offset of the chunk being prefetched; its size is passed by the layer code.
+    const f32x4 *nx_src; f32x4 *nx_dst; int nx_n16;
+    uint32_t off;          // halfword offset of the NEXT chunk to prefetch (uniform)
+    __device__ __forceinline__ void prepare(int hw, int b)
     {
-        const uint32_t o0 = table[c], o1 = table[c + 1];
-        const int n16 = (int)(o1 - o0) >> 3;                       // 16-byte pieces
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(stream + o0);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(lds + b * LDS_BUF_BYTES);
-        for (int base = wave * WAVE; base < n16; base += H_THREADS)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + base + lane), (lds_ptr_t)(dst + base), 16, 0, 0);
+        if (off >= (uint32_t)STREAM_HW) off = 0;                   // the stream wraps for the next sample tile
+        nx_n16 = hw >> 3;                                          // 16-byte units
+        nx_src = reinterpret_cast<const f32x4 *>(stream + off) + lane;
+        nx_dst = reinterpret_cast<f32x4 *>(lds + b * LDS_BUF_BYTES);
+        off += (uint32_t)hw;
     }
-    __device__ __forceinline__ void begin_chunk()
+    // piece p of the next chunk; the caller knows at compile time how many pieces that chunk has (no branch here, so a
+    // chunk's MFMA run stays one basic block and the scheduler may interleave across it)
+    __device__ __forceinline__ void issue_piece(int p)
     {
-        int nxt = chunk + 1;
-        if (nxt == NUM_CHUNKS_H) nxt = 0;
-        issue(nxt, buf ^ 1);
+#ifndef SAHS_ABLATE_NODMA
+        const int base = p * H_THREADS + wave * WAVE;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(nx_src + base), (lds_ptr_t)(nx_dst + base), 16, 0, 0);
+#endif
     }
+    __device__ __forceinline__ void begin_chunk(int next_hw) { prepare(next_hw, buf ^ 1); }
     __device__ __forceinline__ void end_chunk()
     {
+#ifndef SAHS_ABLATE_NOBARRIER
         __syncthreads();
+#endif
         chunk = (chunk + 1 == NUM_CHUNKS_H) ? 0 : chunk + 1;
         buf ^= 1;
     }
     __device__ __forceinline__ const bf16x8 *cur() const { return reinterpret_cast<const bf16x8 *>(lds + buf * LDS_BUF_BYTES); }
-    // bias of a 32-row tile in accumulator order: reg r <-> row (r&3) + 8(r>>2) + 4h
+    // accumulator register r of a 32-row tile <-> row (r&3) + 8(r>>2) + 4h: this lane's bias rows start at +4h, stride 8
+    // bias_lane = LDS address of this lane's first bias row; it is re-materialised (opaquely) once per sample tile so that
+    // the per-tile addresses are NOT hoisted out of the persistent loop (LICM would precompute ~140 of them and spill them;
+    // a spill reload inside a layer waits on vmcnt and thereby on the LDS-DMA prefetch).  All reads are base + immediate.
+    typedef const __attribute__((address_space(3))) float *lds_cfloat;   // stays an LDS pointer: a generic one would become flat_load (vmcnt!)
+    lds_cfloat bias_lane;
+    __device__ __forceinline__ void refresh_bias_base()
+    {
+        uint32_t a = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)lds) + LDS_BIAS_BYTE_OFF + 16 * h;
+        asm volatile("" : "+v"(a));
+        bias_lane = (lds_cfloat)(uintptr_t)a;
+    }
+    __device__ __forceinline__ lds_cfloat bias_ptr(int off) const { return bias_lane + off; }
     __device__ __forceinline__ f32x16 bias16(int off) const
     {
-        const float *b = reinterpret_cast<const float *>(lds + LDS_BIAS_BYTE_OFF) + off + 4 * h;
+        lds_cfloat b = bias_lane + off;
         f32x16 v;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(b + 8 * g);
+            const f32x4 t = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(b + 8 * g);
             v[4 * g + 0] = t[0]; v[4 * g + 1] = t[1]; v[4 * g + 2] = t[2]; v[4 * g + 3] = t[3];
         }
         return v;
@@ -78,11 +104,11 @@ struct CtxH {
     // 16-row layers (WF, HF, FINAL) occupy rows 0..15 of a 32-row tile: rows 16..31 (regs 8..15) carry no bias
     __device__ __forceinline__ f32x16 bias16_half(int off) const
     {
-        const float *b = reinterpret_cast<const float *>(lds + LDS_BIAS_BYTE_OFF) + off + 4 * h;
+        lds_cfloat b = bias_lane + off;
         f32x16 v;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(b + 8 * g);
+            const f32x4 t = *reinterpret_cast<const __attribute__((address_space(3))) f32x4 *>(b + 8 * g);
             v[4 * g + 0] = t[0]; v[4 * g + 1] = t[1]; v[4 * g + 2] = t[2]; v[4 * g + 3] = t[3];
         }
 #pragma unroll
@@ -95,16 +121,23 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // activation (slope in [0,1]: leaky relu == max(x, slope*x)) and fp32 -> bf16 pairs (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ Blk pack_act(const f32x16 acc, float slope)
+__device__ __forceinline__ Blk pack_act(const f32x16 acc, const __attribute__((address_space(3))) float *bias, float slope)   // bias: this lane's rows, LDS
 {
     Blk o;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         uint32_t w[4];
+        typedef const __attribute__((address_space(3))) f32x4 *lds_cf4;
+        const f32x4 b0 = *reinterpret_cast<lds_cf4>(bias + 16 * s), b1 = *reinterpret_cast<lds_cf4>(bias + 16 * s + 8);
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-            const float v0 = acc[8 * s + 2 * jp], v1 = acc[8 * s + 2 * jp + 1];
+            const float v0 = acc[8 * s + 2 * jp] + (jp < 2 ? b0[2 * jp] : b1[2 * jp - 4]);
+            const float v1 = acc[8 * s + 2 * jp + 1] + (jp < 2 ? b0[2 * jp + 1] : b1[2 * jp - 3]);
+#ifdef SAHS_ABLATE_NOACT
+            const f32x2 a = {v0, v1};
+#else
             const f32x2 a = {fmaxf(v0, v0 * slope), fmaxf(v1, v1 * slope)};
+#endif
             w[jp] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
         }
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -113,61 +146,95 @@ __device__ __forceinline__ Blk pack_act(const f32x16 acc, float slope)
     return o;
 }
 
-constexpr int A_PREFETCH = 4;   // A fragments (ds_read_b128 each) kept in flight ahead of the MFMA that consumes them
+constexpr int DMA_PIECES = LDS_BUF_BYTES / (H_THREADS * 16);   // 8 pieces of 8 KB cover the largest chunk
+constexpr int A_PREFETCH = 3;   // A fragments (ds_read_b128 each) kept in flight ahead of the MFMA that consumes them
 
 // hidden layer: NT32 output tiles, activation, bf16 repack.  A chunk is one flat run of G*KB*2 MFMAs;
 // the A-fragment reads run A_PREFETCH steps ahead, across tile boundaries.
-template <int K0, int K1, int K2, int NT32>
+// NEXT_HW: size (halfwords) of the chunk that follows this layer's last one (compile-time: the program is static)
+template <int K0, int K1, int K2, int NT32, int NEXT_HW>
 __device__ __forceinline__ void dense_h(CtxH &cx, const Blk *in0, const Blk *in1, const Blk *in2, Blk *out, int bias_off, float slope)
 {
     constexpr int KB = K0 + K1 + K2;
     constexpr int G = pick_G32(KB, NT32);
     constexpr int STEPS = KB * 2, TOTAL = G * STEPS;
+    // one DMA piece of the next chunk every PSTEP MFMAs, all within the first half of this chunk so that the last one has
+    // half a chunk of MFMA time to land before the vmcnt(0) + barrier that ends the chunk
+    constexpr int PSTEP = TOTAL >= 2 * DMA_PIECES ? TOTAL / (2 * DMA_PIECES) : 1;
 #pragma unroll
     for (int c = 0; c < NT32 / G; ++c) {
-        cx.begin_chunk();
+        const int nhw = (c + 1 < NT32 / G) ? G * KB * 1024 : NEXT_HW;          // constant after unrolling
+        const int npieces = (nhw + H_THREADS * 8 - 1) / (H_THREADS * 8);        // 8 KB = 4096 halfwords per piece
+        cx.begin_chunk(nhw);
         const bf16x8 *A = cx.cur() + cx.lane;
         bf16x8 a[A_PREFETCH];
 #pragma unroll
         for (int i = 0; i < A_PREFETCH; ++i) a[i] = A[i * 64];
-        f32x16 acc = cx.bias16(bias_off + 32 * (c * G));
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;      // bias is added at repack time: the chain starts from an inline zero
 #pragma unroll
         for (int i = 0; i < TOTAL; ++i) {
             const int g = i / STEPS, k = i % STEPS, b = k >> 1, st = k & 1;
             const Blk &x = (b < K0) ? in0[b] : ((b < K0 + K1) ? in1[b - K0] : in2[b - K0 - K1]);
+            if (i % PSTEP == 0 && i / PSTEP < npieces) cx.issue_piece(i / PSTEP);
+#ifdef SAHS_ABLATE_NOMFMA
+            if (i % 16 == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % A_PREFETCH], x.s[st], acc, 0, 0, 0);
+#else
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % A_PREFETCH], x.s[st], acc, 0, 0, 0);
+#endif
+#ifdef SAHS_ABLATE_NOLDSREAD
+            if (i + A_PREFETCH < TOTAL && (i % 16 == 0)) a[i % A_PREFETCH] = A[(i + A_PREFETCH) * 64];
+#else
             if (i + A_PREFETCH < TOTAL) a[i % A_PREFETCH] = A[(i + A_PREFETCH) * 64];
+#endif
             if (k == STEPS - 1) {
-                out[c * G + g] = pack_act(acc, slope);
-                if (g + 1 < G) acc = cx.bias16(bias_off + 32 * (c * G + g + 1));
+#ifdef SAHS_ABLATE_NOPACK
+                asm volatile("" :: "v"(acc));
+                Blk o = in0[0];
+#else
+                Blk o = pack_act(acc, cx.bias_ptr(bias_off + 32 * (c * G + g)), slope);
+#endif
+                // pin the repack HERE: otherwise LLVM sinks it to the next layer's first use and the 16-register fp32
+                // accumulator of every finished tile stays live instead of its 8-register bf16 form (=> spills)
+                asm volatile("" : "+v"(o.s[0]), "+v"(o.s[1]));
+                out[c * G + g] = o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             }
         }
+#pragma unroll
+        for (int pc = (TOTAL + PSTEP - 1) / PSTEP; pc < DMA_PIECES; ++pc)
+            if (pc < npieces) cx.issue_piece(pc);
         cx.end_chunk();
     }
 }
 
-template <int K0>
-__device__ __forceinline__ f32x16 tile_mac(const bf16x8 *A, const Blk *in0, f32x16 acc)
+template <int K0, int NPIECES>
+__device__ __forceinline__ f32x16 tile_mac(CtxH &cx, const bf16x8 *A, const Blk *in0, f32x16 acc)
 {
     bf16x8 a[A_PREFETCH];
 #pragma unroll
     for (int i = 0; i < A_PREFETCH; ++i) a[i] = A[i * 64];
 #pragma unroll
     for (int i = 0; i < K0 * 2; ++i) {
+        if (i < NPIECES) cx.issue_piece(i);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % A_PREFETCH], in0[i >> 1].s[i & 1], acc, 0, 0, 0);
         if (i + A_PREFETCH < K0 * 2) a[i % A_PREFETCH] = A[(i + A_PREFETCH) * 64];
     }
+#pragma unroll
+    for (int pc = K0 * 2; pc < NPIECES; ++pc) cx.issue_piece(pc);
     return acc;
 }
 
 // 16-row output layer accumulated in fp32: init = bias (first) or the running tile (ALPHA -> RGB -> SEG)
-template <int K0>
+template <int K0, int NEXT_HW>
 __device__ __forceinline__ void dense_h_out(CtxH &cx, const Blk *in0, f32x16 &acc, int bias_off, bool first)
 {
-    cx.begin_chunk();
+    cx.begin_chunk(NEXT_HW);
     const bf16x8 *A = cx.cur() + cx.lane;
     if (first) acc = cx.bias16_half(bias_off);
-    acc = tile_mac<K0>(A, in0, acc);
+    acc = tile_mac<K0, (NEXT_HW + H_THREADS * 8 - 1) / (H_THREADS * 8)>(cx, A, in0, acc);
     cx.end_chunk();
 }
 
@@ -256,6 +323,8 @@ __device__ __forceinline__ void grid_block_h(const float *__restrict__ grid, flo
     }
 }
 
+#define CH(id) (kProgH.layer[id].G32 * kProgH.layer[id].KB32 * 1024)   /* halfwords in one chunk of layer id */
+
 __device__ __forceinline__ float bcast32(float v, int lane) { return __shfl(v, lane & 31, WAVE); }
 
 __global__ void __launch_bounds__(H_THREADS, 2)
@@ -275,17 +344,27 @@ field_forward_bf16_kernel(const float *__restrict__ packed, const float *__restr
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float *grid = packed + PACKH_GRID_OFF;
     const int h = cx.h;
+#ifndef SAHS_ABLATE_NOPRIO
+    // The two waves of a SIMD run the same program in lock step (one barrier per chunk), so their MFMA chains and their
+    // VALU repack phases coincide and nothing overlaps.  A static priority for the second-dispatched half lets that wave
+    // take the matrix pipe whenever it wants it; its partner fills the gaps, which shifts the pair into anti-phase.
+    if (cx.wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     {
         const float *bsrc = frame + FRAME_BIAS_OFF + level * BIAS_FLOATS;
         float *bl = reinterpret_cast<float *>(lds_h + LDS_BIAS_BYTE_OFF);
         for (int i = threadIdx.x; i < BIAS_FLOATS; i += H_THREADS) bl[i] = bsrc[i];
-        cx.issue(0, 0);
+        cx.off = 0;
+        cx.prepare(CH(H_W0), 0);
+#pragma unroll
+        for (int pc = 0; pc < (CH(H_W0) + H_THREADS * 8 - 1) / (H_THREADS * 8); ++pc) cx.issue_piece(pc);
         __syncthreads();
     }
     constexpr const LayerH *Ly = kProgH.layer;
 
     const long ntiles = (P + H_PTS_PER_WG - 1) / H_PTS_PER_WG;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        cx.refresh_bias_base();
         const long p_raw = tile * H_PTS_PER_WG + cx.wave * H_PTS_PER_WAVE + (cx.lane & 31);
         const long p = p_raw < P ? p_raw : P - 1;
         const long ray = p / S;
@@ -298,95 +377,137 @@ field_forward_bf16_kernel(const float *__restrict__ packed, const float *__restr
 
         Blk pe_x[2];
         pe_blocks_h<3, 10, 2>(x, h, pe_x);
-        float xw[3], amb[2];
+        // x' (3) and w (2) are parked in LDS between their uses (trunk input, skip-layer input, grid lookup): every VGPR that
+        // is live across the 256-wide layers is one the register allocator would otherwise spill to scratch, and a scratch
+        // reload is a VMEM op whose s_waitcnt also drains the in-flight LDS-DMA weight prefetch.
+        float *stash = reinterpret_cast<float *>(lds_h + LDS_STASH_BYTE_OFF) + (cx.wave * H_PTS_PER_WAVE + (cx.lane & 31)) * STASH_FLOATS;
         {   // warp field
             Blk hh[4], hn[4];
-            dense_h<2, 0, 0, 4>(cx, pe_x, nullptr, nullptr, hh, Ly[H_W0].bias_off, 0.0f);
+            dense_h<2, 0, 0, 4, CH(H_W1)>(cx, pe_x, nullptr, nullptr, hh, Ly[H_W0].bias_off, 0.0f);
 #pragma unroll 1
-            for (int l = 0; l < 3; ++l) {
-                dense_h<4, 0, 0, 4>(cx, hh, nullptr, nullptr, hn, Ly[H_W1].bias_off + 128 * l, 0.0f);
+            for (int l = 0; l < 2; ++l) {
+                dense_h<4, 0, 0, 4, CH(H_W1)>(cx, hh, nullptr, nullptr, hn, Ly[H_W1].bias_off + 128 * l, 0.0f);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hh[i] = hn[i];
             }
-            dense_h<4, 2, 0, 4>(cx, hh, pe_x, nullptr, hn, Ly[H_W4].bias_off, 0.0f);
-            dense_h<4, 0, 0, 4>(cx, hn, nullptr, nullptr, hh, Ly[H_W5].bias_off, 0.0f);
-            f32x16 o;
-            dense_h_out<4>(cx, hh, o, Ly[H_WF].bias_off, true);
+            dense_h<4, 0, 0, 4, CH(H_W4)>(cx, hh, nullptr, nullptr, hn, Ly[H_W3].bias_off, 0.0f);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) xw[i] = x[i] + tanhf(bcast32(o[i], cx.lane));
+            for (int i = 0; i < 4; ++i) hh[i] = hn[i];
+            dense_h<4, 2, 0, 4, CH(H_W5)>(cx, hh, pe_x, nullptr, hn, Ly[H_W4].bias_off, 0.0f);
+            dense_h<4, 0, 0, 4, CH(H_WF)>(cx, hn, nullptr, nullptr, hh, Ly[H_W5].bias_off, 0.0f);
+            f32x16 o;
+            dense_h_out<4, CH(H_H0)>(cx, hh, o, Ly[H_WF].bias_off, true);
+            if (h == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) stash[i] = x[i] + tanhf(o[i]);            // models.py:305 (rows 0..2 live in lane half 0)
+            }
         }
         {   // hyper sheet
             Blk hh[2], hn[2];
-            dense_h<2, 0, 0, 2>(cx, pe_x, nullptr, nullptr, hh, Ly[H_H0].bias_off, 0.0f);
+            dense_h<2, 0, 0, 2, CH(H_H1)>(cx, pe_x, nullptr, nullptr, hh, Ly[H_H0].bias_off, 0.0f);
 #pragma unroll 1
-            for (int l = 0; l < 3; ++l) {
-                dense_h<2, 0, 0, 2>(cx, hh, nullptr, nullptr, hn, Ly[H_H1].bias_off + 64 * l, 0.0f);
+            for (int l = 0; l < 2; ++l) {
+                dense_h<2, 0, 0, 2, CH(H_H1)>(cx, hh, nullptr, nullptr, hn, Ly[H_H1].bias_off + 64 * l, 0.0f);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) hh[i] = hn[i];
             }
-            dense_h<2, 2, 0, 2>(cx, hh, pe_x, nullptr, hn, Ly[H_H4].bias_off, 0.0f);
-            dense_h<2, 0, 0, 2>(cx, hn, nullptr, nullptr, hh, Ly[H_H5].bias_off, 0.0f);
+            dense_h<2, 0, 0, 2, CH(H_H4)>(cx, hh, nullptr, nullptr, hn, Ly[H_H3].bias_off, 0.0f);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) hh[i] = hn[i];
+            dense_h<2, 2, 0, 2, CH(H_H5)>(cx, hh, pe_x, nullptr, hn, Ly[H_H4].bias_off, 0.0f);
+            dense_h<2, 0, 0, 2, CH(H_HF)>(cx, hn, nullptr, nullptr, hh, Ly[H_H5].bias_off, 0.0f);
             f32x16 o;
-            dense_h_out<2>(cx, hh, o, Ly[H_HF].bias_off, true);
-            amb[0] = bcast32(o[0], cx.lane);
-            amb[1] = bcast32(o[1], cx.lane);
+            dense_h_out<2, CH(H_T0)>(cx, hh, o, Ly[H_HF].bias_off, true);
+            if (h == 0) { stash[3] = o[0]; stash[4] = o[1]; }
         }
-        float *dsl = dbg + p * DBG_STRIDE_H;
+        __builtin_amdgcn_wave_barrier();
         if (dbg != nullptr && h == 0 && p_raw < P) {
-            dsl[0] = xw[0] - x[0]; dsl[1] = xw[1] - x[1]; dsl[2] = xw[2] - x[2]; dsl[3] = amb[0]; dsl[4] = amb[1];
+            float *dsl = dbg + p * DBG_STRIDE_H;
+            dsl[0] = stash[0] - x[0]; dsl[1] = stash[1] - x[1]; dsl[2] = stash[2] - x[2]; dsl[3] = stash[3]; dsl[4] = stash[4];
         }
         // radiance trunk
         Blk feat[8];
         f32x16 fin;
         {
-            Blk in_tr[3];
-            pe_blocks_h<3, 10, 2>(xw, h, in_tr);
-            pe_blocks_h<2, 4, 1>(amb, h, in_tr + 2);
             Blk hh[8];
-            dense_h<2, 1, 0, 8>(cx, in_tr, in_tr + 2, nullptr, hh, Ly[H_T0].bias_off, 0.01f);
-#pragma unroll 1
-            for (int l = 1; l <= 8; ++l) {
-                if (l == 3) {
-                    dense_h<8, 2, 1, 8>(cx, hh, in_tr, in_tr + 2, feat, Ly[H_T3].bias_off, 0.01f);
-                } else {
-                    const int boff = (l < 3) ? Ly[H_T1].bias_off + 256 * (l - 1) : Ly[H_T4].bias_off + 256 * (l - 4);
-                    dense_h<8, 0, 0, 8>(cx, hh, nullptr, nullptr, feat, boff, l == 8 ? 1.0f : 0.01f);
-                }
-                if (l < 8) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) hh[i] = feat[i];
-                }
+            {   // the re-injected encoding [PE(x') | PE(w)] is rebuilt at the skip layer instead of staying live (24 VGPRs)
+                Blk in_tr[3];
+                const float xw[3] = {stash[0], stash[1], stash[2]}, amb[2] = {stash[3], stash[4]};
+                pe_blocks_h<3, 10, 2>(xw, h, in_tr);
+                pe_blocks_h<2, 4, 1>(amb, h, in_tr + 2);
+                dense_h<2, 1, 0, 8, CH(H_T1)>(cx, in_tr, in_tr + 2, nullptr, hh, Ly[H_T0].bias_off, 0.01f);
             }
+            // T1, T2, T3 (skip), T4..T7, FEAT: 256-wide layers; hh <- feat between them
+            dense_h<8, 0, 0, 8, CH(H_T2)>(cx, hh, nullptr, nullptr, feat, Ly[H_T1].bias_off, 0.01f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hh[i] = feat[i];
+            dense_h<8, 0, 0, 8, CH(H_T3)>(cx, hh, nullptr, nullptr, feat, Ly[H_T2].bias_off, 0.01f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hh[i] = feat[i];
+            {
+                Blk in_tr[3];
+                const float xw[3] = {stash[0], stash[1], stash[2]}, amb[2] = {stash[3], stash[4]};
+                pe_blocks_h<3, 10, 2>(xw, h, in_tr);
+                pe_blocks_h<2, 4, 1>(amb, h, in_tr + 2);
+                dense_h<8, 2, 1, 8, CH(H_T4)>(cx, hh, in_tr, in_tr + 2, feat, Ly[H_T3].bias_off, 0.01f);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hh[i] = feat[i];
+#pragma unroll 1
+            for (int l = 4; l <= 7; ++l) {
+                dense_h<8, 0, 0, 8, CH(H_T5)>(cx, hh, nullptr, nullptr, feat, Ly[H_T4].bias_off + 256 * (l - 4), 0.01f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) hh[i] = feat[i];
+            }
+            dense_h<8, 0, 0, 8, CH(H_ALPHA)>(cx, hh, nullptr, nullptr, feat, Ly[H_FEAT].bias_off, 1.0f);
         }
-        dense_h_out<8>(cx, feat, fin, Ly[H_ALPHA].bias_off, true);
+        dense_h_out<8, CH(H_D0)>(cx, feat, fin, Ly[H_ALPHA].bias_off, true);
         {   // colour branch
             Blk in_d[2];
-            pe_blocks_h<3, 4, 1>(rd, h, in_d);
-            grid_block_h(grid, xw[0], xw[1], xw[2], h, in_d[1], (dbg != nullptr && p_raw < P) ? dbg + P * DBG_STRIDE_H + p * 32 : nullptr);
+            {
+                const long pr = tile * H_PTS_PER_WG + cx.wave * H_PTS_PER_WAVE + (cx.lane & 31);
+                const long pp = pr < P ? pr : P - 1;
+                const float *rq = rays + (pp / S) * ray_stride;
+                const float rdir[3] = {rq[3], rq[4], rq[5]};                         // re-read: cheaper than keeping it live
+                pe_blocks_h<3, 4, 1>(rdir, h, in_d);
+                grid_block_h(grid, stash[0], stash[1], stash[2], h, in_d[1], (dbg != nullptr && pr < P) ? dbg + P * DBG_STRIDE_H + pp * 32 : nullptr);
+            }
             Blk c[4], cn[4];
-            dense_h<8, 1, 1, 4>(cx, feat, in_d, in_d + 1, c, Ly[H_D0].bias_off, 0.01f);
+            dense_h<8, 1, 1, 4, CH(H_D1)>(cx, feat, in_d, in_d + 1, c, Ly[H_D0].bias_off, 0.01f);
 #pragma unroll 1
-            for (int l = 0; l < 3; ++l) {
-                dense_h<4, 0, 0, 4>(cx, c, nullptr, nullptr, cn, Ly[H_D1].bias_off + 128 * l, 0.01f);
+            for (int l = 0; l < 2; ++l) {
+                dense_h<4, 0, 0, 4, CH(H_D1)>(cx, c, nullptr, nullptr, cn, Ly[H_D1].bias_off + 128 * l, 0.01f);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) c[i] = cn[i];
             }
-            dense_h_out<4>(cx, c, fin, 0, false);
+            dense_h<4, 0, 0, 4, CH(H_RGB)>(cx, c, nullptr, nullptr, cn, Ly[H_D3].bias_off, 0.01f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = cn[i];
+            dense_h_out<4, CH(H_S0)>(cx, c, fin, 0, false);
         }
         {   // seg branch
             Blk s[4], sn[4];
-            dense_h<8, 0, 0, 4>(cx, feat, nullptr, nullptr, s, Ly[H_S0].bias_off, 0.01f);
+            dense_h<8, 0, 0, 4, CH(H_S1)>(cx, feat, nullptr, nullptr, s, Ly[H_S0].bias_off, 0.01f);
 #pragma unroll 1
-            for (int l = 0; l < 3; ++l) {
-                dense_h<4, 0, 0, 4>(cx, s, nullptr, nullptr, sn, Ly[H_S1].bias_off + 128 * l, 0.01f);
+            for (int l = 0; l < 2; ++l) {
+                dense_h<4, 0, 0, 4, CH(H_S1)>(cx, s, nullptr, nullptr, sn, Ly[H_S1].bias_off + 128 * l, 0.01f);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s[i] = sn[i];
             }
-            dense_h_out<4>(cx, s, fin, 0, false);
+            dense_h<4, 0, 0, 4, CH(H_SEG)>(cx, s, nullptr, nullptr, sn, Ly[H_S3].bias_off, 0.01f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] = sn[i];
+            dense_h_out<4, CH(H_W0)>(cx, s, fin, 0, false);
         }
-        if (p_raw < P) {   // rows 4h..4h+3 and 8+4h..8+4h+3 of [rgb3 | seg12 | sigma]
-            *reinterpret_cast<f32x4 *>(raw + p * D_RAW + 4 * h) = f32x4{fin[0], fin[1], fin[2], fin[3]};
-            *reinterpret_cast<f32x4 *>(raw + p * D_RAW + 8 + 4 * h) = f32x4{fin[4], fin[5], fin[6], fin[7]};
+        const long p_out = tile * H_PTS_PER_WG + cx.wave * H_PTS_PER_WAVE + (cx.lane & 31);
+        if (p_out < P) {   // rows 4h..4h+3 and 8+4h..8+4h+3 of [rgb3 | seg12 | sigma]
+#ifdef SAHS_ABLATE_NTSTORE
+            __builtin_nontemporal_store(f32x4{fin[0], fin[1], fin[2], fin[3]}, reinterpret_cast<f32x4 *>(raw + p_out * D_RAW + 4 * h));
+            __builtin_nontemporal_store(f32x4{fin[4], fin[5], fin[6], fin[7]}, reinterpret_cast<f32x4 *>(raw + p_out * D_RAW + 8 + 4 * h));
+#else
+            *reinterpret_cast<f32x4 *>(raw + p_out * D_RAW + 4 * h) = f32x4{fin[0], fin[1], fin[2], fin[3]};
+            *reinterpret_cast<f32x4 *>(raw + p_out * D_RAW + 8 + 4 * h) = f32x4{fin[4], fin[5], fin[6], fin[7]};
+#endif
         }
     }
 }

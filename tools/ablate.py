@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Timing-only ablations of the field kernels (results of ablated builds are WRONG by construction).
+Build here:  python tools/ablate.py build      (variants -> sahs-deformable-nerf_amd/build/variants/)
+Run on GPU:  python tools/ablate.py run [bf16|fp32]
+"""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VDIR = os.path.join(REPO, "sahs-deformable-nerf_amd", "build", "variants")
+VARIANTS = {"base": [], "noprio": ["SAHS_ABLATE_NOPRIO"], "nopack": ["SAHS_ABLATE_NOPACK"], "nopack_nodma": ["SAHS_ABLATE_NOPACK", "SAHS_ABLATE_NODMA"],
+            "nopack_nodma_nolds": ["SAHS_ABLATE_NOPACK", "SAHS_ABLATE_NODMA", "SAHS_ABLATE_NOLDSREAD"], "nodma": ["SAHS_ABLATE_NODMA"], "nomfma": ["SAHS_ABLATE_NOMFMA"], "nomfma_nodma": ["SAHS_ABLATE_NOMFMA", "SAHS_ABLATE_NODMA"],
+            "noldsread": ["SAHS_ABLATE_NOLDSREAD"], "noldsread_nodma": ["SAHS_ABLATE_NOLDSREAD", "SAHS_ABLATE_NODMA"],
+            "ntstore": ["SAHS_ABLATE_NTSTORE"], "noact": ["SAHS_ABLATE_NOACT"]}
+
+
+def build():
+    spec = importlib.util.spec_from_file_location("sahs_build", os.path.join(REPO, "sahs-deformable-nerf_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    os.makedirs(VDIR, exist_ok=True)
+    for name, defs in VARIANTS.items():
+        print(mod.build(defines=defs, out=os.path.join(VDIR, "libsahs_%s.so" % name)))
+
+
+def time_one(precision, libpath=None):
+    import numpy as np
+    import torch
+    sys.path.insert(0, REPO)
+    pkg = importlib.import_module("sahs-deformable-nerf_amd")
+    if libpath is not None:      # swap the bound library in-process (one torch import for all variants)
+        pkg._lib._lib, pkg._lib.LIB_PATH = None, libpath
+    dev = torch.device("cuda:0")
+    W = pkg.weights
+    flat = torch.from_numpy(W.flatten_state_dict(W.hash_state_dict(0, 8.0, 30.0))).to(dev)
+    prec = pkg.ops.PRECISIONS[precision]
+    packed = pkg.ops.pack_weights(flat, prec)
+    rng = np.random.default_rng(0)
+    frame = pkg.ops.fold_conditioning(flat, torch.from_numpy(rng.standard_normal((16, 29)).astype(np.float32)).to(dev),
+                                      torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32)).to(dev))
+    N, S = 131072, 128
+    rays = torch.zeros(N, 8, device=dev)
+    rays[:, 2] = 0.8
+    rays[:, 3:6] = torch.randn(N, 3, device=dev) * 0.15 + torch.tensor([0, 0, -1.0], device=dev)
+    z = torch.sort(torch.rand(N, S, device=dev) * 0.6 + 0.48, dim=1).values
+    raw = torch.empty(N, S, 16, device=dev)
+    for _ in range(2):
+        pkg.ops.field_forward(packed, frame, 1, rays, z, precision=prec, out=raw)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        pkg.ops.field_forward(packed, frame, 1, rays, z, precision=prec, out=raw)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    return {"ms": round(ms, 3), "tflops": round(N * S * 1855744 / ms / 1e9, 1)}
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    else:
+        precision = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+        names = sys.argv[3].split(",") if len(sys.argv) > 3 else list(VARIANTS)
+        for rep in range(2):
+            for name in names:
+                print("%-18s %s" % (name, time_one(precision, os.path.join(VDIR, "libsahs_%s.so" % name))), flush=True)
