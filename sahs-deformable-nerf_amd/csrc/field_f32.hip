@@ -35,102 +35,118 @@ constexpr int LDS_BIAS_OFF = 2 * LDS_BUF_FLOATS;
 constexpr int LDS_FLOATS = LDS_BIAS_OFF + ((BIAS_FLOATS + 3) / 4) * 4;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
-enum Init { INIT_BIAS = 0, INIT_ACCUM = 1 };
-
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+typedef const __attribute__((address_space(3))) float *lds_cfloat;
+typedef const __attribute__((address_space(3))) f32x4 *lds_cf4;
+
+constexpr int LDS_STASH_OFF = LDS_BIAS_OFF + ((BIAS_FLOATS + 3) / 4) * 4;     // floats
+constexpr int STASH_FLOATS = 8;                                                // per sample: x'[3], w[2] (+pad)
+constexpr int LDS_TOTAL_FLOATS = LDS_STASH_OFF + F32_PTS_PER_WG * STASH_FLOATS;
+static_assert(LDS_TOTAL_FLOATS * 4 <= 160 * 1024, "LDS budget");
+constexpr int PIECE_FLOATS = F32_THREADS * 4;                                  // one DMA piece = 8 KB (1 KB per wave)
+constexpr int MAX_PIECES = LDS_BUF_FLOATS / PIECE_FLOATS;                      // 4
+constexpr int A_AHEAD = 3;                                                     // A fragments (one ds_read_b128 = 4 MFMAs) in flight
 
 struct Ctx {
     const float *stream;      // this level's packed weight stream (global)
-    const uint32_t *table;    // chunk start offsets (floats), NUM_CHUNKS + 1 entries
     float *lds;               // dynamic LDS base
-    int chunk;                // index of the chunk currently resident (uniform)
-    int buf;                  // LDS buffer (0/1) holding it; toggles per chunk (NUM_CHUNKS is odd, the stream wraps)
+    int buf;                  // LDS buffer (0/1) holding the current chunk; toggles per chunk (the chunk count is odd, the stream wraps)
     int lane, q, wave;
+    // Next chunk's LDS-DMA.  The chunk sequence is static, so its offset is tracked arithmetically (no table load on the
+    // critical path) and its size -- hence its number of 8-KB pieces -- is a compile-time constant at every call site.
+    uint32_t off;             // float offset of the next chunk to prefetch (uniform)
+    const f32x4 *nx_src; f32x4 *nx_dst;
+    lds_cfloat bias_lane;     // LDS address of this lane's bias rows (refreshed opaquely per sample tile: see refresh())
 
-    // async copy of chunk c into buffer b: global_load_lds writes LDS at (wave-uniform base + lane*16)
-    __device__ __forceinline__ void issue(int c, int b)
+    __device__ __forceinline__ void begin_chunk(int next_floats)
     {
-        const uint32_t o0 = table[c], o1 = table[c + 1];
-        const int n16 = (int)(o1 - o0) >> 2;
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(stream + o0);
-        f32x4 *dst = reinterpret_cast<f32x4 *>(lds + b * LDS_BUF_FLOATS);
-        for (int base = wave * WAVE; base < n16; base += F32_THREADS)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + base + lane), (lds_ptr_t)(dst + base), 16, 0, 0);
+        if (off >= (uint32_t)STREAM_FLOATS) off = 0;
+        nx_src = reinterpret_cast<const f32x4 *>(stream + off) + lane;
+        nx_dst = reinterpret_cast<f32x4 *>(lds + (buf ^ 1) * LDS_BUF_FLOATS);
+        off += (uint32_t)next_floats;
     }
-    __device__ __forceinline__ void begin_chunk()
+    __device__ __forceinline__ void issue_piece(int p)   // global_load_lds writes LDS at (wave-uniform base + lane*16)
     {
-        int nxt = chunk + 1;
-        if (nxt == NUM_CHUNKS) nxt = 0;
-        issue(nxt, buf ^ 1);
+#ifndef SAHS_ABLATE_NODMA
+        const int base = p * F32_THREADS + wave * WAVE;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(nx_src + base), (lds_ptr_t)(nx_dst + base), 16, 0, 0);
+#endif
     }
     __device__ __forceinline__ void end_chunk()
     {
+#ifndef SAHS_ABLATE_NOBARRIER
         __syncthreads();   // drains the in-flight global_load_lds (vmcnt(0)) and orders buffer reuse
-        chunk = (chunk + 1 == NUM_CHUNKS) ? 0 : chunk + 1;
+#endif
         buf ^= 1;
     }
     __device__ __forceinline__ const f32x4 *cur() const { return reinterpret_cast<const f32x4 *>(lds + buf * LDS_BUF_FLOATS); }
-    __device__ __forceinline__ f32x4 bias4(int off) const   // off: float offset of a 16-row tile's bias
+    // Without the opaque refresh LICM precomputes every tile's bias address outside the persistent loop (~280 VGPRs' worth),
+    // spills them, and each reload (a scratch = VMEM op) then waits on vmcnt -- i.e. on the LDS-DMA weight prefetch.
+    __device__ __forceinline__ void refresh()
     {
-        return *reinterpret_cast<const f32x4 *>(lds + LDS_BIAS_OFF + off + 4 * q);
+        uint32_t a = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)lds) + (LDS_BIAS_OFF + 4 * q) * 4;
+        asm volatile("" : "+v"(a));
+        bias_lane = (lds_cfloat)(uintptr_t)a;
     }
+    __device__ __forceinline__ f32x4 bias4(int off_) const { return *reinterpret_cast<lds_cf4>(bias_lane + off_); }
 };
 
-__device__ __forceinline__ f32x4 act4(f32x4 v, float slope)
+__device__ __forceinline__ f32x4 act4(f32x4 v, float slope)   // slope in [0,1]: leaky relu == max(x, slope*x)
 {
     f32x4 o;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = v[r] > 0.0f ? v[r] : v[r] * slope;
+    for (int r = 0; r < 4; ++r) o[r] = fmaxf(v[r], v[r] * slope);
     return o;
 }
 
-__device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 acc)
-{
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[r], acc, 0, 0, 0);
-    return acc;
-}
-
-// One dense layer.  in0[KB0] ++ in1[KB1] are the input k-blocks; out[NT] the output tiles.
+// One dense layer.  in0[KB0] ++ in1[KB1] are the input k-blocks (16 features each); out[NT] the 16-row output tiles.
 // slope: 1 = no activation, 0 = relu, 0.01 = leaky relu.  accum: start from out[] instead of the bias.
-template <int KB0, int KB1, int NT>
+// NEXT = floats in the chunk that follows this layer's last chunk.
+// A chunk is a flat run of G*KB steps; step = one A fragment (ds_read_b128) feeding 4 MFMAs.  Tiles are taken in pairs so
+// two independent accumulation chains alternate (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
+template <int KB0, int KB1, int NT, int NEXT>
 __device__ __forceinline__ void dense(Ctx &cx, const f32x4 *in0, const f32x4 *in1, f32x4 *out, int bias_off, bool accum, float slope)
 {
     constexpr int KB = KB0 + KB1;
     constexpr int G = pick_G(KB, NT);
+    constexpr int NCH = NT / G;
+    constexpr int PAIR = (G >= 2) ? 2 : 1;             // tiles interleaved
+    constexpr int STEPS = G * KB;                      // A fragments per chunk
 #pragma unroll
-    for (int c = 0; c < NT / G; ++c) {
-        cx.begin_chunk();
+    for (int c = 0; c < NCH; ++c) {
+        const int nfl = (c + 1 < NCH) ? G * KB * 256 : NEXT;
+        const int npieces = (nfl + PIECE_FLOATS - 1) / PIECE_FLOATS;
+        // pieces of the next chunk go out during the first half of this chunk's steps
+        const int pstep = (STEPS / 2 >= npieces) ? (STEPS / 2) / npieces : 1;
+        cx.begin_chunk(nfl);
         const f32x4 *A = cx.cur() + cx.lane;
-        if constexpr (G >= 2) {
+        // step s -> (pair p, block b, member m): order p-major, then b, then m
+        auto frag = [&](int s) { const int pp = s / (PAIR * KB), r = s % (PAIR * KB); return ((pp * PAIR + r % PAIR) * KB + r / PAIR) * 64; };
+        f32x4 a[A_AHEAD];
 #pragma unroll
-            for (int g = 0; g < G; g += 2) {
-                const int t0 = c * G + g;
-                f32x4 acc0 = accum ? out[t0] : cx.bias4(bias_off + 16 * t0);
-                f32x4 acc1 = accum ? out[t0 + 1] : cx.bias4(bias_off + 16 * (t0 + 1));
+        for (int s = 0; s < A_AHEAD && s < STEPS; ++s) a[s] = A[frag(s)];
+        f32x4 acc[PAIR];
 #pragma unroll
-                for (int b = 0; b < KB; ++b) {
-                    const f32x4 x = (b < KB0) ? in0[b] : in1[b - KB0];
-                    acc0 = mfma4(A[(g * KB + b) * 64], x, acc0);
-                    acc1 = mfma4(A[((g + 1) * KB + b) * 64], x, acc1);
-                }
-                out[t0] = act4(acc0, slope);
-                out[t0 + 1] = act4(acc1, slope);
+        for (int s = 0; s < STEPS; ++s) {
+            const int pp = s / (PAIR * KB), r = s % (PAIR * KB), m = r % PAIR, b = r / PAIR;
+            const int t = c * G + pp * PAIR + m;
+            if (b == 0) acc[m] = accum ? out[t] : cx.bias4(bias_off + 16 * t);
+            if (s % pstep == 0 && s / pstep < npieces) cx.issue_piece(s / pstep);
+            const f32x4 x = (b < KB0) ? in0[b] : in1[b - KB0];
+            const f32x4 w = a[s % A_AHEAD];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[k], x[k], acc[m], 0, 0, 0);
+            if (s + A_AHEAD < STEPS) a[s % A_AHEAD] = A[frag(s + A_AHEAD)];
+            if (b == KB - 1) {
+                f32x4 o = act4(acc[m], slope);
+                asm volatile("" : "+v"(o));     // pin: keep the finished tile from being sunk into the next layer
+                out[t] = o;
             }
-        } else {
-            // single tile per chunk: two accumulation chains over alternating k-blocks
-            const int t0 = c;
-            f32x4 acc0 = accum ? out[t0] : cx.bias4(bias_off + 16 * t0);
-            f32x4 acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int b = 0; b < KB; b += 2) {
-                acc0 = mfma4(A[b * 64], (b < KB0) ? in0[b] : in1[b - KB0], acc0);
-                if (b + 1 < KB) acc1 = mfma4(A[(b + 1) * 64], (b + 1 < KB0) ? in0[b + 1] : in1[b + 1 - KB0], acc1);
-            }
-            out[t0] = act4(acc0 + acc1, slope);
         }
+#pragma unroll
+        for (int pc = (STEPS + pstep - 1) / pstep; pc < MAX_PIECES; ++pc)
+            if (pc < npieces) cx.issue_piece(pc);
         cx.end_chunk();
     }
 }
@@ -138,33 +154,66 @@ __device__ __forceinline__ void dense(Ctx &cx, const f32x4 *in0, const f32x4 *in
 // ---- positional encoding in B layout ----------------------------------------------------------
 // feature f of positional_encoding(v[0:d], L, include_input=True): [v | sin(2^0 v) | cos(2^0 v) | ...]
 // (nerf_helpers.py:322-349); f >= d+2dL is zero padding.
-template <int D, int L>
-__device__ __forceinline__ float pe_feature(const float *v, int f)
+//
+// sin/cos(2^k x) to ~1e-7 absolute, without a general-purpose range reduction: the octave scaling is a power
+// of two, so the angle is reduced in REVOLUTIONS.  u = x/(2 pi) is formed once per coordinate as an unevaluated
+// sum p + lo (error-free product with a two-term 1/(2 pi), ~48 bits); 2^k p and 2^k lo are exact, 2^k p - rint(2^k p)
+// is exact, so the fraction f of a revolution carries only lo's error (<= 2^-48 * 2^k |u|).  Then the quadrant is
+// peeled off and sin/cos(2 pi g), |g| <= 1/8, are the classic minimax polynomials on [-pi/4, pi/4] (1 ulp).
+// The reference evaluates sin(fl(2^k x)) with SLEEF/libm (1 ulp): both are within rounding of the true value.
+struct RevArg { float p, lo; };
+__device__ __forceinline__ RevArg rev_arg(float x)
 {
-    constexpr int W = D + 2 * D * L;
-    float r = 0.0f;
-    if (f < D) {
-        r = (f == 0) ? v[0] : ((f == 1) ? v[1] : v[D > 2 ? 2 : 0]);
-    } else if (f < W) {
-        const int g = f - D;
-        const int k = g / (2 * D), rem = g % (2 * D);
-        const int fn = rem / D, ax = rem % D;
-        const float x = (ax == 0) ? v[0] : ((ax == 1) ? v[1] : v[D > 2 ? 2 : 0]);
-        const float t = x * (float)(1 << k);
-        float s, c;
-        sincosf(t, &s, &c);
-        r = fn ? c : s;
-    }
+    const float C_HI = 0.15915494f;                 // fl(1/(2 pi))
+    const float C_LO = 6.4206382e-09f;              // 1/(2 pi) - C_HI
+    RevArg r;
+    r.p = x * C_HI;
+    r.lo = fmaf(x, C_LO, fmaf(x, C_HI, -r.p));
     return r;
+}
+// sin(2^k x + fn*pi/2) given rev_arg(x) and scale = 2^k
+__device__ __forceinline__ float sin_octave(RevArg u, float scale, int fn)
+{
+#ifdef SAHS_ABLATE_NOPE
+    return u.p * scale + (float)fn;
+#else
+    const float P = u.p * scale, Lo = u.lo * scale;                 // exact
+    const float f = (P - rintf(P)) + Lo;                            // fraction of a revolution, [-1/2, 1/2]
+    const float qf = rintf(4.0f * f);
+    const float th = fmaf(qf, -0.25f, f) * 6.2831855f;              // |th| <= pi/4
+    const float z = th * th;
+    const float sp = fmaf(th * z, fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), th);
+    const float cp = fmaf(z * z, fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), fmaf(z, -0.5f, 1.0f));
+    const int m = ((int)qf + fn) & 3;                               // sin(th + m pi/2)
+    const float v = (m & 1) ? cp : sp;
+    return (m & 2) ? -v : v;
+#endif
 }
 
 template <int D, int L, int NB>
 __device__ __forceinline__ void pe_blocks(const float *v, int q, f32x4 *out)
 {
+    constexpr int W = D + 2 * D * L;
+    RevArg u[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) u[i] = rev_arg(v[i]);
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[b][r] = pe_feature<D, L>(v, 16 * b + 4 * q + r);
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * b + 4 * q + r;
+            float val = 0.0f;
+            if (f < D) {
+                val = (f == 0) ? v[0] : ((f == 1) ? v[1] : v[D > 2 ? 2 : 0]);
+            } else if (f < W) {
+                const int g = f - D;
+                const int k = g / (2 * D), rem = g % (2 * D);
+                const int fn = rem / D, ax = rem % D;
+                const RevArg a = (ax == 0) ? u[0] : ((ax == 1) ? u[1] : u[D > 2 ? 2 : 0]);
+                val = sin_octave(a, (float)(1 << k), fn);
+            }
+            out[b][r] = val;
+        }
 }
 
 // ---- trilinear feature-grid lookup (models.py:346-365; ATen grid_sampler_3d, align_corners=True,
@@ -196,7 +245,7 @@ __device__ __forceinline__ void grid_blocks(const float *__restrict__ grid, floa
     }
 }
 
-__device__ __forceinline__ float bcast16(float v, int lane) { return __shfl(v, lane & 15, WAVE); }
+#define CHF(id) (kProg.layer[id].G * kProg.layer[id].KB * 256)   /* floats in one chunk of layer id */
 
 __global__ void __launch_bounds__(F32_THREADS, 2)
 field_forward_f32_kernel(const float *__restrict__ packed, const float *__restrict__ frame, int level, long P, int S,
@@ -206,146 +255,171 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Ctx cx;
     cx.stream = packed + PACK_STREAM_OFF + (long)level * STREAM_FLOATS;
-    cx.table = reinterpret_cast<const uint32_t *>(packed + PACK_TABLE_OFF);
     cx.lds = lds;
-    cx.chunk = 0;
-    cx.buf = 0;
+    cx.buf = 1;                       // so that the first chunk lands in buffer 0
     cx.lane = threadIdx.x & 63;
     cx.q = cx.lane >> 4;
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    cx.off = 0;
     const float *grid = packed + PACK_GRID_OFF;
     const int q = cx.q;
 
     {   // per-level biases (static + folded conditioning) -> LDS, first weight chunk -> buffer 0
         const float *bsrc = frame + FRAME_BIAS_OFF + level * BIAS_FLOATS;
         for (int i = threadIdx.x; i < BIAS_FLOATS; i += F32_THREADS) lds[LDS_BIAS_OFF + i] = bsrc[i];
-        cx.issue(0, 0);
-        __syncthreads();
+        cx.begin_chunk(CHF(L_W0));
+#pragma unroll
+        for (int pc = 0; pc < (CHF(L_W0) + PIECE_FLOATS - 1) / PIECE_FLOATS; ++pc) cx.issue_piece(pc);
+        cx.end_chunk();
     }
     constexpr const Layer *Ly = kProg.layer;
 
     const long ntiles = (P + F32_PTS_PER_WG - 1) / F32_PTS_PER_WG;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        cx.refresh();
         const long p_raw = tile * F32_PTS_PER_WG + cx.wave * F32_PTS_PER_WAVE + (cx.lane & 15);
         const long p = p_raw < P ? p_raw : P - 1;
-        const long ray = p / S;
-        const float *rp = rays + ray * ray_stride;
-        const float z = zvals[p];
-        float rd[3] = {rp[3], rp[4], rp[5]};
-        float x[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) x[i] = rp[i] + rd[i] * z;          // train_utils.py:115
-
+        // x' (3) and w (2) are parked in LDS between their uses; the ray direction is re-read where needed: values that stay
+        // live across the 256-wide layers get spilled to scratch, and a scratch reload drains the LDS-DMA prefetch (vmcnt).
+        float *stash = lds + LDS_STASH_OFF + (cx.wave * F32_PTS_PER_WAVE + (cx.lane & 15)) * STASH_FLOATS;
+        const bool dump = dbg != nullptr && q == 0 && p_raw < P;   // lanes holding feature 0 of tile 0
+        float *dsl = dbg + p * DBG_STRIDE;
         f32x4 pe_x[4];
-        pe_blocks<3, 10, 4>(x, q, pe_x);
-
+        float x[3];
+        {
+            const float *rp = rays + (p / S) * ray_stride;
+            const float z = zvals[p];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) x[i] = rp[i] + rp[3 + i] * z;          // train_utils.py:115
+            pe_blocks<3, 10, 4>(x, q, pe_x);
+        }
         // ---- warp field: dx = tanh(MLP) (modules.py:371-390) ----
-        float xw[3];
         {
             f32x4 h[8], hn[8];
-            dense<4, 0, 8>(cx, pe_x, nullptr, h, Ly[L_W0].bias_off, false, 0.0f);
+            dense<4, 0, 8, CHF(L_W1)>(cx, pe_x, nullptr, h, Ly[L_W0].bias_off, false, 0.0f);
 #pragma unroll 1
-            for (int l = 0; l < 3; ++l) {
-                dense<8, 0, 8>(cx, h, nullptr, hn, Ly[L_W1].bias_off + 128 * l, false, 0.0f);
+            for (int l = 0; l < 3; ++l) {      // W1..W3 (the chunk after each is 32 KB: W2, W3, W4B)
+                dense<8, 0, 8, CHF(L_W2)>(cx, h, nullptr, hn, Ly[L_W1].bias_off + 128 * l, false, 0.0f);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) h[i] = hn[i];
             }
-            dense<4, 0, 8>(cx, pe_x, nullptr, hn, Ly[L_W4B].bias_off, false, 1.0f);
-            dense<8, 0, 8>(cx, h, nullptr, hn, 0, true, 0.0f);
-            dense<8, 0, 8>(cx, hn, nullptr, h, Ly[L_W5].bias_off, false, 0.0f);
+            dense<4, 0, 8, CHF(L_W4A)>(cx, pe_x, nullptr, hn, Ly[L_W4B].bias_off, false, 1.0f);
+            dense<8, 0, 8, CHF(L_W5)>(cx, h, nullptr, hn, 0, true, 0.0f);
+            dense<8, 0, 8, CHF(L_WF)>(cx, hn, nullptr, h, Ly[L_W5].bias_off, false, 0.0f);
             f32x4 o[1];
-            dense<8, 0, 1>(cx, h, nullptr, o, Ly[L_WF].bias_off, false, 1.0f);
+            dense<8, 0, 1, CHF(L_H0)>(cx, h, nullptr, o, Ly[L_WF].bias_off, false, 1.0f);
+            if (q == 0) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const float dx = tanhf(bcast16(o[0][i], cx.lane));
-                xw[i] = x[i] + dx;                                       // models.py:305
+                for (int i = 0; i < 3; ++i) stash[i] = x[i] + tanhf(o[0][i]);     // models.py:305 (rows 0..2 live in lane quarter 0)
             }
         }
         // ---- hyper sheet: ambient w (modules.py:444-462) ----
-        float amb[2];
         {
             f32x4 h[4], hn[4];
-            dense<4, 0, 4>(cx, pe_x, nullptr, h, Ly[L_H0].bias_off, false, 0.0f);
+            dense<4, 0, 4, CHF(L_H1)>(cx, pe_x, nullptr, h, Ly[L_H0].bias_off, false, 0.0f);
 #pragma unroll 1
-            for (int l = 0; l < 3; ++l) {
-                dense<4, 0, 4>(cx, h, nullptr, hn, Ly[L_H1].bias_off + 64 * l, false, 0.0f);
+            for (int l = 0; l < 3; ++l) {      // H1..H3 (next chunks: H2, H3, H4B, all 16 KB)
+                dense<4, 0, 4, CHF(L_H2)>(cx, h, nullptr, hn, Ly[L_H1].bias_off + 64 * l, false, 0.0f);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) h[i] = hn[i];
             }
-            dense<4, 0, 4>(cx, pe_x, nullptr, hn, Ly[L_H4B].bias_off, false, 1.0f);
-            dense<4, 0, 4>(cx, h, nullptr, hn, 0, true, 0.0f);
-            dense<4, 0, 4>(cx, hn, nullptr, h, Ly[L_H5].bias_off, false, 0.0f);
+            dense<4, 0, 4, CHF(L_H4A)>(cx, pe_x, nullptr, hn, Ly[L_H4B].bias_off, false, 1.0f);
+            dense<4, 0, 4, CHF(L_H5)>(cx, h, nullptr, hn, 0, true, 0.0f);
+            dense<4, 0, 4, CHF(L_HF)>(cx, hn, nullptr, h, Ly[L_H5].bias_off, false, 0.0f);
             f32x4 o[1];
-            dense<4, 0, 1>(cx, h, nullptr, o, Ly[L_HF].bias_off, false, 1.0f);
-            amb[0] = bcast16(o[0][0], cx.lane);
-            amb[1] = bcast16(o[0][1], cx.lane);
+            dense<4, 0, 1, CHF(L_T0)>(cx, h, nullptr, o, Ly[L_HF].bias_off, false, 1.0f);
+            if (q == 0) { stash[3] = o[0][0]; stash[4] = o[0][1]; }
         }
-        const bool dump = dbg != nullptr && q == 0 && p_raw < P;   // lanes holding feature 0 of tile 0
-        float *dsl = dbg + p * DBG_STRIDE;
-        if (dump) { dsl[0] = xw[0] - x[0]; dsl[1] = xw[1] - x[1]; dsl[2] = xw[2] - x[2]; dsl[3] = amb[0]; dsl[4] = amb[1]; }
+        __builtin_amdgcn_wave_barrier();
+        if (dump) { dsl[0] = stash[0] - x[0]; dsl[1] = stash[1] - x[1]; dsl[2] = stash[2] - x[2]; dsl[3] = stash[3]; dsl[4] = stash[4]; }
 
         // ---- radiance trunk (modules.py:254-275) ----
         f32x4 fin[1];      // FINAL tile: raw[4q..4q+3] of this lane's point
         f32x4 feat[16];
         {
-            f32x4 in_tr[6];
-            pe_blocks<3, 10, 4>(xw, q, in_tr);
-            pe_blocks<2, 4, 2>(amb, q, in_tr + 4);
             f32x4 h[16];
-            dense<4, 2, 16>(cx, in_tr, in_tr + 4, h, Ly[L_T0].bias_off, false, 0.01f);
-            if (dump) dsl[5] = h[0][0];
-            // T1, T2, [T3B], T3A, T4..T7, FEAT: eight 256x256 layers
-#pragma unroll 1
-            for (int l = 1; l <= 8; ++l) {
-                if (l == 3) dense<4, 2, 16>(cx, in_tr, in_tr + 4, feat, Ly[L_T3B].bias_off, false, 1.0f);
-                const int boff = (l < 3) ? Ly[L_T1].bias_off + 256 * (l - 1) : (l == 3 ? 0 : Ly[L_T4].bias_off + 256 * (l - 4));
-                dense<16, 0, 16>(cx, h, nullptr, feat, boff, l == 3, l == 8 ? 1.0f : 0.01f);
-                if (dump) dsl[5 + l] = feat[0][0];
-                if (l < 8) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) h[i] = feat[i];
-                }
+            {
+                f32x4 in_tr[6];
+                const float xw[3] = {stash[0], stash[1], stash[2]}, amb[2] = {stash[3], stash[4]};
+                pe_blocks<3, 10, 4>(xw, q, in_tr);
+                pe_blocks<2, 4, 2>(amb, q, in_tr + 4);
+                dense<4, 2, 16, CHF(L_T1)>(cx, in_tr, in_tr + 4, h, Ly[L_T0].bias_off, false, 0.01f);
             }
+            if (dump) dsl[5] = h[0][0];
+            dense<16, 0, 16, CHF(L_T2)>(cx, h, nullptr, feat, Ly[L_T1].bias_off, false, 0.01f);
+            if (dump) dsl[6] = feat[0][0];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h[i] = feat[i];
+            dense<16, 0, 16, CHF(L_T3B)>(cx, h, nullptr, feat, Ly[L_T2].bias_off, false, 0.01f);
+            if (dump) dsl[7] = feat[0][0];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h[i] = feat[i];
+            {   // skip layer: the re-injected encoding is rebuilt here instead of staying live (24 VGPRs) through T1, T2
+                f32x4 in_tr[6];
+                const float xw[3] = {stash[0], stash[1], stash[2]}, amb[2] = {stash[3], stash[4]};
+                pe_blocks<3, 10, 4>(xw, q, in_tr);
+                pe_blocks<2, 4, 2>(amb, q, in_tr + 4);
+                dense<4, 2, 16, CHF(L_T3A)>(cx, in_tr, in_tr + 4, feat, Ly[L_T3B].bias_off, false, 1.0f);
+            }
+            dense<16, 0, 16, CHF(L_T4)>(cx, h, nullptr, feat, 0, true, 0.01f);
+            if (dump) dsl[8] = feat[0][0];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h[i] = feat[i];
+#pragma unroll 1
+            for (int l = 4; l <= 7; ++l) {     // T4..T7 (next chunks: T5, T6, T7, FEAT, all 32 KB)
+                dense<16, 0, 16, CHF(L_T5)>(cx, h, nullptr, feat, Ly[L_T4].bias_off + 256 * (l - 4), false, 0.01f);
+                if (dump) dsl[5 + l] = feat[0][0];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) h[i] = feat[i];
+            }
+            dense<16, 0, 16, CHF(L_ALPHA)>(cx, h, nullptr, feat, Ly[L_FEAT].bias_off, false, 1.0f);
+            if (dump) dsl[13] = feat[0][0];
         }
-        dense<16, 0, 1>(cx, feat, nullptr, fin, Ly[L_ALPHA].bias_off, false, 1.0f);
+        dense<16, 0, 1, CHF(L_D0B)>(cx, feat, nullptr, fin, Ly[L_ALPHA].bias_off, false, 1.0f);
         if (dbg != nullptr && p_raw < P) *reinterpret_cast<f32x4 *>(dsl + 24 + 4 * q) = fin[0];
         // ---- colour branch (modules.py:276-287) ----
         {
             f32x4 in_d[4];
-            pe_blocks<3, 4, 2>(rd, q, in_d);                          // models.py:340 (raw, un-normalised direction)
-            grid_blocks(grid, xw[0], xw[1], xw[2], q, in_d + 2);      // models.py:525
+            {
+                const float *rp = rays + (p / S) * ray_stride;
+                const float rd[3] = {rp[3], rp[4], rp[5]};
+                pe_blocks<3, 4, 2>(rd, q, in_d);                                  // models.py:340 (raw, un-normalised direction)
+                grid_blocks(grid, stash[0], stash[1], stash[2], q, in_d + 2);     // models.py:525
+            }
             if (dbg != nullptr && p_raw < P) {
                 float *d = dbg + P * DBG_STRIDE + p * 32;
                 *reinterpret_cast<f32x4 *>(d + 4 * q) = in_d[2];
                 *reinterpret_cast<f32x4 *>(d + 16 + 4 * q) = in_d[3];
             }
             f32x4 c[8], cn[8];
-            dense<2, 2, 8>(cx, in_d, in_d + 2, c, Ly[L_D0B].bias_off, false, 1.0f);
-            dense<16, 0, 8>(cx, feat, nullptr, c, 0, true, 0.01f);
+            dense<2, 2, 8, CHF(L_D0A)>(cx, in_d, in_d + 2, c, Ly[L_D0B].bias_off, false, 1.0f);
+            dense<16, 0, 8, CHF(L_D1)>(cx, feat, nullptr, c, 0, true, 0.01f);
             if (dump) dsl[14] = c[0][0];
 #pragma unroll 1
-            for (int l = 0; l < 3; ++l) {
-                dense<8, 0, 8>(cx, c, nullptr, cn, Ly[L_D1].bias_off + 128 * l, false, 0.01f);
+            for (int l = 0; l < 2; ++l) {      // D1, D2
+                dense<8, 0, 8, CHF(L_D2)>(cx, c, nullptr, cn, Ly[L_D1].bias_off + 128 * l, false, 0.01f);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) c[i] = cn[i];
             }
-            if (dump) dsl[15] = c[0][0];
-            dense<8, 0, 1>(cx, c, nullptr, fin, 0, true, 1.0f);
+            dense<8, 0, 8, CHF(L_RGB)>(cx, c, nullptr, cn, Ly[L_D3].bias_off, false, 0.01f);
+            if (dump) dsl[15] = cn[0][0];
+            dense<8, 0, 1, CHF(L_S0)>(cx, cn, nullptr, fin, 0, true, 1.0f);
             if (dbg != nullptr && p_raw < P) *reinterpret_cast<f32x4 *>(dsl + 40 + 4 * q) = fin[0];
         }
         // ---- seg branch (modules.py:289-294) ----
         {
             f32x4 s[8], sn[8];
-            dense<16, 0, 8>(cx, feat, nullptr, s, Ly[L_S0].bias_off, false, 0.01f);
+            dense<16, 0, 8, CHF(L_S1)>(cx, feat, nullptr, s, Ly[L_S0].bias_off, false, 0.01f);
             if (dump) dsl[16] = s[0][0];
 #pragma unroll 1
-            for (int l = 0; l < 3; ++l) {
-                dense<8, 0, 8>(cx, s, nullptr, sn, Ly[L_S1].bias_off + 128 * l, false, 0.01f);
+            for (int l = 0; l < 2; ++l) {      // S1, S2
+                dense<8, 0, 8, CHF(L_S2)>(cx, s, nullptr, sn, Ly[L_S1].bias_off + 128 * l, false, 0.01f);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s[i] = sn[i];
             }
-            if (dump) dsl[17] = s[0][0];
-            dense<8, 0, 1>(cx, s, nullptr, fin, 0, true, 1.0f);
+            dense<8, 0, 8, CHF(L_SEG)>(cx, s, nullptr, sn, Ly[L_S3].bias_off, false, 0.01f);
+            if (dump) dsl[17] = sn[0][0];
+            dense<8, 0, 1, CHF(L_W0)>(cx, sn, nullptr, fin, 0, true, 1.0f);
         }
         if (p_raw < P) *reinterpret_cast<f32x4 *>(raw + p * D_RAW + 4 * q) = fin[0];   // cat((rgb, seg, alpha)) modules.py:295
     }
@@ -363,7 +437,7 @@ extern "C" int sahs_field_forward_f32_launch(const float *packed, const float *f
     if (P <= 0) return 0;
     const long ntiles = (P + F32_PTS_PER_WG - 1) / F32_PTS_PER_WG;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
-    const size_t lds_bytes = (size_t)LDS_FLOATS * sizeof(float);
+    const size_t lds_bytes = (size_t)LDS_TOTAL_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_f32_kernel),
