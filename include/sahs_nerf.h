@@ -94,6 +94,25 @@ int sahs_render_rays(const void *packed, const float *frame, int precision, long
                      float *disp_c, float *acc_c, float *rgb_f, float *disp_f, float *acc_f, float *w_bg, float *depth_f,
                      void *stream);
 
+/* ---- training path (BASELINE.json configs[4]: train_stage_rays_auto.py:437-499 calls loss.backward() through the path) ----
+ * Gradients follow autograd of the reference graph.  fp32 only.  The backward is layer-wise over saved activations:
+ * sahs_field_forward_save = sahs_field_forward that additionally writes sahs_act_words_per_sample() floats per sample. */
+long sahs_act_words_per_sample(void);
+long sahs_field_backward_workspace_words(long P);
+int sahs_field_forward_save(const void *packed, const float *frame, int level, long N, int S, const float *rays, int ray_stride,
+                            const float *z, float *raw, float *act_out, void *stream);
+/* d_raw (P,16) -> grad_flat (+=, canonical flat layout: every Linear weight/bias of warp/hyper/radiance nets and the feature
+ * grid) and grad_cond (+=: [0:76] d driving, [80:116] d pose encoding).  P = N*S samples, P <= 4e6 per call. */
+int sahs_field_backward(const float *flat_params, const float *frame, int level, long P, const float *act_in, const float *d_raw,
+                        float *grad_flat, float *grad_cond, float *workspace, void *stream);
+/* backward of sahs_composite_forward: any of d_rgb (N,15), d_disp, d_acc, d_depth, d_wlast (N) may be NULL -> d_raw (N,S,16). */
+int sahs_composite_backward(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
+                            const float *bg, int white_background, const float *d_rgb, const float *d_disp, const float *d_acc,
+                            const float *d_depth, const float *d_wlast, float *d_raw, void *stream);
+/* grad_cond[0:76] -> AudioNet parameter gradients in grad_flat (+=) and, optionally, grad_audio (16,29) (+=). */
+int sahs_conditioning_backward(const float *flat_params, const float *audio, const float *grad_cond, float *grad_flat,
+                               float *grad_audio, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

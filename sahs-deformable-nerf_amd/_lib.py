@@ -32,6 +32,12 @@ SIGNATURES = {
     "sahs_resample": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "sahs_sample_pdf": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, _P]),
     "sahs_render_rays": (_I, [_P, _P, _I, _L, _P, _I, _I, _I, _I, _I] + [_P] * 18),
+    "sahs_act_words_per_sample": (_L, []),
+    "sahs_field_backward_workspace_words": (_L, [_L]),
+    "sahs_field_forward_save": (_I, [_P, _P, _I, _L, _I, _P, _I, _P, _P, _P, _P]),
+    "sahs_field_backward": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
+    "sahs_composite_backward": (_I, [_L, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "sahs_conditioning_backward": (_I, [_P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -11,11 +11,19 @@ using namespace sahs;
 extern "C" {
 int sahs_pack_weights_f32_launch(const float *flat, float *packed, hipStream_t stream);
 int sahs_pack_weights_bf16_launch(const float *flat, float *packed, hipStream_t stream);
+long sahs_field_backward_ws_words(long P);
+int sahs_field_backward_launch(const float *flat, const float *frame, int level, long P, const float *actbuf, const float *d_raw,
+                               float *grad_flat, float *grad_cond, float *ws, hipStream_t stream);
+int sahs_composite_backward_launch(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
+                                   const float *bg, int white_bkgd, const float *d_rgb, const float *d_disp, const float *d_acc,
+                                   const float *d_depth, const float *d_wlast, float *d_raw, hipStream_t stream);
+int sahs_conditioning_backward_launch(const float *flat, const float *audio, const float *grad_cond, float *grad_flat, float *grad_audio,
+                                      hipStream_t stream);
 int sahs_field_forward_bf16_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                    const float *zvals, float *raw, float *dbg, int num_cu, hipStream_t stream);
 int sahs_fold_conditioning_launch(const float *flat, const float *audio, const float *pose, int pose_ld, float *frame, hipStream_t stream);
 int sahs_field_forward_f32_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
-                                  const float *zvals, float *raw, float *dbg, int num_cu, hipStream_t stream);
+                                  const float *zvals, float *raw, float *dbg, float *actbuf, int num_cu, hipStream_t stream);
 int sahs_ray_bundle_launch(int H, int W, float fx, float fy, float cx, float cy, const float *c2w, int ld, float *ro, float *rd,
                            hipStream_t stream);
 int sahs_stratified_depths_launch(long N, int S, const float *rays, int ray_stride, int lindisp, const float *t_rand, float *z,
@@ -105,7 +113,7 @@ int sahs_field_forward(const void *packed, const float *frame, int level, long N
     REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_field_forward(alignment)");
     if (precision != SAHS_F32 && precision != SAHS_BF16) return fail(2, "sahs_field_forward: unknown precision %s%ld", "", precision);
     int e = precision == SAHS_F32
-                ? sahs_field_forward_f32_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(),
+                ? sahs_field_forward_f32_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, nullptr, num_cus(),
                                                 (hipStream_t)stream)
                 : sahs_field_forward_bf16_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(),
                                                  (hipStream_t)stream);
@@ -139,6 +147,48 @@ int sahs_sample_pdf(long N, int nb, int ns, const float *bins, const float *weig
     REQUIRE(N >= 0 && nb >= 2 && nb < 256 && ns >= 1 && ns <= 256, "sahs_sample_pdf(shape: 2 <= nb < 256, 1 <= ns <= 256)");
     int e = sahs_resample_launch(N, nb + 1, ns, 0, bins, weights, u, samples, nullptr, (long long *)inds, (hipStream_t)stream);
     return e ? hip_fail("sahs_sample_pdf", e) : 0;
+}
+
+long sahs_act_words_per_sample(void) { return act::STRIDE; }
+long sahs_field_backward_workspace_words(long P) { return sahs_field_backward_ws_words(P); }
+
+int sahs_field_forward_save(const void *packed, const float *frame, int level, long N, int S, const float *rays, int ray_stride,
+                            const float *z, float *raw, float *act_out, void *stream)
+{
+    REQUIRE(packed && frame && rays && z && raw && act_out, "sahs_field_forward_save");
+    REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_field_forward_save(shape)");
+    REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && ALIGNED16(act_out), "sahs_field_forward_save(alignment)");
+    int e = sahs_field_forward_f32_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, nullptr, act_out, num_cus(),
+                                          (hipStream_t)stream);
+    return e ? hip_fail("sahs_field_forward_save", e) : 0;
+}
+
+int sahs_field_backward(const float *flat_params, const float *frame, int level, long P, const float *act_in, const float *d_raw,
+                        float *grad_flat, float *grad_cond, float *workspace, void *stream)
+{
+    REQUIRE(flat_params && frame && act_in && d_raw && grad_flat && grad_cond && workspace, "sahs_field_backward");
+    REQUIRE((level == 0 || level == 1) && P >= 0 && P <= 4000000L, "sahs_field_backward(0 <= P <= 4e6 samples per call)");
+    int e = sahs_field_backward_launch(flat_params, frame, level, P, act_in, d_raw, grad_flat, grad_cond, workspace, (hipStream_t)stream);
+    return e ? hip_fail("sahs_field_backward", e) : 0;
+}
+
+int sahs_composite_backward(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
+                            const float *bg, int white_background, const float *d_rgb, const float *d_disp, const float *d_acc,
+                            const float *d_depth, const float *d_wlast, float *d_raw, void *stream)
+{
+    REQUIRE(raw && z && rays && d_raw && ray_stride >= 6 && ALIGNED16(raw) && ALIGNED16(d_raw), "sahs_composite_backward");
+    REQUIRE(N >= 0 && S >= 1 && S <= 256, "sahs_composite_backward(shape: 1 <= S <= 256)");
+    int e = sahs_composite_backward_launch(N, S, raw, z, rays, ray_stride, noise, bg, white_background, d_rgb, d_disp, d_acc, d_depth, d_wlast,
+                                           d_raw, (hipStream_t)stream);
+    return e ? hip_fail("sahs_composite_backward", e) : 0;
+}
+
+int sahs_conditioning_backward(const float *flat_params, const float *audio, const float *grad_cond, float *grad_flat, float *grad_audio,
+                               void *stream)
+{
+    REQUIRE(flat_params && audio && grad_cond && grad_flat, "sahs_conditioning_backward");
+    int e = sahs_conditioning_backward_launch(flat_params, audio, grad_cond, grad_flat, grad_audio, (hipStream_t)stream);
+    return e ? hip_fail("sahs_conditioning_backward", e) : 0;
 }
 
 int sahs_render_rays(const void *packed, const float *frame, int precision, long N, const float *rays, int ray_stride, int Sc, int nf,

@@ -1,0 +1,454 @@
+// field_bwd.hip -- gradients of the per-sample field (BASELINE.json configs[4]: training step through the HIP ops).
+//
+// Layer-wise backward over the activations saved by field_forward_f32_kernel<SAVE> (sahs::act layout):
+// for every dense layer   dW += dY^T X,   db += colsum(dY),   dX = (dY W) * act'(X)
+// run as fp32 MFMA GEMMs over all samples of the call, plus small kernels for the positional-encoding, tanh and
+// trilinear-grid derivatives.  This first version is NOT fused (activations and per-layer gradients go through
+// HBM: 19 KB + ~3.6 KB per sample); it exists to make the training path exact and native, the fused
+// recompute-in-backward kernel is the follow-up.  Conventions follow autograd of the reference graph
+// (models.py:514-528, modules.py:371-390 / 444-462 / 254-295): the per-frame constant inputs (driving, pose
+// encoding) get their weight-column gradients from the bias gradient (their value is the same for every sample:
+// dW[:, const] = db (x) c) and their own gradient from W[:, const]^T db.
+#include <hip/hip_runtime.h>
+#include "sahs_common.hpp"
+#include "sahs_layout.hpp"
+
+namespace sahs {
+
+// ------------------------------------------------------------------------------------------------
+// C[M x N] (op)= A'[M x K] B[K x N], fp32, v_mfma_f32_16x16x4_f32.  TA: A'(m,k) = A[k*lda + m], else A[m*lda + k];
+// B(k,n) = B[k*ldb + n].  64x64 tile per 256-thread workgroup, K in steps of 16 through LDS; blockIdx.z splits K.
+// mode 0: C = acc; 1: C += acc; 2: atomicAdd(C, acc).  mask != null: acc *= (mask[m*ldm + n] > 0 ? 1 : slope).
+// ------------------------------------------------------------------------------------------------
+constexpr int GT = 64, GK = 16, GLD = 80;   // LDS row stride 80 floats: the two 16-lane groups of a ds_read_b32 half hit disjoint banks
+
+template <bool TA>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(int M, int N, int K, const float *__restrict__ A, long lda,
+                                                       const float *__restrict__ B, long ldb, float *__restrict__ C, long ldc, int mode,
+                                                       const float *__restrict__ mask, long ldm, float slope, int kslab)
+{
+    __shared__ float As[GK][GLD], Bs[GK][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c16 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long m0 = (long)blockIdx.y * GT;
+    const int n0 = blockIdx.x * GT;
+    const long k_lo = (long)blockIdx.z * kslab;
+    const long k_hi = (k_lo + kslab < K) ? k_lo + kslab : K;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (long k0 = k_lo; k0 < k_hi; k0 += GK) {
+        // stage A' tile: As[k][m]
+#pragma unroll
+        for (int e = tid; e < GT * GK; e += 256) {
+            int kk, mm;
+            if (TA) { kk = e / GT; mm = e % GT; } else { mm = e / GK; kk = e % GK; }   // contiguous index fastest in global memory
+            const long m = m0 + mm, k = k0 + kk;
+            float v = 0.0f;
+            if (m < M && k < k_hi) v = TA ? A[k * lda + m] : A[m * lda + k];
+            As[kk][mm] = v;
+        }
+#pragma unroll
+        for (int e = tid; e < GT * GK; e += 256) {
+            const int kk = e / GT, nn = e % GT;
+            const long k = k0 + kk;
+            const int n = n0 + nn;
+            Bs[kk][nn] = (k < k_hi && n < N) ? B[k * ldb + n] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < GK / 4; ++s) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[4 * s + q][32 * wm + 16 * i + c16];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[4 * s + q][32 * wn + 16 * j + c16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long m = m0 + 32 * wm + 16 * i + 4 * q + r;
+                const int n = n0 + 32 * wn + 16 * j + c16;
+                if (m < M && n < N) {
+                    float v = acc[i][j][r];
+                    if (mask != nullptr) v *= (mask[m * ldm + n] > 0.0f) ? 1.0f : slope;
+                    float *dst = C + m * ldc + n;
+                    if (mode == 0) *dst = v;
+                    else if (mode == 1) *dst += v;
+                    else atomicAdd(dst, v);
+                }
+            }
+}
+
+// db[n] += sum_m Y[m*ld + n]
+__global__ void __launch_bounds__(256) colsum_kernel(long M, int N, const float *__restrict__ Y, long ld, float *__restrict__ out, int rows_per_block)
+{
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
+    const long m_lo = (long)blockIdx.y * rows_per_block, m_hi = (m_lo + rows_per_block < M) ? m_lo + rows_per_block : M;
+    float s = 0.0f;
+    if (n < N)
+        for (long m = m_lo + sub; m < m_hi; m += 4) s += Y[m * ld + n];
+    __shared__ float red[4][64];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// dst[m*ldd + n] (op)= src[m*lds + n] for n < N   (mode 0 copy, 1 add)
+__global__ void copy2d_kernel(long M, int N, const float *__restrict__ src, long lds_, float *__restrict__ dst, long ldd, int mode)
+{
+    const long total = M * N;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long m = e / N; const int n = (int)(e % N);
+        const float v = src[m * lds_ + n];
+        if (mode) dst[m * ldd + n] += v; else dst[m * ldd + n] = v;
+    }
+}
+
+// d_feat[m][:] += d_sigma[m] * w_alpha[:]   (rank-1: fc_alpha has one output row)
+__global__ void rank1_add_kernel(long M, int N, const float *__restrict__ dcol, long ldc, const float *__restrict__ w, float *__restrict__ dst, long ldd)
+{
+    const long total = M * N;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long m = e / N; const int n = (int)(e % N);
+        dst[m * ldd + n] += dcol[m * ldc] * w[n];
+    }
+}
+
+// ---- positional-encoding backward: d(enc)/d(coord) from the saved sin/cos rows -----------------------------
+// enc = [v | sin(2^k v) | cos(2^k v)]_k (nerf_helpers.py:322-349): d sin = 2^k cos, d cos = -2^k sin.
+template <int D, int L>
+__device__ __forceinline__ void pe_grad(const float *enc, const float *denc, float *dv)
+{
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+        float g = denc[a];
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            const int si = D + 2 * D * k + a, ci = si + D;
+            g += (float)(1 << k) * (denc[si] * enc[ci] - denc[ci] * enc[si]);
+        }
+        dv[a] = g;
+    }
+}
+
+// Per sample: d_in [P x 96] = gradient wrt [PE63(x') pad 64 | PE18(w) pad 32]; d_gridf [P x 32].
+// Outputs: d_xw [P x 4] = dL/dx' (PE part + trilinear part), d_w [P x 4] = dL/dw; scatter-adds d_grid (channel-first, as in
+// the flat parameter buffer).  Trilinear derivative as ATen's grid_sampler_3d backward (align_corners=True, zeros padding).
+__global__ void __launch_bounds__(256) encode_grid_backward_kernel(long P, const float *__restrict__ actbuf, const float *__restrict__ d_in,
+                                                                   const float *__restrict__ d_gridf, const float *__restrict__ grid_cf,
+                                                                   float *__restrict__ d_grid_cf, float *__restrict__ d_xw,
+                                                                   float *__restrict__ d_w)
+{
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+        const float *a = actbuf + p * (long)act::STRIDE;
+        float gx[3], gw[2];
+        pe_grad<3, 10>(a + act::PEX, d_in + p * 96, gx);
+        pe_grad<2, 4>(a + act::PEW, d_in + p * 96 + 64, gw);
+        // trilinear
+        const float x = a[act::XW], y = a[act::XW + 1], z = a[act::XW + 2];
+        const float R1 = (float)(G_RES - 1);
+        const float ix = ((x + 1.0f) / 2.0f) * R1, iy = ((y + 1.0f) / 2.0f) * R1, iz = ((z + 1.0f) / 2.0f) * R1;
+        const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+        const float wx[2] = {(fx + 1.0f) - ix, ix - fx}, wy[2] = {(fy + 1.0f) - iy, iy - fy}, wz[2] = {(fz + 1.0f) - iz, iz - fz};
+        const bool ok = fx >= -1.0f && fx <= (float)G_RES && fy >= -1.0f && fy <= (float)G_RES && fz >= -1.0f && fz <= (float)G_RES;
+        const int xi = ok ? (int)fx : -2, yi = ok ? (int)fy : -2, zi = ok ? (int)fz : -2;
+        const long vox = (long)G_RES * G_RES * G_RES;
+        float gix = 0.0f, giy = 0.0f, giz = 0.0f;
+        const float *dg = d_gridf + p * 32;
+        for (int n = 0; n < 8; ++n) {
+            const int bx = n & 1, by = (n >> 1) & 1, bz = n >> 2;
+            const int cx = xi + bx, cy = yi + by, cz = zi + bz;
+            if (cx < 0 || cx >= G_RES || cy < 0 || cy >= G_RES || cz < 0 || cz >= G_RES) continue;
+            const long v = ((long)cz * G_RES + cy) * G_RES + cx;
+            const float wt = (wx[bx] * wy[by]) * wz[bz];
+            float dot = 0.0f;
+            for (int c = 0; c < D_GRID; ++c) {
+                const float g = dg[c];
+                atomicAdd(d_grid_cf + (long)c * vox + v, g * wt);
+                dot += g * grid_cf[(long)c * vox + v];
+            }
+            gix += dot * (bx ? 1.0f : -1.0f) * wy[by] * wz[bz];
+            giy += dot * (by ? 1.0f : -1.0f) * wx[bx] * wz[bz];
+            giz += dot * (bz ? 1.0f : -1.0f) * wx[bx] * wy[by];
+        }
+        const float sc = R1 / 2.0f;
+        d_xw[p * 4 + 0] = gx[0] + gix * sc;
+        d_xw[p * 4 + 1] = gx[1] + giy * sc;
+        d_xw[p * 4 + 2] = gx[2] + giz * sc;
+        d_xw[p * 4 + 3] = 0.0f;
+        d_w[p * 4 + 0] = gw[0]; d_w[p * 4 + 1] = gw[1]; d_w[p * 4 + 2] = 0.0f; d_w[p * 4 + 3] = 0.0f;
+    }
+}
+
+// g3[p][i] = d_xw[p][i] * (1 - dx_i^2)   (x' = x + tanh(.), models.py:304-305)
+__global__ void tanh_backward_kernel(long P, const float *__restrict__ actbuf, const float *__restrict__ d_xw, float *__restrict__ g3)
+{
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float dx = actbuf[p * (long)act::STRIDE + act::DX + i];
+            g3[p * 4 + i] = d_xw[p * 4 + i] * (1.0f - dx * dx);
+        }
+        g3[p * 4 + 3] = 0.0f;
+    }
+}
+
+// per-frame constants: dW[r][col0 + k] += db[r] * c[k];  dc[k] += sum_r W[r][col0 + k] * db[r]
+__global__ void __launch_bounds__(256) const_cols_backward_kernel(int rows, int cols, const float *__restrict__ W, float *__restrict__ dW, long ld,
+                                                                  int col0, const float *__restrict__ db, const float *__restrict__ c,
+                                                                  float *__restrict__ dc)
+{
+    for (int k = threadIdx.x; k < cols; k += blockDim.x) {
+        float s = 0.0f;
+        const float ck = c[k];
+        for (int r = 0; r < rows; ++r) {
+            const float g = db[r];
+            s += W[(long)r * ld + col0 + k] * g;
+            dW[(long)r * ld + col0 + k] += g * ck;
+        }
+        dc[k] += s;
+    }
+}
+
+__global__ void axpy_kernel(int n, const float *__restrict__ x, float *__restrict__ y)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[i] += x[i];
+}
+
+}  // namespace sahs
+
+using namespace sahs;
+
+namespace {
+
+struct Bwd {
+    hipStream_t st;
+    long P;
+    int err = 0;
+    void check() { if (!err) err = (int)hipGetLastError(); }
+    // dX[P x N] (mode) = dY[P x K] * W[K x N] (* mask)
+    void nn(const float *dY, long ldy, int K, const float *W, long ldw, int N, float *dX, long ldx, int mode, const float *mask = nullptr,
+            long ldm = 0, float slope = 0.0f)
+    {
+        dim3 g((N + GT - 1) / GT, (unsigned)((P + GT - 1) / GT), 1);
+        gemm_f32_kernel<false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K);
+        check();
+    }
+    // dW[M x N] += dY[P x M]^T * X[P x N]
+    void tn(const float *dY, long ldy, int M, const float *X, long ldx, int N, float *dW, long ldw)
+    {
+        const int kslab = 4096;
+        dim3 g((N + GT - 1) / GT, (M + GT - 1) / GT, (unsigned)((P + kslab - 1) / kslab));
+        gemm_f32_kernel<true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, kslab);
+        check();
+    }
+    void colsum(const float *dY, long ldy, int N, float *db)
+    {
+        const int rows = 2048;
+        dim3 g((N + 63) / 64, (unsigned)((P + rows - 1) / rows));
+        colsum_kernel<<<g, 256, 0, st>>>(P, N, dY, ldy, db, rows);
+        check();
+    }
+    void copy(const float *src, long lds_, int N, float *dst, long ldd, int mode)
+    {
+        copy2d_kernel<<<2048, 256, 0, st>>>(P, N, src, lds_, dst, ldd, mode);
+        check();
+    }
+};
+
+}  // namespace
+
+// Words of workspace per call: gA, gB, dfeat (P x 256 each), din (P x 96), dgridf (P x 32), dxw, dw, g3 (P x 4 each), db (BIAS_FLOATS)
+constexpr int DB_SCRATCH = 8192;   // per-call bias-gradient scratch (all layers of one level: ~5.3 K floats)
+extern "C" long sahs_field_backward_ws_words(long P) { return P * (256L * 3 + 96 + 32 + 12) + DB_SCRATCH; }
+
+// grad_cond: [0:76] d_driving, [80:116] d_pose36 (accumulated).  grad_flat: accumulated.  d_raw: (P,16).
+extern "C" int sahs_field_backward_launch(const float *flat, const float *frame, int level, long P, const float *actbuf, const float *d_raw,
+                                          float *grad_flat, float *grad_cond, float *ws, hipStream_t stream)
+{
+    if (P <= 0) return 0;
+    if (P > 4000000L) return -3;   // gridDim.y of the P x N GEMMs; callers chunk larger batches
+    Bwd b{stream, P};
+    const FlatOffsets &F = kFlat;
+    const FlatOffsets::Lvl &Lv = F.lvl[level];
+    float *gA = ws, *gB = gA + P * 256, *dfeat = gB + P * 256, *din = dfeat + P * 256, *dgridf = din + P * 96, *dxw = dgridf + P * 32,
+          *dw = dxw + P * 4, *g3 = dw + P * 4, *db = g3 + P * 4;
+    const long AS = act::STRIDE;
+    hipMemsetAsync(db, 0, sizeof(float) * DB_SCRATCH, stream);
+    hipMemsetAsync(din, 0, sizeof(float) * P * 96, stream);
+    const float *drv = frame + FRAME_DRV_OFF, *p36 = frame + FRAME_POSE_OFF;
+    float *d_drv = grad_cond + 0, *d_p36 = grad_cond + 80;
+    auto W = [&](long off) { return flat + off; };
+    auto G = [&](long off) { return grad_flat + off; };
+    int dbo = 0;   // running offset into db scratch
+    auto newdb = [&](int n) { float *p = db + dbo; dbo += (n + 3) / 4 * 4; return p; };
+    auto add_bias = [&](float *dbl, long boff, int n) { axpy_kernel<<<1, 256, 0, stream>>>(n, dbl, G(boff)); b.check(); };
+    auto consts = [&](long woff, long ld, int rows, int col0, int cols, const float *dbl, const float *c, float *dc) {
+        const_cols_backward_kernel<<<1, 256, 0, stream>>>(rows, cols, W(woff), G(woff), ld, col0, dbl, c, dc);
+        b.check();
+    };
+    // generic plain layer: given dY (pre-activation grads of this layer, P x out) and its input X (P x in, stride ldx):
+    //   dW += dY^T X, db += colsum, and (if dX) dX = dY W * mask(prevact)
+    auto layer_params = [&](const float *dY, long ldy, int out, long woff, long boff, long ldw, int col0, const float *X, long ldx, int in,
+                            float *dbl) {
+        b.tn(dY, ldy, out, X, ldx, in, G(woff) + col0, ldw);
+        (void)boff; (void)dbl;
+    };
+
+    // ================= seg branch: seg = fc_seg(s3), s_i = lrelu(layers_seg[i](.)) (modules.py:289-294) =================
+    const float *A = actbuf;
+    {
+        const float *dseg = d_raw + 3;   // (P,12), ld 16
+        float *dbl = newdb(N_SEG);
+        b.tn(dseg, 16, N_SEG, A + act::S + 384, AS, BR_H, G(Lv.segout_w), BR_H);
+        b.colsum(dseg, 16, N_SEG, dbl); add_bias(dbl, Lv.segout_b, N_SEG);
+        b.nn(dseg, 16, N_SEG, W(Lv.segout_w), BR_H, BR_H, gA, 256, 0, A + act::S + 384, AS, 0.01f);
+        float *cur = gA, *nxt = gB;
+        for (int i = 3; i >= 1; --i) {   // layers_seg[i]: s_{i-1} (128) -> s_i
+            float *d = newdb(BR_H);
+            b.tn(cur, 256, BR_H, A + act::S + 128 * (i - 1), AS, BR_H, G(Lv.seg_w[i]), BR_H);
+            b.colsum(cur, 256, BR_H, d); add_bias(d, Lv.seg_b[i], BR_H);
+            b.nn(cur, 256, BR_H, W(Lv.seg_w[i]), BR_H, BR_H, nxt, 256, 0, A + act::S + 128 * (i - 1), AS, 0.01f);
+            float *t = cur; cur = nxt; nxt = t;
+        }
+        float *d = newdb(BR_H);   // layers_seg[0]: feat (256) -> s0
+        b.tn(cur, 256, BR_H, A + act::FEAT, AS, TR_H, G(Lv.seg_w[0]), TR_H);
+        b.colsum(cur, 256, BR_H, d); add_bias(d, Lv.seg_b[0], BR_H);
+        b.nn(cur, 256, BR_H, W(Lv.seg_w[0]), TR_H, TR_H, dfeat, 256, 0);       // feat has no activation
+    }
+    // ================= colour branch (modules.py:276-287) =================
+    {
+        const float *drgb = d_raw;   // (P,3), ld 16
+        float *dbl = newdb(4);
+        b.tn(drgb, 16, 3, A + act::C + 384, AS, BR_H, G(Lv.rgb_w), BR_H);
+        b.colsum(drgb, 16, 3, dbl); add_bias(dbl, Lv.rgb_b, 3);
+        b.nn(drgb, 16, 3, W(Lv.rgb_w), BR_H, BR_H, gA, 256, 0, A + act::C + 384, AS, 0.01f);
+        float *cur = gA, *nxt = gB;
+        for (int i = 3; i >= 1; --i) {
+            float *d = newdb(BR_H);
+            b.tn(cur, 256, BR_H, A + act::C + 128 * (i - 1), AS, BR_H, G(Lv.dir_w[i]), BR_H);
+            b.colsum(cur, 256, BR_H, d); add_bias(d, Lv.dir_b[i], BR_H);
+            b.nn(cur, 256, BR_H, W(Lv.dir_w[i]), BR_H, BR_H, nxt, 256, 0, A + act::C + 128 * (i - 1), AS, 0.01f);
+            float *t = cur; cur = nxt; nxt = t;
+        }
+        // layers_dir[0]: [feat256 | dirPE27 | grid32] -> c0
+        float *d = newdb(BR_H);
+        b.tn(cur, 256, BR_H, A + act::FEAT, AS, TR_H, G(Lv.dir_w[0]), D_DIR_IN);
+        b.tn(cur, 256, BR_H, A + act::DIR, AS, D_DIR, G(Lv.dir_w[0]) + TR_H, D_DIR_IN);
+        b.tn(cur, 256, BR_H, A + act::GRID, AS, D_GRID, G(Lv.dir_w[0]) + TR_H + D_DIR, D_DIR_IN);
+        b.colsum(cur, 256, BR_H, d); add_bias(d, Lv.dir_b[0], BR_H);
+        b.nn(cur, 256, BR_H, W(Lv.dir_w[0]), D_DIR_IN, TR_H, dfeat, 256, 1);
+        b.nn(cur, 256, BR_H, W(Lv.dir_w[0]) + TR_H + D_DIR, D_DIR_IN, D_GRID, dgridf, 32, 0);
+    }
+    // ================= sigma = fc_alpha(feat) (modules.py:275) =================
+    {
+        const float *dsig = d_raw + 15;  // (P,1), ld 16
+        float *dbl = newdb(4);
+        b.tn(dsig, 16, 1, A + act::FEAT, AS, TR_H, G(Lv.alpha_w), TR_H);
+        b.colsum(dsig, 16, 1, dbl); add_bias(dbl, Lv.alpha_b, 1);
+        rank1_add_kernel<<<2048, 256, 0, stream>>>(P, TR_H, dsig, 16, W(Lv.alpha_w), dfeat, 256); b.check();
+    }
+    // ================= trunk (modules.py:267-274) =================
+    {
+        // feat = fc_feat(t7)
+        float *d = newdb(TR_H);
+        b.tn(dfeat, 256, TR_H, A + act::T + 7 * 256, AS, TR_H, G(Lv.feat_w), TR_H);
+        b.colsum(dfeat, 256, TR_H, d); add_bias(d, Lv.feat_b, TR_H);
+        b.nn(dfeat, 256, TR_H, W(Lv.feat_w), TR_H, TR_H, gA, 256, 0, A + act::T + 7 * 256, AS, 0.01f);
+        float *cur = gA, *nxt = gB;
+        for (int i = 7; i >= 1; --i) {   // layers_xyz[i]: input t_{i-1} (and, for i == 3, [PE(x') | PE(w) | pose36])
+            float *dl = newdb(TR_H);
+            const long ldw = (i == 3) ? TR_H + D_TR_IN : TR_H;
+            b.tn(cur, 256, TR_H, A + act::T + (i - 1) * 256, AS, TR_H, G(Lv.xyz_w[i]), ldw);
+            b.colsum(cur, 256, TR_H, dl); add_bias(dl, Lv.xyz_b[i], TR_H);
+            if (i == 3) {
+                b.tn(cur, 256, TR_H, A + act::PEX, AS, D_XYZ, G(Lv.xyz_w[3]) + TR_H, ldw);
+                b.tn(cur, 256, TR_H, A + act::PEW, AS, D_AMB, G(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw);
+                consts(Lv.xyz_w[3], ldw, TR_H, TR_H + D_XYZ + D_AMB, D_POSE, dl, p36, d_p36);
+                b.nn(cur, 256, TR_H, W(Lv.xyz_w[3]) + TR_H, ldw, D_XYZ, din, 96, 1);
+                b.nn(cur, 256, TR_H, W(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw, D_AMB, din + 64, 96, 1);
+            }
+            b.nn(cur, 256, TR_H, W(Lv.xyz_w[i]), ldw, TR_H, nxt, 256, 0, A + act::T + (i - 1) * 256, AS, 0.01f);
+            float *t = cur; cur = nxt; nxt = t;
+        }
+        // layers_xyz[0]: [PE63(x') | PE18(w) | pose36] -> t0
+        float *dl = newdb(TR_H);
+        b.tn(cur, 256, TR_H, A + act::PEX, AS, D_XYZ, G(Lv.xyz_w[0]), D_TR_IN);
+        b.tn(cur, 256, TR_H, A + act::PEW, AS, D_AMB, G(Lv.xyz_w[0]) + D_XYZ, D_TR_IN);
+        b.colsum(cur, 256, TR_H, dl); add_bias(dl, Lv.xyz_b[0], TR_H);
+        consts(Lv.xyz_w[0], D_TR_IN, TR_H, D_XYZ + D_AMB, D_POSE, dl, p36, d_p36);
+        b.nn(cur, 256, TR_H, W(Lv.xyz_w[0]), D_TR_IN, D_XYZ, din, 96, 1);
+        b.nn(cur, 256, TR_H, W(Lv.xyz_w[0]) + D_XYZ, D_TR_IN, D_AMB, din + 64, 96, 1);
+    }
+    // ================= encodings + feature grid -> d x', d w =================
+    encode_grid_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, din, dgridf, W(F.grid), G(F.grid), dxw, dw);
+    b.check();
+    // ================= hyper sheet (modules.py:444-462): w = fc_ambient(g5) =================
+    {
+        float *dbl = newdb(4);
+        b.tn(dw, 4, 2, A + act::HH + 5 * 64, AS, HYP_H, G(F.hyp_fw), HYP_H);
+        b.colsum(dw, 4, 2, dbl); add_bias(dbl, F.hyp_fb, 2);
+        b.nn(dw, 4, 2, W(F.hyp_fw), HYP_H, HYP_H, gA, 256, 0, A + act::HH + 5 * 64, AS, 0.0f);
+        float *cur = gA, *nxt = gB;
+        for (int i = 5; i >= 1; --i) {
+            float *dl = newdb(HYP_H);
+            const long ldw = (i == 4) ? HYP_H + D_DEF_IN : HYP_H;
+            b.tn(cur, 256, HYP_H, A + act::HH + (i - 1) * 64, AS, HYP_H, G(F.hyp_w[i]), ldw);
+            b.colsum(cur, 256, HYP_H, dl); add_bias(dl, F.hyp_b[i], HYP_H);
+            if (i == 4) {
+                b.tn(cur, 256, HYP_H, A + act::E, AS, D_XYZ, G(F.hyp_w[4]) + HYP_H, ldw);
+                consts(F.hyp_w[4], ldw, HYP_H, HYP_H + D_XYZ, D_DRV, dl, drv, d_drv);
+                consts(F.hyp_w[4], ldw, HYP_H, HYP_H + D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);
+            }
+            b.nn(cur, 256, HYP_H, W(F.hyp_w[i]), ldw, HYP_H, nxt, 256, 0, A + act::HH + (i - 1) * 64, AS, 0.0f);
+            float *t = cur; cur = nxt; nxt = t;
+        }
+        float *dl = newdb(HYP_H);
+        b.tn(cur, 256, HYP_H, A + act::E, AS, D_XYZ, G(F.hyp_w[0]), D_DEF_IN);
+        b.colsum(cur, 256, HYP_H, dl); add_bias(dl, F.hyp_b[0], HYP_H);
+        consts(F.hyp_w[0], D_DEF_IN, HYP_H, D_XYZ, D_DRV, dl, drv, d_drv);
+        consts(F.hyp_w[0], D_DEF_IN, HYP_H, D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);
+    }
+    // ================= warp field (modules.py:371-390): x' = x + tanh(fc_final(h5)) =================
+    {
+        tanh_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, dxw, g3); b.check();
+        float *dbl = newdb(4);
+        b.tn(g3, 4, 3, A + act::WH + 5 * 128, AS, WARP_H, G(F.warp_fw), WARP_H);
+        b.colsum(g3, 4, 3, dbl); add_bias(dbl, F.warp_fb, 3);
+        b.nn(g3, 4, 3, W(F.warp_fw), WARP_H, WARP_H, gA, 256, 0, A + act::WH + 5 * 128, AS, 0.0f);
+        float *cur = gA, *nxt = gB;
+        for (int i = 5; i >= 1; --i) {
+            float *dl = newdb(WARP_H);
+            const long ldw = (i == 4) ? WARP_H + D_DEF_IN : WARP_H;
+            b.tn(cur, 256, WARP_H, A + act::WH + (i - 1) * 128, AS, WARP_H, G(F.warp_w[i]), ldw);
+            b.colsum(cur, 256, WARP_H, dl); add_bias(dl, F.warp_b[i], WARP_H);
+            if (i == 4) {
+                b.tn(cur, 256, WARP_H, A + act::E, AS, D_XYZ, G(F.warp_w[4]) + WARP_H, ldw);
+                consts(F.warp_w[4], ldw, WARP_H, WARP_H + D_XYZ, D_DRV, dl, drv, d_drv);
+                consts(F.warp_w[4], ldw, WARP_H, WARP_H + D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);
+            }
+            b.nn(cur, 256, WARP_H, W(F.warp_w[i]), ldw, WARP_H, nxt, 256, 0, A + act::WH + (i - 1) * 128, AS, 0.0f);
+            float *t = cur; cur = nxt; nxt = t;
+        }
+        float *dl = newdb(WARP_H);
+        b.tn(cur, 256, WARP_H, A + act::E, AS, D_XYZ, G(F.warp_w[0]), D_DEF_IN);
+        b.colsum(cur, 256, WARP_H, dl); add_bias(dl, F.warp_b[0], WARP_H);
+        consts(F.warp_w[0], D_DEF_IN, WARP_H, D_XYZ, D_DRV, dl, drv, d_drv);
+        consts(F.warp_w[0], D_DEF_IN, WARP_H, D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);
+    }
+    (void)layer_params;
+    return b.err;
+}

@@ -106,7 +106,8 @@ __device__ __forceinline__ f32x4 act4(f32x4 v, float slope)   // slope in [0,1]:
 // A chunk is a flat run of G*KB steps; step = one A fragment (ds_read_b128) feeding 4 MFMAs.  Tiles are taken in pairs so
 // two independent accumulation chains alternate (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
 template <int KB0, int KB1, int NT, int NEXT>
-__device__ __forceinline__ void dense(Ctx &cx, const f32x4 *in0, const f32x4 *in1, f32x4 *out, int bias_off, bool accum, float slope)
+__device__ __forceinline__ void dense(Ctx &cx, const f32x4 *in0, const f32x4 *in1, f32x4 *out, int bias_off, bool accum, float slope,
+                                      float *save = nullptr)   // save: this lane's slot of the layer's saved-activation block, or null
 {
     constexpr int KB = KB0 + KB1;
     constexpr int G = pick_G(KB, NT);
@@ -142,6 +143,7 @@ __device__ __forceinline__ void dense(Ctx &cx, const f32x4 *in0, const f32x4 *in
                 f32x4 o = act4(acc[m], slope);
                 asm volatile("" : "+v"(o));     // pin: keep the finished tile from being sunk into the next layer
                 out[t] = o;
+                if (save != nullptr) *reinterpret_cast<f32x4 *>(save + 16 * t) = o;
             }
         }
 #pragma unroll
@@ -247,10 +249,12 @@ __device__ __forceinline__ void grid_blocks(const float *__restrict__ grid, floa
 
 #define CHF(id) (kProg.layer[id].G * kProg.layer[id].KB * 256)   /* floats in one chunk of layer id */
 
+// SAVE: also store every layer's activations (sahs::act layout, 19 KB/sample) for field_bwd.hip
+template <bool SAVE>
 __global__ void __launch_bounds__(F32_THREADS, 2)
 field_forward_f32_kernel(const float *__restrict__ packed, const float *__restrict__ frame, int level, long P, int S,
                          const float *__restrict__ rays, int ray_stride, const float *__restrict__ zvals,
-                         float *__restrict__ raw, float *__restrict__ dbg)
+                         float *__restrict__ raw, float *__restrict__ dbg, float *__restrict__ actbuf)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Ctx cx;
@@ -284,6 +288,8 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         float *stash = lds + LDS_STASH_OFF + (cx.wave * F32_PTS_PER_WAVE + (cx.lane & 15)) * STASH_FLOATS;
         const bool dump = dbg != nullptr && q == 0 && p_raw < P;   // lanes holding feature 0 of tile 0
         float *dsl = dbg + p * DBG_STRIDE;
+        float *sv = (SAVE && p_raw < P) ? actbuf + p * (long)act::STRIDE + 4 * q : nullptr;   // this lane's slot in its sample's row
+#define SV(off) (SAVE && sv != nullptr ? sv + (off) : nullptr)
         f32x4 pe_x[4];
         float x[3];
         {
@@ -292,43 +298,54 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
 #pragma unroll
             for (int i = 0; i < 3; ++i) x[i] = rp[i] + rp[3 + i] * z;          // train_utils.py:115
             pe_blocks<3, 10, 4>(x, q, pe_x);
+            if (SAVE && sv != nullptr) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4 *>(sv + act::E + 16 * b) = pe_x[b];
+            }
         }
         // ---- warp field: dx = tanh(MLP) (modules.py:371-390) ----
         {
             f32x4 h[8], hn[8];
-            dense<4, 0, 8, CHF(L_W1)>(cx, pe_x, nullptr, h, Ly[L_W0].bias_off, false, 0.0f);
+            dense<4, 0, 8, CHF(L_W1)>(cx, pe_x, nullptr, h, Ly[L_W0].bias_off, false, 0.0f, SV(act::WH));
 #pragma unroll 1
             for (int l = 0; l < 3; ++l) {      // W1..W3 (the chunk after each is 32 KB: W2, W3, W4B)
-                dense<8, 0, 8, CHF(L_W2)>(cx, h, nullptr, hn, Ly[L_W1].bias_off + 128 * l, false, 0.0f);
+                dense<8, 0, 8, CHF(L_W2)>(cx, h, nullptr, hn, Ly[L_W1].bias_off + 128 * l, false, 0.0f, SV(act::WH + 128 * (l + 1)));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) h[i] = hn[i];
             }
             dense<4, 0, 8, CHF(L_W4A)>(cx, pe_x, nullptr, hn, Ly[L_W4B].bias_off, false, 1.0f);
-            dense<8, 0, 8, CHF(L_W5)>(cx, h, nullptr, hn, 0, true, 0.0f);
-            dense<8, 0, 8, CHF(L_WF)>(cx, hn, nullptr, h, Ly[L_W5].bias_off, false, 0.0f);
+            dense<8, 0, 8, CHF(L_W5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::WH + 4 * 128));
+            dense<8, 0, 8, CHF(L_WF)>(cx, hn, nullptr, h, Ly[L_W5].bias_off, false, 0.0f, SV(act::WH + 5 * 128));
             f32x4 o[1];
             dense<8, 0, 1, CHF(L_H0)>(cx, h, nullptr, o, Ly[L_WF].bias_off, false, 1.0f);
             if (q == 0) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) stash[i] = x[i] + tanhf(o[0][i]);     // models.py:305 (rows 0..2 live in lane quarter 0)
+                for (int i = 0; i < 3; ++i) {
+                    const float dxv = tanhf(o[0][i]);
+                    stash[i] = x[i] + dxv;                                            // models.py:305 (rows 0..2 live in lane quarter 0)
+                    if (SAVE && sv != nullptr) { sv[act::DX + i] = dxv; sv[act::XW + i] = x[i] + dxv; }
+                }
             }
         }
         // ---- hyper sheet: ambient w (modules.py:444-462) ----
         {
             f32x4 h[4], hn[4];
-            dense<4, 0, 4, CHF(L_H1)>(cx, pe_x, nullptr, h, Ly[L_H0].bias_off, false, 0.0f);
+            dense<4, 0, 4, CHF(L_H1)>(cx, pe_x, nullptr, h, Ly[L_H0].bias_off, false, 0.0f, SV(act::HH));
 #pragma unroll 1
             for (int l = 0; l < 3; ++l) {      // H1..H3 (next chunks: H2, H3, H4B, all 16 KB)
-                dense<4, 0, 4, CHF(L_H2)>(cx, h, nullptr, hn, Ly[L_H1].bias_off + 64 * l, false, 0.0f);
+                dense<4, 0, 4, CHF(L_H2)>(cx, h, nullptr, hn, Ly[L_H1].bias_off + 64 * l, false, 0.0f, SV(act::HH + 64 * (l + 1)));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) h[i] = hn[i];
             }
             dense<4, 0, 4, CHF(L_H4A)>(cx, pe_x, nullptr, hn, Ly[L_H4B].bias_off, false, 1.0f);
-            dense<4, 0, 4, CHF(L_H5)>(cx, h, nullptr, hn, 0, true, 0.0f);
-            dense<4, 0, 4, CHF(L_HF)>(cx, hn, nullptr, h, Ly[L_H5].bias_off, false, 0.0f);
+            dense<4, 0, 4, CHF(L_H5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::HH + 4 * 64));
+            dense<4, 0, 4, CHF(L_HF)>(cx, hn, nullptr, h, Ly[L_H5].bias_off, false, 0.0f, SV(act::HH + 5 * 64));
             f32x4 o[1];
             dense<4, 0, 1, CHF(L_T0)>(cx, h, nullptr, o, Ly[L_HF].bias_off, false, 1.0f);
-            if (q == 0) { stash[3] = o[0][0]; stash[4] = o[0][1]; }
+            if (q == 0) {
+                stash[3] = o[0][0]; stash[4] = o[0][1];
+                if (SAVE && sv != nullptr) { sv[act::AW] = o[0][0]; sv[act::AW + 1] = o[0][1]; }
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (dump) { dsl[0] = stash[0] - x[0]; dsl[1] = stash[1] - x[1]; dsl[2] = stash[2] - x[2]; dsl[3] = stash[3]; dsl[4] = stash[4]; }
@@ -343,14 +360,18 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                 const float xw[3] = {stash[0], stash[1], stash[2]}, amb[2] = {stash[3], stash[4]};
                 pe_blocks<3, 10, 4>(xw, q, in_tr);
                 pe_blocks<2, 4, 2>(amb, q, in_tr + 4);
-                dense<4, 2, 16, CHF(L_T1)>(cx, in_tr, in_tr + 4, h, Ly[L_T0].bias_off, false, 0.01f);
+                if (SAVE && sv != nullptr) {
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x4 *>(sv + act::PEX + 16 * b) = in_tr[b];   // PEX (4 blocks) then PEW (2)
+                }
+                dense<4, 2, 16, CHF(L_T1)>(cx, in_tr, in_tr + 4, h, Ly[L_T0].bias_off, false, 0.01f, SV(act::T));
             }
             if (dump) dsl[5] = h[0][0];
-            dense<16, 0, 16, CHF(L_T2)>(cx, h, nullptr, feat, Ly[L_T1].bias_off, false, 0.01f);
+            dense<16, 0, 16, CHF(L_T2)>(cx, h, nullptr, feat, Ly[L_T1].bias_off, false, 0.01f, SV(act::T + 256));
             if (dump) dsl[6] = feat[0][0];
 #pragma unroll
             for (int i = 0; i < 16; ++i) h[i] = feat[i];
-            dense<16, 0, 16, CHF(L_T3B)>(cx, h, nullptr, feat, Ly[L_T2].bias_off, false, 0.01f);
+            dense<16, 0, 16, CHF(L_T3B)>(cx, h, nullptr, feat, Ly[L_T2].bias_off, false, 0.01f, SV(act::T + 512));
             if (dump) dsl[7] = feat[0][0];
 #pragma unroll
             for (int i = 0; i < 16; ++i) h[i] = feat[i];
@@ -361,18 +382,18 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                 pe_blocks<2, 4, 2>(amb, q, in_tr + 4);
                 dense<4, 2, 16, CHF(L_T3A)>(cx, in_tr, in_tr + 4, feat, Ly[L_T3B].bias_off, false, 1.0f);
             }
-            dense<16, 0, 16, CHF(L_T4)>(cx, h, nullptr, feat, 0, true, 0.01f);
+            dense<16, 0, 16, CHF(L_T4)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768));
             if (dump) dsl[8] = feat[0][0];
 #pragma unroll
             for (int i = 0; i < 16; ++i) h[i] = feat[i];
 #pragma unroll 1
             for (int l = 4; l <= 7; ++l) {     // T4..T7 (next chunks: T5, T6, T7, FEAT, all 32 KB)
-                dense<16, 0, 16, CHF(L_T5)>(cx, h, nullptr, feat, Ly[L_T4].bias_off + 256 * (l - 4), false, 0.01f);
+                dense<16, 0, 16, CHF(L_T5)>(cx, h, nullptr, feat, Ly[L_T4].bias_off + 256 * (l - 4), false, 0.01f, SV(act::T + 256 * l));
                 if (dump) dsl[5 + l] = feat[0][0];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) h[i] = feat[i];
             }
-            dense<16, 0, 16, CHF(L_ALPHA)>(cx, h, nullptr, feat, Ly[L_FEAT].bias_off, false, 1.0f);
+            dense<16, 0, 16, CHF(L_ALPHA)>(cx, h, nullptr, feat, Ly[L_FEAT].bias_off, false, 1.0f, SV(act::FEAT));
             if (dump) dsl[13] = feat[0][0];
         }
         dense<16, 0, 1, CHF(L_D0B)>(cx, feat, nullptr, fin, Ly[L_ALPHA].bias_off, false, 1.0f);
@@ -385,6 +406,10 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                 const float rd[3] = {rp[3], rp[4], rp[5]};
                 pe_blocks<3, 4, 2>(rd, q, in_d);                                  // models.py:340 (raw, un-normalised direction)
                 grid_blocks(grid, stash[0], stash[1], stash[2], q, in_d + 2);     // models.py:525
+                if (SAVE && sv != nullptr) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4 *>(sv + act::DIR + 16 * b) = in_d[b];   // DIR (2 blocks) then GRID (2)
+                }
             }
             if (dbg != nullptr && p_raw < P) {
                 float *d = dbg + P * DBG_STRIDE + p * 32;
@@ -393,15 +418,15 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
             }
             f32x4 c[8], cn[8];
             dense<2, 2, 8, CHF(L_D0A)>(cx, in_d, in_d + 2, c, Ly[L_D0B].bias_off, false, 1.0f);
-            dense<16, 0, 8, CHF(L_D1)>(cx, feat, nullptr, c, 0, true, 0.01f);
+            dense<16, 0, 8, CHF(L_D1)>(cx, feat, nullptr, c, 0, true, 0.01f, SV(act::C));
             if (dump) dsl[14] = c[0][0];
 #pragma unroll 1
             for (int l = 0; l < 2; ++l) {      // D1, D2
-                dense<8, 0, 8, CHF(L_D2)>(cx, c, nullptr, cn, Ly[L_D1].bias_off + 128 * l, false, 0.01f);
+                dense<8, 0, 8, CHF(L_D2)>(cx, c, nullptr, cn, Ly[L_D1].bias_off + 128 * l, false, 0.01f, SV(act::C + 128 * (l + 1)));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) c[i] = cn[i];
             }
-            dense<8, 0, 8, CHF(L_RGB)>(cx, c, nullptr, cn, Ly[L_D3].bias_off, false, 0.01f);
+            dense<8, 0, 8, CHF(L_RGB)>(cx, c, nullptr, cn, Ly[L_D3].bias_off, false, 0.01f, SV(act::C + 384));
             if (dump) dsl[15] = cn[0][0];
             dense<8, 0, 1, CHF(L_S0)>(cx, cn, nullptr, fin, 0, true, 1.0f);
             if (dbg != nullptr && p_raw < P) *reinterpret_cast<f32x4 *>(dsl + 40 + 4 * q) = fin[0];
@@ -409,15 +434,15 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         // ---- seg branch (modules.py:289-294) ----
         {
             f32x4 s[8], sn[8];
-            dense<16, 0, 8, CHF(L_S1)>(cx, feat, nullptr, s, Ly[L_S0].bias_off, false, 0.01f);
+            dense<16, 0, 8, CHF(L_S1)>(cx, feat, nullptr, s, Ly[L_S0].bias_off, false, 0.01f, SV(act::S));
             if (dump) dsl[16] = s[0][0];
 #pragma unroll 1
             for (int l = 0; l < 2; ++l) {      // S1, S2
-                dense<8, 0, 8, CHF(L_S2)>(cx, s, nullptr, sn, Ly[L_S1].bias_off + 128 * l, false, 0.01f);
+                dense<8, 0, 8, CHF(L_S2)>(cx, s, nullptr, sn, Ly[L_S1].bias_off + 128 * l, false, 0.01f, SV(act::S + 128 * (l + 1)));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s[i] = sn[i];
             }
-            dense<8, 0, 8, CHF(L_SEG)>(cx, s, nullptr, sn, Ly[L_S3].bias_off, false, 0.01f);
+            dense<8, 0, 8, CHF(L_SEG)>(cx, s, nullptr, sn, Ly[L_S3].bias_off, false, 0.01f, SV(act::S + 384));
             if (dump) dsl[17] = sn[0][0];
             dense<8, 0, 1, CHF(L_W0)>(cx, sn, nullptr, fin, 0, true, 1.0f);
         }
@@ -431,7 +456,7 @@ using namespace sahs;
 
 // dbg (optional, may be null): [P x 24: see DBG_STRIDE][P x 32: grid features]
 extern "C" int sahs_field_forward_f32_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays,
-                                             int ray_stride, const float *zvals, float *raw, float *dbg, int num_cu,
+                                             int ray_stride, const float *zvals, float *raw, float *dbg, float *actbuf, int num_cu,
                                              hipStream_t stream)
 {
     if (P <= 0) return 0;
@@ -440,11 +465,17 @@ extern "C" int sahs_field_forward_f32_launch(const float *packed, const float *f
     const size_t lds_bytes = (size_t)LDS_TOTAL_FLOATS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_f32_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_f32_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_f32_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    field_forward_f32_kernel<<<grid, F32_THREADS, lds_bytes, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg);
+    if (actbuf != nullptr)
+        field_forward_f32_kernel<true><<<grid, F32_THREADS, lds_bytes, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, actbuf);
+    else
+        field_forward_f32_kernel<false><<<grid, F32_THREADS, lds_bytes, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, nullptr);
     return (int)hipGetLastError();
 }

@@ -341,3 +341,30 @@ constexpr long PACKH_WORDS = PACKH_TABLE_OFF + ((NUM_CHUNKS_H + 1 + 3) / 4) * 4;
 
 }  // namespace hb
 }  // namespace sahs
+
+// =============================================================================================
+// Saved activations for the backward pass (field_bwd.hip).  One row per sample, fp32, every entry a whole number
+// of 16-feature blocks in the field kernel's B layout, so the forward kernel stores each finished tile with one
+// float4 per lane.  Hidden activations are stored POST activation (relu/leaky-relu keep the sign, so the
+// derivative mask is recovered from them); PE rows hold sin and cos of every octave, so the PE derivative needs
+// no trigonometry.
+// =============================================================================================
+namespace sahs {
+namespace act {
+constexpr int E = 0;                    // PE63(x), 64
+constexpr int WH = E + 64;              // warp hidden h0..h5, 6 x 128
+constexpr int DX = WH + 6 * 128;        // dx = tanh(.), 3 (+13 pad)
+constexpr int HH = DX + 16;             // hyper hidden g0..g5, 6 x 64
+constexpr int AW = HH + 6 * 64;         // ambient w, 2 (+14 pad)
+constexpr int XW = AW + 16;             // warped point x', 3 (+13 pad)
+constexpr int PEX = XW + 16;            // PE63(x'), 64
+constexpr int PEW = PEX + 64;           // PE18(w), 32
+constexpr int T = PEW + 32;             // trunk t0..t7, 8 x 256
+constexpr int FEAT = T + 8 * 256;       // 256
+constexpr int DIR = FEAT + 256;         // PE27(rd), 32
+constexpr int GRID = DIR + 32;          // grid features, 32
+constexpr int C = GRID + 32;            // colour hidden c0..c3, 4 x 128
+constexpr int S = C + 4 * 128;          // seg hidden s0..s3, 4 x 128
+constexpr int STRIDE = S + 4 * 128;     // 4768 floats = 19 KB per sample
+}  // namespace act
+}  // namespace sahs

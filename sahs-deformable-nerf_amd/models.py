@@ -85,9 +85,12 @@ class AudioFaceModel(nn.Module):
         self._cache = {}
 
     # ---- weight plumbing ----
-    def flat_params(self):
+    def flat_params(self, differentiable=False):
+        """Canonical flat buffer (state_dict order).  differentiable=True keeps the autograd link to the parameters, so a
+        gradient w.r.t. the flat buffer (RenderRaysFn.backward) is scattered back to every nn.Parameter by torch.cat's backward."""
         sd = dict(self.named_parameters())
-        return torch.cat([sd[k].reshape(-1) for k, _ in W.canonical_spec()]).detach().float().contiguous()
+        flat = torch.cat([sd[k].reshape(-1) for k, _ in W.canonical_spec()]).float().contiguous()
+        return flat if differentiable else flat.detach()
 
     def load_flat(self, flat):
         off = 0

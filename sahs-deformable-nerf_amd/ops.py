@@ -2,10 +2,11 @@
 is the HIP library's.  Every function requires CUDA(HIP) fp32 tensors and raises otherwise --
 there is no eager/CPU path here.
 
-autograd: FieldFn / CompositeFn / ResampleFn wrap the forward kernels.  ResampleFn is
-non-differentiable (the reference detaches it, train_utils.py:164).  Backward kernels are the
-next row of the scope table (SURVEY.md section 8, B*): until they land, a call that would need a
-gradient raises instead of silently returning none.
+autograd: ``RenderRaysFn`` (one ray chunk of predict_and_render_radiance) is the differentiable op: its
+backward runs the HIP backward kernels (composite_backward, field_backward, conditioning_backward) and
+returns gradients for the flat parameter buffer and the audio window.  Importance resampling is not
+differentiated (the reference detaches it, train_utils.py:164).  The stand-alone seam functions
+(model(...), volume_render_radiance_field) are forward-only and raise if a gradient would be needed.
 """
 import ctypes
 
@@ -37,8 +38,8 @@ def _req(t, name, dtype=torch.float32):
 
 def _no_grad_needed(*tensors):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError("backward through the HIP field/composite ops is not built yet (forward/eval only); "
-                                  "wrap the call in torch.no_grad()")
+        raise NotImplementedError("this seam is forward-only; gradients flow through run_one_iter_of_nerf / RenderRaysFn "
+                                  "(wrap the call in torch.no_grad())")
 
 
 def param_count():
@@ -168,3 +169,91 @@ def render_rays(packed, frame, rays, num_coarse, num_fine, precision=SAHS_F32, l
     if num_fine > 0:
         return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_bg, depth_f
     return rgb_c, disp_c, acc_c, None, None, None, w_bg, depth_f
+
+
+# ---------------------------------------------------------------------------------------------------------
+# training path
+# ---------------------------------------------------------------------------------------------------------
+def field_forward_save(packed, frame, level, rays, z):
+    """fp32 field forward that also returns the saved activations (N*S, act_words) for field_backward."""
+    packed, frame, rays, z = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays"), _req(z, "z")
+    N, S = z.shape
+    raw = torch.empty(N, S, 16, dtype=torch.float32, device=z.device)
+    act = torch.empty(N * S, _lib.lib().sahs_act_words_per_sample(), dtype=torch.float32, device=z.device)
+    check(_lib.lib().sahs_field_forward_save(_p(packed), _p(frame), int(level), N, S, _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(act),
+                                              _stream()), "sahs_field_forward_save")
+    return raw, act
+
+
+def field_backward(flat, frame, level, act, d_raw, grad_flat, grad_cond):
+    flat, frame, act, d_raw = _req(flat, "flat_params"), _req(frame, "frame"), _req(act, "act"), _req(d_raw, "d_raw")
+    P = act.shape[0]
+    ws = torch.empty(_lib.lib().sahs_field_backward_workspace_words(P), dtype=torch.float32, device=act.device)
+    check(_lib.lib().sahs_field_backward(_p(flat), _p(frame), int(level), P, _p(act), _p(d_raw), _p(grad_flat), _p(grad_cond), _p(ws), _stream()),
+          "sahs_field_backward")
+
+
+def composite_backward(raw, z, rays, noise, bg, white_background, d_rgb, d_disp, d_acc, d_depth, d_wlast):
+    raw, z, rays = _req(raw, "raw"), _req(z, "z"), _req(rays, "rays")
+    N, S = z.shape
+    d_raw = torch.empty(N, S, 16, dtype=torch.float32, device=z.device)
+    gs = [_req(g, n) for g, n in ((d_rgb, "d_rgb"), (d_disp, "d_disp"), (d_acc, "d_acc"), (d_depth, "d_depth"), (d_wlast, "d_wlast"))]
+    check(_lib.lib().sahs_composite_backward(N, S, _p(raw), _p(z), _p(rays), int(rays.shape[1]), _p(_req(noise, "noise")), _p(_req(bg, "bg")),
+                                              int(bool(white_background)), *[_p(g) for g in gs], _p(d_raw), _stream()), "sahs_composite_backward")
+    return d_raw
+
+
+class RenderRaysFn(torch.autograd.Function):
+    """predict_and_render_radiance (train_utils.py:72-206) for one ray chunk, differentiable w.r.t. the model
+    parameters (as the canonical flat buffer) and the audio window.
+
+    forward: the six forward launches (sahs_render_rays).  backward: per level -- re-run the field with activation
+    saving, composite backward, field backward -- then the conditioning backward; rays are processed in blocks so the
+    saved activations (19 KB per sample) stay bounded."""
+
+    BLOCK_RAYS = 4096
+
+    @staticmethod
+    def forward(ctx, flat, audio, pose, rays, bg, t_rand, noise_c, u, noise_f, packed, num_coarse, num_fine, lindisp, white_background):
+        frame = fold_conditioning(flat.detach(), audio.detach(), pose)
+        ws = {}
+        outs = render_rays(packed, frame, rays, num_coarse, num_fine, precision=SAHS_F32, lindisp=lindisp, white_background=white_background,
+                           bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f, workspace=ws)
+        ctx.save_for_backward(flat.detach(), audio.detach(), rays, ws["z_c"].clone(), ws["z_f"].clone(), frame, packed,
+                              *[t if t is not None else torch.empty(0, device=rays.device) for t in (bg, noise_c, noise_f)])
+        ctx.cfg = (num_coarse, num_fine, bool(white_background), bg is not None, noise_c is not None, noise_f is not None)
+        ctx.mark_non_differentiable(outs[6]) if False else None
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rgb_c, g_disp_c, g_acc_c, g_rgb_f, g_disp_f, g_acc_f, g_wbg, g_depth_f):
+        flat, audio, rays, z_c, z_f, frame, packed, bg, noise_c, noise_f = ctx.saved_tensors
+        nc, nf, white, has_bg, has_nc, has_nf = ctx.cfg
+        bg = bg if has_bg else None
+        noise_c = noise_c if has_nc else None
+        noise_f = noise_f if has_nf else None
+        dev = rays.device
+        grad_flat = torch.zeros_like(flat)
+        grad_cond = torch.zeros(128, dtype=torch.float32, device=dev)
+        grad_audio = torch.zeros_like(audio)
+        c = lambda t: None if t is None else t.contiguous().float()
+        N = rays.shape[0]
+        for s in range(0, N, RenderRaysFn.BLOCK_RAYS):
+            e = min(N, s + RenderRaysFn.BLOCK_RAYS)
+            sl = slice(s, e)
+            rb = rays[sl].contiguous()
+            bgb = None if bg is None else bg[sl].contiguous()
+            for level, z, noise, grads in ((1, z_f, noise_f, (g_rgb_f, g_disp_f, g_acc_f, g_depth_f, g_wbg)),
+                                           (0, z_c, noise_c, (g_rgb_c, g_disp_c, g_acc_c, None, None))):
+                if all(g is None for g in grads):
+                    continue
+                zb = z[sl].contiguous()
+                raw, act = field_forward_save(packed, frame, level, rb, zb)
+                nb = None if noise is None else noise[sl].contiguous()
+                gb = [None if g is None else c(g[sl]) for g in grads]
+                d_raw = composite_backward(raw, zb, rb, nb, bgb, white, *gb)
+                field_backward(flat, frame, level, act, d_raw.view(-1, 16), grad_flat, grad_cond)
+                del raw, act, d_raw
+        check(_lib.lib().sahs_conditioning_backward(_p(flat), _p(audio), _p(grad_cond), _p(grad_flat), _p(grad_audio), _stream()),
+              "sahs_conditioning_backward")
+        return (grad_flat, grad_audio) + (None,) * 12

@@ -34,7 +34,7 @@ def predict_and_render_radiance(ray_batch, model, options, mode="train", driving
     if latent_code is not None:
         raise NotImplementedError("latent codes are not used by the shipped audio configs")
     opt = getattr(options.nerf, mode)
-    ops._no_grad_needed(ray_batch, driving, background_prior, *model.parameters())
+    needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in model.parameters()) or (driving is not None and driving.requires_grad))
     rays = ray_batch.to(torch.float32)
     if not rays.is_contiguous():
         rays = rays.contiguous()
@@ -53,6 +53,13 @@ def predict_and_render_radiance(ray_batch, model, options, mode="train", driving
         if background_prior.shape[-1] != 15:
             raise NotImplementedError("background_prior must have 15 channels (rgb3 + seg12)")
         bg = background_prior.to(torch.float32)
+    if needs_grad:
+        # training step (train_stage_rays_auto.py:437-499): differentiable op, fp32; its backward runs the HIP backward kernels
+        if model.precision != ops.SAHS_F32:
+            raise NotImplementedError("training runs the fp32 path; build the model with precision='fp32'")
+        flat = model.flat_params(differentiable=True)
+        return ops.RenderRaysFn.apply(flat, driving.to(torch.float32), pose.to(torch.float32), rays.detach(), bg, t_rand, noise_c, u, noise_f,
+                                      packed, nc, nf, bool(opt.lindisp), bool(opt.white_background))
     return ops.render_rays(packed, frame, rays, nc, nf, precision=model.precision, lindisp=bool(opt.lindisp),
                            white_background=bool(opt.white_background), bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f,
                            workspace=_workspace)
