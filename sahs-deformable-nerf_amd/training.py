@@ -1,0 +1,74 @@
+"""Stage-I training step around the HIP ops (BASELINE.json configs[4]; semantics of
+``train_stage_rays_auto.py:390-509``, which is out of sync with ``nerf/`` as shipped -- SURVEY.md section 0.3 -- so this
+mirrors what the step computes, not its tuple unpacking).
+
+  1. semantic-weighted ray sampling: p(pixel) ~ sum_c sample_prob[c] * mask[pixel, c]            (:390-394, :417-419)
+  2. 2048 rays without replacement; gather origins, directions, target colour, background prior, class mask (:421-432)
+  3. run_one_iter_of_nerf(mode="train") -> coarse and fine 15-channel renders                               (:437-452)
+  4. loss = sum over {coarse, fine} of  MSE + 0.02 * CE + 0.005 * (masked MSE + masked CE of classes 7:9)   (:455-465)
+     [+ 0.005 * ||spatial_embeddings|| when regularize_spatial_embedding]                                  (:476-477, :490-491)
+  5. sample_prob <- normalised sum of the four weighted per-class losses (feeds the next step's sampling)   (:466-468)
+  6. backward, Adam step, lr = lr0 * decay_factor ** (i / (lr_decay * 1000))                               (:493-509)
+"""
+import torch
+
+from .nerf_helpers import MaskCrossEntropyLoss, MaskMSELoss, get_ray_bundle, mse2psnr
+from .train_utils import run_one_iter_of_nerf
+
+
+def semantic_ray_probs(sample_prob, mask):
+    """(12,), (H, W, 12) -> (H*W,) sampling distribution over pixels."""
+    p = torch.sum(sample_prob.reshape(1, 1, -1) * mask, dim=-1).reshape(-1).double()
+    return (p / p.sum()).float()
+
+
+def sample_training_rays(probs, num_rays, generator=None):
+    """Indices of ``num_rays`` distinct pixels drawn with probability ``probs`` (np.random.choice(replace=False, p=...))."""
+    return torch.multinomial(probs, num_rays, replacement=False, generator=generator)
+
+
+def stage1_loss(rgb_coarse, rgb_fine, target_rgb, mask, mse_loss=None, ce_loss=None):
+    """-> (loss, new_sample_prob, fine_mse).  rgb_*: (R,15) = [rgb3 | seg12]; target_rgb (R,3); mask (R,12) one-hot."""
+    mse_loss = mse_loss or MaskMSELoss()
+    ce_loss = ce_loss or MaskCrossEntropyLoss()
+    total, weighted = 0.0, []
+    fine_mse = None
+    for rgb in (rgb_coarse, rgb_fine):
+        if rgb is None:
+            continue
+        l2, m_l2, m_l2_w = mse_loss(mask, rgb[..., :3], target_rgb[..., :3])
+        ce, m_ce, m_ce_w = ce_loss(mask, rgb[..., 3:], mask)
+        mouth = torch.sum(m_l2[7:9] + m_ce[7:9])
+        total = total + l2 + 0.02 * ce + 0.005 * mouth
+        weighted += [m_l2_w, m_ce_w]
+        fine_mse = l2
+    w = torch.stack([x.detach() for x in weighted]).sum(0)
+    return total, w / w.sum(), fine_mse
+
+
+def learning_rate(cfg, step):
+    return cfg.optimizer.lr * (cfg.scheduler.lr_decay_factor ** (step / (cfg.scheduler.lr_decay * 1000)))
+
+
+def train_step(model, optimizer, cfg, step, image, mask, pose, intrinsics, audio, background, sample_prob, generator=None,
+               regularize_spatial_embedding=False):
+    """One optimisation step on one frame.  image (H,W,3), mask (H,W,12) one-hot float, background (H,W,15).
+    Returns dict(loss, psnr, sample_prob)."""
+    H, W = image.shape[:2]
+    probs = semantic_ray_probs(sample_prob, mask)
+    sel = sample_training_rays(probs, int(cfg.nerf.train.num_random_rays), generator)
+    ro, rd = get_ray_bundle(H, W, intrinsics, pose)
+    ro, rd = ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]
+    target = image.reshape(-1, image.shape[-1])[sel]
+    bg = background.reshape(-1, 15)[sel] if background is not None else None
+    m = mask.reshape(-1, 12)[sel].float()
+    outs = run_one_iter_of_nerf(H, W, intrinsics, model, ro, rd, cfg, mode="train", driving=audio, pose=pose, background_prior=bg, inHead=m)
+    loss, new_prob, fine_mse = stage1_loss(outs[0], outs[3], target, m)
+    if regularize_spatial_embedding:
+        loss = loss + torch.norm(model.spatial_embeddings) * 0.0005 * 10
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    optimizer.step()
+    for group in optimizer.param_groups:
+        group["lr"] = learning_rate(cfg, step)
+    return dict(loss=float(loss.detach()), psnr=mse2psnr(float(fine_mse.detach())), sample_prob=new_prob)

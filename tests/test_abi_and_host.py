@@ -117,3 +117,36 @@ def test_masked_losses_match_their_definition():
     ce = -(mask * torch.log(p + 1e-10)).sum(-1)
     assert torch.allclose(glob, ce.mean()) and torch.allclose(per[3], (ce * mask[:, 3]).sum() / max(1.0, float(mask[:, 3].sum())))
     assert abs(H.mse2psnr(0.01) - 20.0) < 1e-12 and H.mse2psnr(0) == 50.0
+
+
+def test_training_host_logic():
+    """train_stage_rays_auto.py:390-394, 455-468, 504-507: sampling distribution, loss recipe, lr schedule."""
+    sahs = pkg()
+    Tr = pkg("training")
+    cfg = sahs.default_config()
+    g = torch.Generator().manual_seed(1)
+    H = W = 8
+    mask = torch.zeros(H, W, 12)
+    cls = torch.randint(0, 12, (H, W), generator=g)
+    mask.scatter_(2, cls[..., None], 1.0)
+    sp = torch.rand(12, generator=g)
+    probs = Tr.semantic_ray_probs(sp, mask)
+    assert abs(float(probs.sum()) - 1.0) < 1e-6
+    assert torch.allclose(probs, sp[cls.reshape(-1)] / sp[cls.reshape(-1)].sum(), atol=1e-7)
+    sel = Tr.sample_training_rays(probs, 16, g)
+    assert len(set(sel.tolist())) == 16
+    R = 40
+    m = torch.zeros(R, 12)
+    m[torch.arange(R), torch.randint(0, 12, (R,), generator=g)] = 1.0
+    rc = torch.cat([torch.rand(R, 3, generator=g), torch.softmax(torch.rand(R, 12, generator=g), -1)], 1)
+    rf = torch.cat([torch.rand(R, 3, generator=g), torch.softmax(torch.rand(R, 12, generator=g), -1)], 1)
+    tgt = torch.rand(R, 3, generator=g)
+    loss, new_p, fine_mse = Tr.stage1_loss(rc, rf, tgt, m)
+    H_ = pkg("nerf_helpers")
+    want = 0.0
+    for r in (rc, rf):
+        l2, ml2, _ = H_.MaskMSELoss()(m, r[:, :3], tgt)
+        ce, mce, _ = H_.MaskCrossEntropyLoss()(m, r[:, 3:], m)
+        want = want + l2 + 0.02 * ce + 0.005 * torch.sum(ml2[7:9] + mce[7:9])
+    assert torch.allclose(loss, want) and abs(float(new_p.sum()) - 1.0) < 1e-6 and new_p.shape == (12,)
+    assert abs(Tr.learning_rate(cfg, 0) - 5e-4) < 1e-12 and abs(Tr.learning_rate(cfg, 250000) - 5e-5) < 1e-12

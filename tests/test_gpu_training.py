@@ -1,0 +1,114 @@
+"""configs[4] on the MI355X: a 2048-ray training step through the HIP autograd op, checked against plain PyTorch autograd
+of the eager restatement (oracle/torch_eager.py, itself pinned to the reference's golden gradients) and timed; then a few
+optimiser steps of the drop-in training loop."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_step_2048_rays_vs_eager_autograd(weights_mod):
+    from oracle import torch_eager as TE
+    sahs = pkg()
+    dev = torch.device("cuda:0")
+    cfg = sahs.default_config()
+    sd_np = weights_mod.hash_state_dict(0, 8.0, 30.0)
+    model = sahs.AudioFaceModel(cfg).to(dev).load_flat(weights_mod.flatten_state_dict(sd_np)).train()
+    sd_t = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in sd_np.items()}
+    field = TE.EagerField(sd_t)
+    rng = np.random.default_rng(3)
+    R = 2048
+    audio = torch.from_numpy(rng.standard_normal((16, 29)).astype(np.float32)).to(dev)
+    pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32)).to(dev)
+    ro = torch.zeros(R, 3, device=dev)
+    ro[:, 2] = 0.8
+    rd = torch.randn(R, 3, device=dev) * 0.15 + torch.tensor([0, 0, -1.0], device=dev)
+    bg = torch.cat([torch.rand(R, 3, device=dev), torch.ones(R, 1, device=dev), torch.zeros(R, 11, device=dev)], 1)
+    A, B = torch.randn(R, 15, device=dev), torch.randn(R, 15, device=dev)
+    rand = [dict(t_rand=torch.rand(R, 64, device=dev), noise_c=torch.randn(R, 64, device=dev) * 0.1, u=torch.rand(R, 64, device=dev),
+                 noise_f=torch.randn(R, 128, device=dev) * 0.1)]
+    feed = [("rand", rand[0]["t_rand"]), ("randn", rand[0]["noise_c"] / 0.1), ("rand", rand[0]["u"]), ("randn", rand[0]["noise_f"] / 0.1)]
+
+    def hip_step():
+        log = list(feed)
+        o_rand, o_randn = torch.rand, torch.randn
+        torch.rand = lambda *a, **k: log.pop(0)[1]
+        torch.randn = lambda *a, **k: log.pop(0)[1]
+        try:
+            outs = sahs.run_one_iter_of_nerf(0, 0, None, model, ro, rd, cfg, mode="train", driving=audio, pose=pose, background_prior=bg)
+        finally:
+            torch.rand, torch.randn = o_rand, o_randn
+        loss = (outs[0] * A).sum() + (outs[3] * B).sum() + outs[7].sum() * 0.1
+        model.zero_grad(set_to_none=True)
+        loss.backward()
+        return loss
+
+    def eager_step():
+        outs = TE.run_one_iter(field, ro, rd, cfg.dataset.near, cfg.dataset.far, audio, pose, bg=bg, rand=rand, perturb=True, noise_std=0.1)
+        loss = (outs[0] * A).sum() + (outs[3] * B).sum() + outs[7].sum() * 0.1
+        for v in sd_t.values():
+            v.grad = None
+        loss.backward()
+        return loss
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            loss = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, loss
+
+    t_hip, l_hip = timed(hip_step, 3)
+    t_eager, l_eager = timed(eager_step, 2)
+    assert abs(float(l_hip) - float(l_eager)) <= 1e-3 * abs(float(l_eager)) + 1e-2
+    worst = 0.0
+    for k, p in model.named_parameters():
+        ref = sd_t[k].grad
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((p.grad - ref).abs().max()) / scale
+        worst = max(worst, err)
+        assert err <= 2e-2, "%s: %.3e of scale" % (k, err)
+    res = dict(rays=R, hip_step_s=t_hip, eager_step_s=t_eager, hip_rays_per_s=R / t_hip, eager_rays_per_s=R / t_eager,
+               speedup=t_eager / t_hip, worst_grad_err_rel_scale=worst)
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    json.dump(res, open(os.path.join(REPO, "gpurun_out", "train_step.json"), "w"), indent=1)
+    print(json.dumps(res))
+
+
+def test_training_loop_reduces_loss(weights_mod):
+    sahs = pkg()
+    Tr = pkg("training")
+    dev = torch.device("cuda:0")
+    cfg = sahs.default_config()
+    cfg.nerf.train.num_random_rays = 512
+    model = sahs.AudioFaceModel(cfg).to(dev).load_flat(weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 8.0, 30.0))).train()
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.optimizer.lr)
+    g = torch.Generator(device=dev).manual_seed(0)
+    H = W = 32
+    image = torch.rand(H, W, 3, device=dev, generator=g) * 0.2 + 0.4
+    mask = torch.zeros(H, W, 12, device=dev)
+    mask[..., 0] = 1.0
+    mask[8:16, 8:16] = 0.0
+    mask[8:16, 8:16, 7] = 1.0
+    bgp = torch.cat([torch.rand(H, W, 3, device=dev, generator=g), torch.ones(H, W, 1, device=dev), torch.zeros(H, W, 11, device=dev)], -1)
+    audio = torch.randn(16, 29, device=dev, generator=g)
+    pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32)).to(dev)
+    intr = np.array([1200.0 * H / 512, 1200.0 * H / 512, 0.5, 0.5], np.float32)
+    sp = torch.ones(12, device=dev) / 12
+    torch.manual_seed(0)
+    losses = []
+    for step in range(8):
+        r = Tr.train_step(model, opt, cfg, step, image, mask, pose, intr, audio, bgp, sp, generator=g)
+        sp = r["sample_prob"]
+        losses.append(r["loss"])
+        assert np.isfinite(r["loss"]) and abs(float(sp.sum()) - 1) < 1e-5
+    assert min(losses[4:]) < losses[0], losses
