@@ -20,66 +20,124 @@ namespace sahs {
 // B(k,n) = B[k*ldb + n].  64x64 tile per 256-thread workgroup, K in steps of 16 through LDS; blockIdx.z splits K.
 // mode 0: C = acc; 1: C += acc; 2: atomicAdd(C, acc).  mask != null: acc *= (mask[m*ldm + n] > 0 ? 1 : slope).
 // ------------------------------------------------------------------------------------------------
-constexpr int GT = 64, GK = 16, GLD = 80;   // LDS row stride 80 floats: the two 16-lane groups of a ds_read_b32 half hit disjoint banks
+constexpr int GT = 128, GK = 16, GLD = 132;   // 128x128 tile, K-step 16; LDS row stride 132 floats
+
+// Global -> register staging of one K-step of both operands (8 floats per thread per operand), so that the loads of step
+// k+1 are in flight while step k is multiplied (the LDS tiles are double buffered).
+struct Stage { float a[8], b[8]; };
+
+template <bool TA>
+__device__ __forceinline__ void stage_load(Stage &st, int tid, long m0, int n0, long k0, long k_hi, int M, int N, const float *__restrict__ A,
+                                           long lda, const float *__restrict__ B, long ldb, bool va, bool vb)
+{
+    // A' tile element (kk, mm): thread covers 8 consecutive elements along the contiguous global direction
+    if (TA) {   // A'(m,k) = A[k*lda + m]: contiguous in m.  16 k-rows x 128 m: thread -> row kk = tid/16, mm = (tid%16)*8
+        const int kk = tid >> 4, mm = (tid & 15) * 8;
+        const long k = k0 + kk, m = m0 + mm;
+        if (va && k < k_hi && m + 7 < M) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(A + k * lda + m), v1 = *reinterpret_cast<const f32x4 *>(A + k * lda + m + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { st.a[i] = v0[i]; st.a[4 + i] = v1[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st.a[i] = (k < k_hi && m + i < M) ? A[k * lda + m + i] : 0.0f;
+        }
+    } else {    // A'(m,k) = A[m*lda + k]: contiguous in k.  128 m-rows x 16 k: thread -> mm = tid/2, kk = (tid%2)*8
+        const int mm = tid >> 1, kk = (tid & 1) * 8;
+        const long m = m0 + mm, k = k0 + kk;
+        if (va && m < M && k + 7 < k_hi) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(A + m * lda + k), v1 = *reinterpret_cast<const f32x4 *>(A + m * lda + k + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { st.a[i] = v0[i]; st.a[4 + i] = v1[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st.a[i] = (m < M && k + i < k_hi) ? A[m * lda + k + i] : 0.0f;
+        }
+    }
+    {           // B(k,n) = B[k*ldb + n]: contiguous in n.  16 k-rows x 128 n
+        const int kk = tid >> 4, nn = (tid & 15) * 8;
+        const long k = k0 + kk;
+        const int n = n0 + nn;
+        if (vb && k < k_hi && n + 7 < N) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(B + k * ldb + n), v1 = *reinterpret_cast<const f32x4 *>(B + k * ldb + n + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { st.b[i] = v0[i]; st.b[4 + i] = v1[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st.b[i] = (k < k_hi && n + i < N) ? B[k * ldb + n + i] : 0.0f;
+        }
+    }
+}
+
+template <bool TA>
+__device__ __forceinline__ void stage_store(const Stage &st, int tid, float (*As)[GLD], float (*Bs)[GLD])
+{
+    if (TA) {
+        const int kk = tid >> 4, mm = (tid & 15) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) As[kk][mm + i] = st.a[i];
+    } else {
+        const int mm = tid >> 1, kk = (tid & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) As[kk + i][mm] = st.a[i];
+    }
+    const int kk = tid >> 4, nn = (tid & 15) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Bs[kk][nn + i] = st.b[i];
+}
 
 template <bool TA>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(int M, int N, int K, const float *__restrict__ A, long lda,
                                                        const float *__restrict__ B, long ldb, float *__restrict__ C, long ldc, int mode,
                                                        const float *__restrict__ mask, long ldm, float slope, int kslab)
 {
-    __shared__ float As[GK][GLD], Bs[GK][GLD];
+    __shared__ float As[2][GK][GLD], Bs[2][GK][GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c16 = lane & 15;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;              // each wave: 64 x 64 = 4 x 4 MFMA tiles
     const long m0 = (long)blockIdx.y * GT;
     const int n0 = blockIdx.x * GT;
     const long k_lo = (long)blockIdx.z * kslab;
     const long k_hi = (k_lo + kslab < K) ? k_lo + kslab : K;
-    f32x4 acc[2][2];
+    // 16-byte vector loads only when every row start is 16-byte aligned
+    const bool va = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
+    const bool vb = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (ldb % 4 == 0);
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    Stage st;
+    stage_load<TA>(st, tid, m0, n0, k_lo, k_hi, M, N, A, lda, B, ldb, va, vb);
+    stage_store<TA>(st, tid, As[0], Bs[0]);
+    __syncthreads();
+    int cur = 0;
     for (long k0 = k_lo; k0 < k_hi; k0 += GK) {
-        // stage A' tile: As[k][m]
-#pragma unroll
-        for (int e = tid; e < GT * GK; e += 256) {
-            int kk, mm;
-            if (TA) { kk = e / GT; mm = e % GT; } else { mm = e / GK; kk = e % GK; }   // contiguous index fastest in global memory
-            const long m = m0 + mm, k = k0 + kk;
-            float v = 0.0f;
-            if (m < M && k < k_hi) v = TA ? A[k * lda + m] : A[m * lda + k];
-            As[kk][mm] = v;
-        }
-#pragma unroll
-        for (int e = tid; e < GT * GK; e += 256) {
-            const int kk = e / GT, nn = e % GT;
-            const long k = k0 + kk;
-            const int n = n0 + nn;
-            Bs[kk][nn] = (k < k_hi && n < N) ? B[k * ldb + n] : 0.0f;
-        }
-        __syncthreads();
+        const bool more = k0 + GK < k_hi;
+        if (more) stage_load<TA>(st, tid, m0, n0, k0 + GK, k_hi, M, N, A, lda, B, ldb, va, vb);
 #pragma unroll
         for (int s = 0; s < GK / 4; ++s) {
-            float a[2], b[2];
+            float a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[4 * s + q][32 * wm + 16 * i + c16];
+            for (int i = 0; i < 4; ++i) a[i] = As[cur][4 * s + q][64 * wm + 16 * i + c16];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[4 * s + q][32 * wn + 16 * j + c16];
+            for (int j = 0; j < 4; ++j) b[j] = Bs[cur][4 * s + q][64 * wn + 16 * j + c16];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (more) stage_store<TA>(st, tid, As[cur ^ 1], Bs[cur ^ 1]);
         __syncthreads();
+        cur ^= 1;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long m = m0 + 32 * wm + 16 * i + 4 * q + r;
-                const int n = n0 + 32 * wn + 16 * j + c16;
+                const long m = m0 + 64 * wm + 16 * i + 4 * q + r;
+                const int n = n0 + 64 * wn + 16 * j + c16;
                 if (m < M && n < N) {
                     float v = acc[i][j][r];
                     if (mask != nullptr) v *= (mask[m * ldm + n] > 0.0f) ? 1.0f : slope;

@@ -112,3 +112,33 @@ def test_training_loop_reduces_loss(weights_mod):
         losses.append(r["loss"])
         assert np.isfinite(r["loss"]) and abs(float(sp.sum()) - 1) < 1e-5
     assert min(losses[4:]) < losses[0], losses
+
+
+@pytest.mark.parametrize("S,use_bg,white", [(64, True, False), (128, True, False), (100, False, True)])
+def test_composite_backward_vs_autograd(S, use_bg, white):
+    """Seam-level: sahs_composite_backward against torch autograd of the eager compositing (volume_rendering_utils.py:7-78)."""
+    from oracle import torch_eager as TE
+    ops = pkg("ops")
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(S)
+    N = 257
+    raw = (torch.randn(N, S, 16, device=dev, generator=g) * 1.5)
+    raw[..., 15] = raw[..., 15] * 6 + 1.0
+    z = torch.sort(torch.rand(N, S, device=dev, generator=g) * 0.6 + 0.48, dim=1).values
+    rays = torch.zeros(N, 8, device=dev)
+    rays[:, 3:6] = torch.randn(N, 3, device=dev, generator=g) * 0.2 + torch.tensor([0, 0, -1.0], device=dev)
+    bg = torch.rand(N, 15, device=dev, generator=g) if use_bg else None
+    noise = torch.randn(N, S, device=dev, generator=g) * 0.1
+    gr = [torch.randn(N, 15, device=dev, generator=g)] + [torch.randn(N, device=dev, generator=g) for _ in range(4)]
+    x = raw.clone().requires_grad_(True)
+    xin = x
+    if use_bg:
+        xin = torch.cat((x[:, :-1], torch.cat((bg, x[:, -1, -1:]), dim=-1).unsqueeze(1)), dim=1)
+    rgb, disp, acc, w, depth = TE.volume_render(xin, z, rays[:, 3:6], noise, white, use_bg)
+    loss = (rgb * gr[0]).sum() + (disp * gr[1]).sum() * 1e-3 + (acc * gr[2]).sum() + (depth * gr[3]).sum() + (w[:, -1] * gr[4]).sum()
+    loss.backward()
+    d_raw = ops.composite_backward(raw, z, rays, noise, bg, white, gr[0], gr[1] * 1e-3, gr[2], gr[3], gr[4])
+    ref = x.grad
+    scale = float(ref.abs().max())
+    err = float((d_raw - ref).abs().max())
+    assert err <= 2e-4 * scale + 1e-6, (err, scale)
