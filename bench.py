@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = configs[1] (exact, headline); bf16 = configs[2] (bf16 MFMA operands, fp32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bf16 (configs[2]) leg that is reported beside the fp32 headline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,92 +76,103 @@ def main():
 
     pkg = importlib.import_module("sahs-deformable-nerf_amd")
     ops = pkg.ops
-    cfg, model, fw, audio, pose, intr, bg_all = build_inputs(pkg, dev, args.size, args.precision)
-    prec = model.precision
     H = W = args.size
     R = H * W
-    opt = cfg.nerf.validation
-    nc, nf, chunk = int(opt.num_coarse), int(opt.num_fine), int(opt.chunksize)
-    lo, hi = pkg.distributed.shard_bounds(R, world, rank)     # this rank's contiguous ray block
-    near, far = float(cfg.dataset.near), float(cfg.dataset.far)
-    packed, _ = model.packed()
-    torch.manual_seed(cfg.experiment.randomseed + rank)
-    ev = lambda: torch.cuda.Event(enable_timing=True)
-    field_events = []
-    ws = {}
 
-    def step(record):
-        ro, rd = pkg.get_ray_bundle(H, W, intr, pose)
-        frame = model.frame(audio, pose)
-        ro, rd = ro.view(-1, 3)[lo:hi], rd.view(-1, 3)[lo:hi]
-        n = hi - lo
-        rays = torch.cat([ro, rd, torch.full((n, 1), near, device=dev), torch.full((n, 1), far, device=dev)], dim=1)
-        outs = []
-        for s in range(0, n, chunk):
-            rb = rays[s:s + chunk].contiguous()
-            bgb = bg_all[lo + s: lo + s + rb.shape[0]]
-            N = rb.shape[0]
-            # same launches, in the same order, as sahs_render_rays / predict_and_render_radiance
-            t_rand = torch.rand((N, nc), device=dev)
-            z_c = ops.stratified_depths(rb, nc, False, t_rand)
-            e0, e1, e2, e3 = ev(), ev(), ev(), ev()
-            e0.record()
-            raw = ops.field_forward(packed, frame, 0, rb, z_c, precision=prec, out=ws.get(("raw", N, nc)))
-            e1.record()
-            ws[("raw", N, nc)] = raw
-            rgb_c, disp_c, acc_c, wts, _ = ops.composite_forward(raw, z_c, rb, bg=bgb)
-            u = torch.rand((N, nf), device=dev)
-            z_f = ops.resample(z_c, wts, nf, u=u)
-            e2.record()
-            raw_f = ops.field_forward(packed, frame, 1, rb, z_f, precision=prec, out=ws.get(("raw", N, nc + nf)))
-            e3.record()
-            ws[("raw", N, nc + nf)] = raw_f
-            rgb_f, disp_f, acc_f, wts_f, depth_f = ops.composite_forward(raw_f, z_f, rb, bg=bgb)
-            outs.append(torch.cat([rgb_c, disp_c[:, None], acc_c[:, None], rgb_f, disp_f[:, None], acc_f[:, None],
-                                   wts_f[:, -1:], depth_f[:, None]], dim=1))       # 36 floats / ray
-            if record:
-                field_events.append((e0, e1, N * nc))
-                field_events.append((e2, e3, N * (nc + nf)))
-        mine = torch.cat(outs, dim=0)
-        return pkg.distributed.all_gather_rows(mine, R) if world > 1 else mine   # RCCL all-gather of 36 floats/ray
+    def measure(precision, steps, warmup):
+        """Timed frames of the W512 workload at one precision -> (rays/s, ms/step, roofline dict, inputs)."""
+        cfg, model, fw, audio, pose, intr, bg_all = build_inputs(pkg, dev, args.size, precision)
+        prec = model.precision
+        opt = cfg.nerf.validation
+        nc, nf, chunk = int(opt.num_coarse), int(opt.num_fine), int(opt.chunksize)
+        lo, hi = pkg.distributed.shard_bounds(R, world, rank)     # this rank's contiguous ray block
+        near, far = float(cfg.dataset.near), float(cfg.dataset.far)
+        packed, _ = model.packed()
+        torch.manual_seed(cfg.experiment.randomseed + rank)
+        ev = lambda: torch.cuda.Event(enable_timing=True)
+        field_events = []
+        ws = {}
 
-    def barrier():
+        def step(record):
+            ro, rd = pkg.get_ray_bundle(H, W, intr, pose)
+            frame = model.frame(audio, pose)
+            ro, rd = ro.view(-1, 3)[lo:hi], rd.view(-1, 3)[lo:hi]
+            n = hi - lo
+            rays = torch.cat([ro, rd, torch.full((n, 1), near, device=dev), torch.full((n, 1), far, device=dev)], dim=1)
+            outs = []
+            for s in range(0, n, chunk):
+                rb = rays[s:s + chunk].contiguous()
+                bgb = bg_all[lo + s: lo + s + rb.shape[0]]
+                N = rb.shape[0]
+                # same launches, in the same order, as sahs_render_rays / predict_and_render_radiance
+                t_rand = torch.rand((N, nc), device=dev)
+                z_c = ops.stratified_depths(rb, nc, False, t_rand)
+                e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+                e0.record()
+                raw = ops.field_forward(packed, frame, 0, rb, z_c, precision=prec, out=ws.get(("raw", N, nc)))
+                e1.record()
+                ws[("raw", N, nc)] = raw
+                rgb_c, disp_c, acc_c, wts, _ = ops.composite_forward(raw, z_c, rb, bg=bgb)
+                u = torch.rand((N, nf), device=dev)
+                z_f = ops.resample(z_c, wts, nf, u=u)
+                e2.record()
+                raw_f = ops.field_forward(packed, frame, 1, rb, z_f, precision=prec, out=ws.get(("raw", N, nc + nf)))
+                e3.record()
+                ws[("raw", N, nc + nf)] = raw_f
+                rgb_f, disp_f, acc_f, wts_f, depth_f = ops.composite_forward(raw_f, z_f, rb, bg=bgb)
+                outs.append(torch.cat([rgb_c, disp_c[:, None], acc_c[:, None], rgb_f, disp_f[:, None], acc_f[:, None],
+                                       wts_f[:, -1:], depth_f[:, None]], dim=1))       # 36 floats / ray
+                if record:
+                    field_events.append((e0, e1, N * nc))
+                    field_events.append((e2, e3, N * (nc + nf)))
+            mine = torch.cat(outs, dim=0)
+            return pkg.distributed.all_gather_rows(mine, R) if world > 1 else mine   # RCCL all-gather of 36 floats/ray
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        with torch.no_grad():
+            for _ in range(warmup):
+                step(False)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = step(True)
+            barrier()
+            dt = time.perf_counter() - t0
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert bool(torch.isfinite(out).all())
+        field_ms = sum(a.elapsed_time(b) for a, b, _ in field_events)
+        field_flop = sum(p for _, _, p in field_events) * FLOP_PER_SAMPLE
+        achieved = field_flop / (field_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": KERNEL[precision], "achieved": achieved, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+                "frac": achieved / PEAK_TFLOPS[precision], "traffic": None, "launches": len(field_events),
+                "avg_launch_ms": field_ms / len(field_events), "flop_per_sample": FLOP_PER_SAMPLE, "field_time_share": field_ms * 1e-3 / dt}
+        return R * steps / dt, dt / steps * 1e3, roof, (cfg, fw, audio, pose, intr, bg_all, nc, nf, chunk, near, far)
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step(False)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step(True)
-        barrier()
-        dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert bool(torch.isfinite(out).all())
-
-    field_ms = sum(a.elapsed_time(b) for a, b, _ in field_events)
-    field_flop = sum(p for _, _, p in field_events) * FLOP_PER_SAMPLE
-    achieved = field_flop / (field_ms * 1e-3) / 1e12
-    launches = len(field_events)
-
+    value, ms_per_step, roof, (cfg, fw, audio, pose, intr, bg_all, nc, nf, chunk, near, far) = measure(args.precision, args.steps, args.warmup)
+    if args.precision == "fp32":   # HBM bytes of the dominant dispatch from rocprofv3 PMC (profiles/r1_fp32_pmc_summary.csv), fine launch
+        roof["traffic"] = {"write_GB": 1.105, "fetch_GB_x2_corrected": 30.7, "algorithmic_GB": 1.14,
+                           "note": "fetch = L2 misses of the LDS-DMA weight stream (served by Infinity Cache), 128 GB/s: not a bound"}
     result = {
-        "metric": "rendered rays/sec (coarse64+fine128, 8x256 MLP)", "value": R * args.steps / dt, "unit": "rays/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "metric": "rendered rays/sec (coarse64+fine128, 8x256 MLP)", "value": value, "unit": "rays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
         "config": {"workload": "W512: %dx%d rays, 64 coarse + 128 fine evaluations/ray, deform(6x128+6x64)+radiance(8x256) MLPs, "
                                "validation mode (perturb on), bg prior, hash-filled density-boosted weights" % (H, W),
                    "rays_per_step": R, "ray_chunk": chunk, "parallelism": "rays x%d" % world, "precision": args.precision},
-        "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": achieved, "peak": PEAK_TFLOPS[args.precision],
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": None,
-                     "launches": launches, "avg_launch_ms": field_ms / launches, "flop_per_sample": FLOP_PER_SAMPLE,
-                     "field_time_share": field_ms * 1e-3 / dt},
+        "roofline": roof,
     }
+    if args.precision == "fp32" and world == 1 and not args.no_secondary:
+        # BASELINE.json configs[2]: same workload through the bf16-MFMA field kernel (fp32 accumulate); reported beside the
+        # fp32 headline, never instead of it (PSNR delta vs fp32 on this workload: tests/test_gpu_bf16.py, 0.002 dB)
+        v2, ms2, roof2, _ = measure("bf16", max(args.steps, 5), 2)
+        result["bf16"] = {"value": v2, "unit": "rays/s", "ms_per_step": ms2, "dtype": "bf16", "roofline": roof2}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle   # cpu_baseline leg only: the oracle is the thing timed here, never the product path
