@@ -156,9 +156,11 @@ def main():
         return R * steps / dt, dt / steps * 1e3, roof, (cfg, fw, audio, pose, intr, bg_all, nc, nf, chunk, near, far)
 
     value, ms_per_step, roof, (cfg, fw, audio, pose, intr, bg_all, nc, nf, chunk, near, far) = measure(args.precision, args.steps, args.warmup)
-    if args.precision == "fp32":   # HBM bytes of the dominant dispatch from rocprofv3 PMC (profiles/r1_fp32_pmc_summary.csv), fine launch
-        roof["traffic"] = {"write_GB": 1.105, "fetch_GB_x2_corrected": 30.7, "algorithmic_GB": 1.14,
-                           "note": "fetch = L2 misses of the LDS-DMA weight stream (served by Infinity Cache), 128 GB/s: not a bound"}
+    # HBM-side bytes of the dominant dispatch (a fine launch, 16.8 M samples) from the rocprofv3 PMC passes committed under
+    # profiles/r1_final_pmc_summary.csv: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction for 16 B/lane streaming reads).
+    # Algorithmic bytes for that launch: 1.074 GB of raw output + 0.07 GB of depths.  (Static: bench.py cannot collect PMCs.)
+    roof["traffic"] = {"fp32": 1.074e9 + 4.28e9, "bf16": 1.074e9 + 0.09e9}[args.precision]
+    roof["traffic_note"] = "bytes per fine launch; reads beyond the algorithmic 0.07 GB are L2 misses of the weight stream (L2 hit 99 %)"
     result = {
         "metric": "rendered rays/sec (coarse64+fine128, 8x256 MLP)", "value": value, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -172,6 +174,7 @@ def main():
         # BASELINE.json configs[2]: same workload through the bf16-MFMA field kernel (fp32 accumulate); reported beside the
         # fp32 headline, never instead of it (PSNR delta vs fp32 on this workload: tests/test_gpu_bf16.py, 0.002 dB)
         v2, ms2, roof2, _ = measure("bf16", max(args.steps, 5), 2)
+        roof2["traffic"] = 1.074e9 + 0.09e9
         result["bf16"] = {"value": v2, "unit": "rays/s", "ms_per_step": ms2, "dtype": "bf16", "roofline": roof2}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -187,7 +190,7 @@ def main():
         t0 = time.perf_counter()
         oracle.run_one_iter_of_nerf(fw, ro_c, rd_c, near, far, nc, nf, audio.cpu().numpy(), pose.cpu().numpy(), background_prior=bg_c, rand=rnd)
         cdt = time.perf_counter() - t0
-        result["cpu_baseline"] = {"value": cs * cs / cdt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+        result["cpu_baseline"] = {"value": cs * cs / cdt, "unit": "rays/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
                                   "sample": "central %dx%d ray crop of the same frame (same weights, 64+128 evaluations/ray), "
                                             "C oracle with OpenMP over points, %.1f s" % (cs, cs, cdt)}
     if rank == 0:

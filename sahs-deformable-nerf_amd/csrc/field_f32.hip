@@ -196,9 +196,8 @@ template <int D, int L, int NB>
 __device__ __forceinline__ void pe_blocks(const float *v, int q, f32x4 *out)
 {
     constexpr int W = D + 2 * D * L;
-    RevArg u[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) u[i] = rev_arg(v[i]);
+    // plain scalars, selected with ternaries: an array of structs indexed by the lane-dependent axis ends up in scratch
+    const RevArg u0 = rev_arg(v[0]), u1 = rev_arg(v[1]), u2 = rev_arg(v[D > 2 ? 2 : 0]);
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -211,7 +210,9 @@ __device__ __forceinline__ void pe_blocks(const float *v, int q, f32x4 *out)
                 const int g = f - D;
                 const int k = g / (2 * D), rem = g % (2 * D);
                 const int fn = rem / D, ax = rem % D;
-                const RevArg a = (ax == 0) ? u[0] : ((ax == 1) ? u[1] : u[D > 2 ? 2 : 0]);
+                RevArg a;
+                a.p = (ax == 0) ? u0.p : ((ax == 1) ? u1.p : u2.p);
+                a.lo = (ax == 0) ? u0.lo : ((ax == 1) ? u1.lo : u2.lo);
                 val = sin_octave(a, (float)(1 << k), fn);
             }
             out[b][r] = val;
