@@ -299,6 +299,34 @@ def main():
     finally:
         F.relu = orig_relu
 
+    # ---- eval post-processing (eval_stage_rays.py:116-151 torch_normal_map; nerf/utils.py:112-140 label2color, :5-66 shrink) ----
+    # The eval script imports imageio/torchvision (absent here) and names from nerf/__init__; neither is touched by
+    # torch_normal_map, so empty stand-in modules / None names are enough to import it (same recipe as the pytorch3d stub).
+    for n in ("imageio", "torchvision"):
+        if n not in sys.modules:
+            sys.modules[n] = types.ModuleType(n)
+    nerf_pkg = sys.modules["nerf"]
+    nerf_pkg.utils = importlib.import_module("nerf.utils")
+    for nm, val in (("CfgNode", ref.cfgnode.CfgNode), ("get_ray_bundle", ref.nerf_helpers.get_ray_bundle),
+                    ("get_ray_bundle_by_mask", ref.nerf_helpers.get_ray_bundle_by_mask), ("load_flame_data", None), ("load_llff_data", None),
+                    ("models", ref.models), ("get_embedding_function", ref.nerf_helpers.get_embedding_function),
+                    ("run_one_iter_of_nerf", ref.train_utils.run_one_iter_of_nerf), ("meshgrid_xy", ref.nerf_helpers.meshgrid_xy)):
+        setattr(nerf_pkg, nm, val)
+    sys.path.insert(0, REF)
+    ev = importlib.import_module("eval_stage_rays")
+    Hn = 24
+    disp = torch.from_numpy((1.0 / rng.uniform(0.5, 1.0, (Hn, Hn))).astype(np.float32))
+    wbg = torch.from_numpy(rng.uniform(0, 0.5, (Hn, Hn)).astype(np.float32))
+    focal = np.array([1200.0 * Hn / 512, 1150.0 * Hn / 512, 0.48, 0.52], np.float32)
+    seg = torch.from_numpy(rng.standard_normal((Hn, Hn, 12)).astype(np.float32))
+    onehot = np.eye(12, dtype=np.float32)[rng.integers(0, 12, (Hn, Hn))]
+    out["post"] = dict(disp=disp.numpy(), w_bg=wbg.numpy(), focal=focal, seg=seg.numpy(), onehot=onehot,
+                       normals_clean=ev.torch_normal_map(disp.clone(), focal, wbg.clone(), clean=True).numpy(),
+                       normals_raw=ev.torch_normal_map(disp.clone(), focal, None, clean=False).numpy(),
+                       normals_central=ev.torch_normal_map(disp.clone(), focal, wbg.clone(), clean=True, central_difference=True).numpy(),
+                       seg_color=nerf_pkg.utils.label2color(seg).numpy(), shrink=nerf_pkg.utils.shrink(onehot),
+                       disp_img=ev.cast_to_disparity_image(disp))
+
     for name, d in out.items():
         d = dict(d)
         if name.startswith("e2e") or name == "train_grads":

@@ -150,3 +150,19 @@ def test_training_host_logic():
         want = want + l2 + 0.02 * ce + 0.005 * torch.sum(ml2[7:9] + mce[7:9])
     assert torch.allclose(loss, want) and abs(float(new_p.sum()) - 1.0) < 1e-6 and new_p.shape == (12,)
     assert abs(Tr.learning_rate(cfg, 0) - 5e-4) < 1e-12 and abs(Tr.learning_rate(cfg, 250000) - 5e-5) < 1e-12
+
+
+def test_eval_postprocessing_vs_reference():
+    """normal map (eval_stage_rays.py:116-151), label2color / shrink (nerf/utils.py) against vectors produced by the reference."""
+    from conftest import load_golden
+    E = pkg("evaluation")
+    g = load_golden("post")
+    disp, wbg, focal = torch.from_numpy(g["disp"]), torch.from_numpy(g["w_bg"]), g["focal"]
+    for key, kw in (("normals_clean", dict(weights=wbg, clean=True)), ("normals_raw", dict(weights=None, clean=False)),
+                    ("normals_central", dict(weights=wbg, clean=True, central_difference=True))):
+        n = E.normal_map(disp, focal, **kw).numpy()
+        assert n.shape == g[key].shape
+        assert np.abs(n - g[key]).max() <= 2e-3, (key, np.abs(n - g[key]).max())
+    assert np.array_equal(E.label2color(torch.from_numpy(g["seg"])).numpy(), g["seg_color"])
+    assert np.array_equal(E.shrink(g["onehot"]), g["shrink"])
+    assert np.array_equal(E.cast_to_disparity_image(disp), g["disp_img"])
