@@ -86,17 +86,31 @@ __device__ __forceinline__ void stage_store(const Stage &st, int tid, float (*As
     for (int i = 0; i < 8; ++i) Bs[kk][nn + i] = st.b[i];
 }
 
+// TA && rowsum != null: the n-block-0 workgroups also accumulate rowsum[m] += sum_k A'(m,k) (the bias gradient of the layer whose
+// weight gradient this GEMM is) from the A tiles they stage anyway.
+// nbn > 0 (1-D grid): XCD-aware mapping -- the nbn column blocks of one row block run on the same XCD (consecutive slots of
+// workgroup ids congruent mod 8), so the second one finds the shared A tile in that XCD's L2.
 template <bool TA>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(int M, int N, int K, const float *__restrict__ A, long lda,
                                                        const float *__restrict__ B, long ldb, float *__restrict__ C, long ldc, int mode,
-                                                       const float *__restrict__ mask, long ldm, float slope, int kslab)
+                                                       const float *__restrict__ mask, long ldm, float slope, int kslab,
+                                                       float *__restrict__ rowsum, int nbn)
 {
     __shared__ float As[2][GK][GLD], Bs[2][GK][GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c16 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;              // each wave: 64 x 64 = 4 x 4 MFMA tiles
-    const long m0 = (long)blockIdx.y * GT;
-    const int n0 = blockIdx.x * GT;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (nbn > 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        bx = slot % nbn;
+        by = (slot / nbn) * 8 + xcd;
+        if ((long)by * GT >= M) return;
+    }
+    const long m0 = (long)by * GT;
+    const int n0 = bx * GT;
     const long k_lo = (long)blockIdx.z * kslab;
+    const bool do_sum = TA && rowsum != nullptr && bx == 0;
+    float cs[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const long k_hi = (k_lo + kslab < K) ? k_lo + kslab : K;
     // 16-byte vector loads only when every row start is 16-byte aligned
     const bool va = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda % 4 == 0);
@@ -109,11 +123,19 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(int M, int N, int K, cons
     Stage st;
     stage_load<TA>(st, tid, m0, n0, k_lo, k_hi, M, N, A, lda, B, ldb, va, vb);
     stage_store<TA>(st, tid, As[0], Bs[0]);
+    if (do_sum)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cs[i] += st.a[i];
     __syncthreads();
     int cur = 0;
     for (long k0 = k_lo; k0 < k_hi; k0 += GK) {
         const bool more = k0 + GK < k_hi;
-        if (more) stage_load<TA>(st, tid, m0, n0, k0 + GK, k_hi, M, N, A, lda, B, ldb, va, vb);
+        if (more) {
+            stage_load<TA>(st, tid, m0, n0, k0 + GK, k_hi, M, N, A, lda, B, ldb, va, vb);
+            if (do_sum)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) cs[i] += st.a[i];
+        }
 #pragma unroll
         for (int s = 0; s < GK / 4; ++s) {
             float a[4], b[4];
@@ -147,21 +169,18 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(int M, int N, int K, cons
                     else atomicAdd(dst, v);
                 }
             }
-}
-
-// db[n] += sum_m Y[m*ld + n]
-__global__ void __launch_bounds__(256) colsum_kernel(long M, int N, const float *__restrict__ Y, long ld, float *__restrict__ out, int rows_per_block)
-{
-    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sub = threadIdx.x >> 6;
-    const long m_lo = (long)blockIdx.y * rows_per_block, m_hi = (m_lo + rows_per_block < M) ? m_lo + rows_per_block : M;
-    float s = 0.0f;
-    if (n < N)
-        for (long m = m_lo + sub; m < m_hi; m += 4) s += Y[m * ld + n];
-    __shared__ float red[4][64];
-    red[sub][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (sub == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (do_sum) {   // the K loop ended on a barrier: the LDS tiles are free.  Thread (kk, mm) holds the sums of its 8 m over k = kk mod 16.
+        const int kk = tid >> 4, mm = (tid & 15) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) As[0][kk][mm + i] = cs[i];
+        __syncthreads();
+        if (tid < GT && m0 + tid < M) {
+            float t = 0.0f;
+#pragma unroll
+            for (int k = 0; k < GK; ++k) t += As[0][k][tid];
+            atomicAdd(rowsum + m0 + tid, t);
+        }
+    }
 }
 
 // dst[m*ldd + n] (op)= src[m*lds + n] for n < N   (mode 0 copy, 1 add)
@@ -202,52 +221,94 @@ __device__ __forceinline__ void pe_grad(const float *enc, const float *denc, flo
     }
 }
 
-// Per sample: d_in [P x 96] = gradient wrt [PE63(x') pad 64 | PE18(w) pad 32]; d_gridf [P x 32].
-// Outputs: d_xw [P x 4] = dL/dx' (PE part + trilinear part), d_w [P x 4] = dL/dw; scatter-adds d_grid (channel-first, as in
-// the flat parameter buffer).  Trilinear derivative as ATen's grid_sampler_3d backward (align_corners=True, zeros padding).
-__global__ void __launch_bounds__(256) encode_grid_backward_kernel(long P, const float *__restrict__ actbuf, const float *__restrict__ d_in,
-                                                                   const float *__restrict__ d_gridf, const float *__restrict__ grid_cf,
-                                                                   float *__restrict__ d_grid_cf, float *__restrict__ d_xw,
-                                                                   float *__restrict__ d_w)
+// Per sample: d_in [P x 96] = gradient wrt [PE63(x') pad 64 | PE18(w) pad 32].  d_xw [P x 4] += dL/dx' through PE63 (the trilinear
+// part was written by grid_backward_kernel), d_w [P x 4] = dL/dw.
+__global__ void __launch_bounds__(256) encode_backward_kernel(long P, const float *__restrict__ actbuf, const float *__restrict__ d_in,
+                                                              float *__restrict__ d_xw, float *__restrict__ d_w)
 {
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
         const float *a = actbuf + p * (long)act::STRIDE;
         float gx[3], gw[2];
         pe_grad<3, 10>(a + act::PEX, d_in + p * 96, gx);
         pe_grad<2, 4>(a + act::PEW, d_in + p * 96 + 64, gw);
-        // trilinear
-        const float x = a[act::XW], y = a[act::XW + 1], z = a[act::XW + 2];
+        f32x4 t = *reinterpret_cast<const f32x4 *>(d_xw + p * 4);
+        t[0] += gx[0]; t[1] += gx[1]; t[2] += gx[2];
+        *reinterpret_cast<f32x4 *>(d_xw + p * 4) = t;
+        *reinterpret_cast<f32x4 *>(d_w + p * 4) = f32x4{gw[0], gw[1], 0.0f, 0.0f};
+    }
+}
+
+// Trilinear feature-grid backward (ATen grid_sampler_3d backward, align_corners=True, zeros padding; models.py:346-365).
+// Half a wave per sample, lane = channel: the 32 channel gradients of one corner are one 128-byte atomic burst into the
+// CHANNEL-LAST accumulator d_grid_cl [voxel][32] (transposed into the channel-first parameter gradient afterwards); the
+// coordinate gradient is the 32-lane reduction of dg * grid.  Writes d_xw[p][0:3] = trilinear part, [3] = 0.
+__global__ void __launch_bounds__(256) grid_backward_kernel(long P, const float *__restrict__ actbuf, const float *__restrict__ d_gridf,
+                                                            const float *__restrict__ grid_cl, float *__restrict__ d_grid_cl,
+                                                            float *__restrict__ d_xw)
+{
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long p2 = wave * 2; p2 < P; p2 += nwaves * 2) {
+        const long p = p2 + h;
+        const bool live = p < P;
+        const long pc = live ? p : P - 1;
+        const float *a = actbuf + pc * (long)act::STRIDE + act::XW;
+        const float x = a[0], y = a[1], z = a[2];
         const float R1 = (float)(G_RES - 1);
         const float ix = ((x + 1.0f) / 2.0f) * R1, iy = ((y + 1.0f) / 2.0f) * R1, iz = ((z + 1.0f) / 2.0f) * R1;
         const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-        const float wx[2] = {(fx + 1.0f) - ix, ix - fx}, wy[2] = {(fy + 1.0f) - iy, iy - fy}, wz[2] = {(fz + 1.0f) - iz, iz - fz};
+        const float wx0 = (fx + 1.0f) - ix, wx1 = ix - fx, wy0 = (fy + 1.0f) - iy, wy1 = iy - fy, wz0 = (fz + 1.0f) - iz, wz1 = iz - fz;
         const bool ok = fx >= -1.0f && fx <= (float)G_RES && fy >= -1.0f && fy <= (float)G_RES && fz >= -1.0f && fz <= (float)G_RES;
         const int xi = ok ? (int)fx : -2, yi = ok ? (int)fy : -2, zi = ok ? (int)fz : -2;
-        const long vox = (long)G_RES * G_RES * G_RES;
+        const float g = live ? d_gridf[pc * 32 + c] : 0.0f;
         float gix = 0.0f, giy = 0.0f, giz = 0.0f;
-        const float *dg = d_gridf + p * 32;
+#pragma unroll
         for (int n = 0; n < 8; ++n) {
             const int bx = n & 1, by = (n >> 1) & 1, bz = n >> 2;
             const int cx = xi + bx, cy = yi + by, cz = zi + bz;
-            if (cx < 0 || cx >= G_RES || cy < 0 || cy >= G_RES || cz < 0 || cz >= G_RES) continue;
-            const long v = ((long)cz * G_RES + cy) * G_RES + cx;
-            const float wt = (wx[bx] * wy[by]) * wz[bz];
-            float dot = 0.0f;
-            for (int c = 0; c < D_GRID; ++c) {
-                const float g = dg[c];
-                atomicAdd(d_grid_cf + (long)c * vox + v, g * wt);
-                dot += g * grid_cf[(long)c * vox + v];
+            const bool in = live && cx >= 0 && cx < G_RES && cy >= 0 && cy < G_RES && cz >= 0 && cz < G_RES;
+            if (in) {
+                const long v = (((long)cz * G_RES + cy) * G_RES + cx) * D_GRID + c;
+                const float wxb = bx ? wx1 : wx0, wyb = by ? wy1 : wy0, wzb = bz ? wz1 : wz0;
+                atomicAdd(d_grid_cl + v, g * ((wxb * wyb) * wzb));
+                const float t = g * grid_cl[v];
+                gix += t * (bx ? 1.0f : -1.0f) * wyb * wzb;
+                giy += t * (by ? 1.0f : -1.0f) * wxb * wzb;
+                giz += t * (bz ? 1.0f : -1.0f) * wxb * wyb;
             }
-            gix += dot * (bx ? 1.0f : -1.0f) * wy[by] * wz[bz];
-            giy += dot * (by ? 1.0f : -1.0f) * wx[bx] * wz[bz];
-            giz += dot * (bz ? 1.0f : -1.0f) * wx[bx] * wy[by];
         }
-        const float sc = R1 / 2.0f;
-        d_xw[p * 4 + 0] = gx[0] + gix * sc;
-        d_xw[p * 4 + 1] = gx[1] + giy * sc;
-        d_xw[p * 4 + 2] = gx[2] + giz * sc;
-        d_xw[p * 4 + 3] = 0.0f;
-        d_w[p * 4 + 0] = gw[0]; d_w[p * 4 + 1] = gw[1]; d_w[p * 4 + 2] = 0.0f; d_w[p * 4 + 3] = 0.0f;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+            gix += __shfl_xor(gix, off, 64);
+            giy += __shfl_xor(giy, off, 64);
+            giz += __shfl_xor(giz, off, 64);
+        }
+        if (live && c == 0) {
+            const float sc = R1 / 2.0f;
+            *reinterpret_cast<f32x4 *>(d_xw + p * 4) = f32x4{gix * sc, giy * sc, giz * sc, 0.0f};
+        }
+    }
+}
+
+// channel-first [32][vox] <-> channel-last [vox][32] (mode 0: dst_cl = src_cf;  mode 1: dst_cf += src_cl)
+__global__ void __launch_bounds__(256) grid_transpose_kernel(const float *__restrict__ src, float *__restrict__ dst, int mode)
+{
+    __shared__ float t[32][33];
+    const long vox = (long)G_RES * G_RES * G_RES;
+    const long v0 = (long)blockIdx.x * 32;
+    const int i = threadIdx.x & 31, j = threadIdx.x >> 5;   // 8 rows per pass
+    if (mode == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int ch = j + 8 * r; t[ch][i] = src[(long)ch * vox + v0 + i]; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int vv = j + 8 * r; dst[(v0 + vv) * 32 + i] = t[i][vv]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int vv = j + 8 * r; t[vv][i] = src[(v0 + vv) * 32 + i]; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int ch = j + 8 * r; dst[(long)ch * vox + v0 + i] += t[i][ch]; }
     }
 }
 
@@ -301,23 +362,21 @@ struct Bwd {
     void nn(const float *dY, long ldy, int K, const float *W, long ldw, int N, float *dX, long ldx, int mode, const float *mask = nullptr,
             long ldm = 0, float slope = 0.0f)
     {
-        dim3 g((N + GT - 1) / GT, (unsigned)((P + GT - 1) / GT), 1);
-        gemm_f32_kernel<false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K);
+        const int nbn = (N + GT - 1) / GT;
+        const long nbm = (P + GT - 1) / GT;
+        dim3 g((unsigned)(((nbm + 7) / 8) * 8 * nbn), 1, 1);
+        gemm_f32_kernel<false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn);
         check();
     }
-    // dW[M x N] += dY[P x M]^T * X[P x N]
-    void tn(const float *dY, long ldy, int M, const float *X, long ldx, int N, float *dW, long ldw)
+    // dW[M x N] += dY[P x M]^T * X[P x N];  db != null: db[M] += column sums of dY (fused: the dY tiles are staged anyway).
+    // The sample dimension is cut into slabs so that every launch has ~6 workgroups per CU whatever the layer width.
+    void tn(const float *dY, long ldy, int M, const float *X, long ldx, int N, float *dW, long ldw, float *db = nullptr)
     {
-        const int kslab = 4096;
+        const int tiles = ((N + GT - 1) / GT) * ((M + GT - 1) / GT);
+        long kslab = (P * tiles / 1536 + 15) / 16 * 16;
+        kslab = kslab < 256 ? 256 : (kslab > 8192 ? 8192 : kslab);
         dim3 g((N + GT - 1) / GT, (M + GT - 1) / GT, (unsigned)((P + kslab - 1) / kslab));
-        gemm_f32_kernel<true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, kslab);
-        check();
-    }
-    void colsum(const float *dY, long ldy, int N, float *db)
-    {
-        const int rows = 2048;
-        dim3 g((N + 63) / 64, (unsigned)((P + rows - 1) / rows));
-        colsum_kernel<<<g, 256, 0, st>>>(P, N, dY, ldy, db, rows);
+        gemm_f32_kernel<true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0);
         check();
     }
     void copy(const float *src, long lds_, int N, float *dst, long ldd, int mode)
@@ -329,9 +388,10 @@ struct Bwd {
 
 }  // namespace
 
-// Words of workspace per call: gA, gB, dfeat (P x 256 each), din (P x 96), dgridf (P x 32), dxw, dw, g3 (P x 4 each), db (BIAS_FLOATS)
+// Words of workspace per call: gA, gB, dfeat (P x 256 each), din (P x 96), dgridf (P x 32), dxw, dw, g3 (P x 4 each), db scratch,
+// channel-last copies of the feature grid and of its gradient accumulator
 constexpr int DB_SCRATCH = 8192;   // per-call bias-gradient scratch (all layers of one level: ~5.3 K floats)
-extern "C" long sahs_field_backward_ws_words(long P) { return P * (256L * 3 + 96 + 32 + 12) + DB_SCRATCH; }
+extern "C" long sahs_field_backward_ws_words(long P) { return P * (256L * 3 + 96 + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS; }
 
 // grad_cond: [0:76] d_driving, [80:116] d_pose36 (accumulated).  grad_flat: accumulated.  d_raw: (P,16).
 extern "C" int sahs_field_backward_launch(const float *flat, const float *frame, int level, long P, const float *actbuf, const float *d_raw,
@@ -343,10 +403,10 @@ extern "C" int sahs_field_backward_launch(const float *flat, const float *frame,
     const FlatOffsets &F = kFlat;
     const FlatOffsets::Lvl &Lv = F.lvl[level];
     float *gA = ws, *gB = gA + P * 256, *dfeat = gB + P * 256, *din = dfeat + P * 256, *dgridf = din + P * 96, *dxw = dgridf + P * 32,
-          *dw = dxw + P * 4, *g3 = dw + P * 4, *db = g3 + P * 4;
+          *dw = dxw + P * 4, *g3 = dw + P * 4, *db = g3 + P * 4, *grid_cl = db + DB_SCRATCH, *dgrid_cl = grid_cl + GRID_FLOATS;
     const long AS = act::STRIDE;
-    hipMemsetAsync(db, 0, sizeof(float) * DB_SCRATCH, stream);
-    hipMemsetAsync(din, 0, sizeof(float) * P * 96, stream);
+    if (hipMemsetAsync(db, 0, sizeof(float) * DB_SCRATCH, stream) != hipSuccess) return (int)hipGetLastError();
+    if (hipMemsetAsync(dgrid_cl, 0, sizeof(float) * GRID_FLOATS, stream) != hipSuccess) return (int)hipGetLastError();
     const float *drv = frame + FRAME_DRV_OFF, *p36 = frame + FRAME_POSE_OFF;
     float *d_drv = grad_cond + 0, *d_p36 = grad_cond + 80;
     auto W = [&](long off) { return flat + off; };
@@ -371,43 +431,43 @@ extern "C" int sahs_field_backward_launch(const float *flat, const float *frame,
     {
         const float *dseg = d_raw + 3;   // (P,12), ld 16
         float *dbl = newdb(N_SEG);
-        b.tn(dseg, 16, N_SEG, A + act::S + 384, AS, BR_H, G(Lv.segout_w), BR_H);
-        b.colsum(dseg, 16, N_SEG, dbl); add_bias(dbl, Lv.segout_b, N_SEG);
+        b.tn(dseg, 16, N_SEG, A + act::S + 384, AS, BR_H, G(Lv.segout_w), BR_H, dbl);
+        add_bias(dbl, Lv.segout_b, N_SEG);
         b.nn(dseg, 16, N_SEG, W(Lv.segout_w), BR_H, BR_H, gA, 256, 0, A + act::S + 384, AS, 0.01f);
         float *cur = gA, *nxt = gB;
         for (int i = 3; i >= 1; --i) {   // layers_seg[i]: s_{i-1} (128) -> s_i
             float *d = newdb(BR_H);
-            b.tn(cur, 256, BR_H, A + act::S + 128 * (i - 1), AS, BR_H, G(Lv.seg_w[i]), BR_H);
-            b.colsum(cur, 256, BR_H, d); add_bias(d, Lv.seg_b[i], BR_H);
+            b.tn(cur, 256, BR_H, A + act::S + 128 * (i - 1), AS, BR_H, G(Lv.seg_w[i]), BR_H, d);
+            add_bias(d, Lv.seg_b[i], BR_H);
             b.nn(cur, 256, BR_H, W(Lv.seg_w[i]), BR_H, BR_H, nxt, 256, 0, A + act::S + 128 * (i - 1), AS, 0.01f);
             float *t = cur; cur = nxt; nxt = t;
         }
         float *d = newdb(BR_H);   // layers_seg[0]: feat (256) -> s0
-        b.tn(cur, 256, BR_H, A + act::FEAT, AS, TR_H, G(Lv.seg_w[0]), TR_H);
-        b.colsum(cur, 256, BR_H, d); add_bias(d, Lv.seg_b[0], BR_H);
+        b.tn(cur, 256, BR_H, A + act::FEAT, AS, TR_H, G(Lv.seg_w[0]), TR_H, d);
+        add_bias(d, Lv.seg_b[0], BR_H);
         b.nn(cur, 256, BR_H, W(Lv.seg_w[0]), TR_H, TR_H, dfeat, 256, 0);       // feat has no activation
     }
     // ================= colour branch (modules.py:276-287) =================
     {
         const float *drgb = d_raw;   // (P,3), ld 16
         float *dbl = newdb(4);
-        b.tn(drgb, 16, 3, A + act::C + 384, AS, BR_H, G(Lv.rgb_w), BR_H);
-        b.colsum(drgb, 16, 3, dbl); add_bias(dbl, Lv.rgb_b, 3);
+        b.tn(drgb, 16, 3, A + act::C + 384, AS, BR_H, G(Lv.rgb_w), BR_H, dbl);
+        add_bias(dbl, Lv.rgb_b, 3);
         b.nn(drgb, 16, 3, W(Lv.rgb_w), BR_H, BR_H, gA, 256, 0, A + act::C + 384, AS, 0.01f);
         float *cur = gA, *nxt = gB;
         for (int i = 3; i >= 1; --i) {
             float *d = newdb(BR_H);
-            b.tn(cur, 256, BR_H, A + act::C + 128 * (i - 1), AS, BR_H, G(Lv.dir_w[i]), BR_H);
-            b.colsum(cur, 256, BR_H, d); add_bias(d, Lv.dir_b[i], BR_H);
+            b.tn(cur, 256, BR_H, A + act::C + 128 * (i - 1), AS, BR_H, G(Lv.dir_w[i]), BR_H, d);
+            add_bias(d, Lv.dir_b[i], BR_H);
             b.nn(cur, 256, BR_H, W(Lv.dir_w[i]), BR_H, BR_H, nxt, 256, 0, A + act::C + 128 * (i - 1), AS, 0.01f);
             float *t = cur; cur = nxt; nxt = t;
         }
         // layers_dir[0]: [feat256 | dirPE27 | grid32] -> c0
         float *d = newdb(BR_H);
-        b.tn(cur, 256, BR_H, A + act::FEAT, AS, TR_H, G(Lv.dir_w[0]), D_DIR_IN);
+        b.tn(cur, 256, BR_H, A + act::FEAT, AS, TR_H, G(Lv.dir_w[0]), D_DIR_IN, d);
         b.tn(cur, 256, BR_H, A + act::DIR, AS, D_DIR, G(Lv.dir_w[0]) + TR_H, D_DIR_IN);
         b.tn(cur, 256, BR_H, A + act::GRID, AS, D_GRID, G(Lv.dir_w[0]) + TR_H + D_DIR, D_DIR_IN);
-        b.colsum(cur, 256, BR_H, d); add_bias(d, Lv.dir_b[0], BR_H);
+        add_bias(d, Lv.dir_b[0], BR_H);
         b.nn(cur, 256, BR_H, W(Lv.dir_w[0]), D_DIR_IN, TR_H, dfeat, 256, 1);
         b.nn(cur, 256, BR_H, W(Lv.dir_w[0]) + TR_H + D_DIR, D_DIR_IN, D_GRID, dgridf, 32, 0);
     }
@@ -415,57 +475,63 @@ extern "C" int sahs_field_backward_launch(const float *flat, const float *frame,
     {
         const float *dsig = d_raw + 15;  // (P,1), ld 16
         float *dbl = newdb(4);
-        b.tn(dsig, 16, 1, A + act::FEAT, AS, TR_H, G(Lv.alpha_w), TR_H);
-        b.colsum(dsig, 16, 1, dbl); add_bias(dbl, Lv.alpha_b, 1);
+        b.tn(dsig, 16, 1, A + act::FEAT, AS, TR_H, G(Lv.alpha_w), TR_H, dbl);
+        add_bias(dbl, Lv.alpha_b, 1);
         rank1_add_kernel<<<2048, 256, 0, stream>>>(P, TR_H, dsig, 16, W(Lv.alpha_w), dfeat, 256); b.check();
     }
     // ================= trunk (modules.py:267-274) =================
     {
         // feat = fc_feat(t7)
         float *d = newdb(TR_H);
-        b.tn(dfeat, 256, TR_H, A + act::T + 7 * 256, AS, TR_H, G(Lv.feat_w), TR_H);
-        b.colsum(dfeat, 256, TR_H, d); add_bias(d, Lv.feat_b, TR_H);
+        b.tn(dfeat, 256, TR_H, A + act::T + 7 * 256, AS, TR_H, G(Lv.feat_w), TR_H, d);
+        add_bias(d, Lv.feat_b, TR_H);
         b.nn(dfeat, 256, TR_H, W(Lv.feat_w), TR_H, TR_H, gA, 256, 0, A + act::T + 7 * 256, AS, 0.01f);
         float *cur = gA, *nxt = gB;
         for (int i = 7; i >= 1; --i) {   // layers_xyz[i]: input t_{i-1} (and, for i == 3, [PE(x') | PE(w) | pose36])
             float *dl = newdb(TR_H);
             const long ldw = (i == 3) ? TR_H + D_TR_IN : TR_H;
-            b.tn(cur, 256, TR_H, A + act::T + (i - 1) * 256, AS, TR_H, G(Lv.xyz_w[i]), ldw);
-            b.colsum(cur, 256, TR_H, dl); add_bias(dl, Lv.xyz_b[i], TR_H);
+            b.tn(cur, 256, TR_H, A + act::T + (i - 1) * 256, AS, TR_H, G(Lv.xyz_w[i]), ldw, dl);
+            add_bias(dl, Lv.xyz_b[i], TR_H);
             if (i == 3) {
                 b.tn(cur, 256, TR_H, A + act::PEX, AS, D_XYZ, G(Lv.xyz_w[3]) + TR_H, ldw);
                 b.tn(cur, 256, TR_H, A + act::PEW, AS, D_AMB, G(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw);
                 consts(Lv.xyz_w[3], ldw, TR_H, TR_H + D_XYZ + D_AMB, D_POSE, dl, p36, d_p36);
-                b.nn(cur, 256, TR_H, W(Lv.xyz_w[3]) + TR_H, ldw, D_XYZ, din, 96, 1);
-                b.nn(cur, 256, TR_H, W(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw, D_AMB, din + 64, 96, 1);
+                b.nn(cur, 256, TR_H, W(Lv.xyz_w[3]) + TR_H, ldw, D_XYZ, din, 96, 0);        // first writer of din stores,
+                b.nn(cur, 256, TR_H, W(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw, D_AMB, din + 64, 96, 0);   // layers_xyz[0] below accumulates
             }
             b.nn(cur, 256, TR_H, W(Lv.xyz_w[i]), ldw, TR_H, nxt, 256, 0, A + act::T + (i - 1) * 256, AS, 0.01f);
             float *t = cur; cur = nxt; nxt = t;
         }
         // layers_xyz[0]: [PE63(x') | PE18(w) | pose36] -> t0
         float *dl = newdb(TR_H);
-        b.tn(cur, 256, TR_H, A + act::PEX, AS, D_XYZ, G(Lv.xyz_w[0]), D_TR_IN);
+        b.tn(cur, 256, TR_H, A + act::PEX, AS, D_XYZ, G(Lv.xyz_w[0]), D_TR_IN, dl);
         b.tn(cur, 256, TR_H, A + act::PEW, AS, D_AMB, G(Lv.xyz_w[0]) + D_XYZ, D_TR_IN);
-        b.colsum(cur, 256, TR_H, dl); add_bias(dl, Lv.xyz_b[0], TR_H);
+        add_bias(dl, Lv.xyz_b[0], TR_H);
         consts(Lv.xyz_w[0], D_TR_IN, TR_H, D_XYZ + D_AMB, D_POSE, dl, p36, d_p36);
         b.nn(cur, 256, TR_H, W(Lv.xyz_w[0]), D_TR_IN, D_XYZ, din, 96, 1);
         b.nn(cur, 256, TR_H, W(Lv.xyz_w[0]) + D_XYZ, D_TR_IN, D_AMB, din + 64, 96, 1);
     }
     // ================= encodings + feature grid -> d x', d w =================
-    encode_grid_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, din, dgridf, W(F.grid), G(F.grid), dxw, dw);
-    b.check();
+    {
+        const int tb = (int)(GRID_FLOATS / 32 / 32);   // 32 voxels x 32 channels per block
+        grid_transpose_kernel<<<tb, 256, 0, stream>>>(W(F.grid), grid_cl, 0); b.check();
+        const long gb = (P + 7) / 8;                    // 4 waves x 2 samples per block pass
+        grid_backward_kernel<<<(unsigned)(gb < 8192 ? gb : 8192), 256, 0, stream>>>(P, actbuf, dgridf, grid_cl, dgrid_cl, dxw); b.check();
+        grid_transpose_kernel<<<tb, 256, 0, stream>>>(dgrid_cl, G(F.grid), 1); b.check();
+        encode_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, din, dxw, dw); b.check();
+    }
     // ================= hyper sheet (modules.py:444-462): w = fc_ambient(g5) =================
     {
         float *dbl = newdb(4);
-        b.tn(dw, 4, 2, A + act::HH + 5 * 64, AS, HYP_H, G(F.hyp_fw), HYP_H);
-        b.colsum(dw, 4, 2, dbl); add_bias(dbl, F.hyp_fb, 2);
+        b.tn(dw, 4, 2, A + act::HH + 5 * 64, AS, HYP_H, G(F.hyp_fw), HYP_H, dbl);
+        add_bias(dbl, F.hyp_fb, 2);
         b.nn(dw, 4, 2, W(F.hyp_fw), HYP_H, HYP_H, gA, 256, 0, A + act::HH + 5 * 64, AS, 0.0f);
         float *cur = gA, *nxt = gB;
         for (int i = 5; i >= 1; --i) {
             float *dl = newdb(HYP_H);
             const long ldw = (i == 4) ? HYP_H + D_DEF_IN : HYP_H;
-            b.tn(cur, 256, HYP_H, A + act::HH + (i - 1) * 64, AS, HYP_H, G(F.hyp_w[i]), ldw);
-            b.colsum(cur, 256, HYP_H, dl); add_bias(dl, F.hyp_b[i], HYP_H);
+            b.tn(cur, 256, HYP_H, A + act::HH + (i - 1) * 64, AS, HYP_H, G(F.hyp_w[i]), ldw, dl);
+            add_bias(dl, F.hyp_b[i], HYP_H);
             if (i == 4) {
                 b.tn(cur, 256, HYP_H, A + act::E, AS, D_XYZ, G(F.hyp_w[4]) + HYP_H, ldw);
                 consts(F.hyp_w[4], ldw, HYP_H, HYP_H + D_XYZ, D_DRV, dl, drv, d_drv);
@@ -475,8 +541,8 @@ extern "C" int sahs_field_backward_launch(const float *flat, const float *frame,
             float *t = cur; cur = nxt; nxt = t;
         }
         float *dl = newdb(HYP_H);
-        b.tn(cur, 256, HYP_H, A + act::E, AS, D_XYZ, G(F.hyp_w[0]), D_DEF_IN);
-        b.colsum(cur, 256, HYP_H, dl); add_bias(dl, F.hyp_b[0], HYP_H);
+        b.tn(cur, 256, HYP_H, A + act::E, AS, D_XYZ, G(F.hyp_w[0]), D_DEF_IN, dl);
+        add_bias(dl, F.hyp_b[0], HYP_H);
         consts(F.hyp_w[0], D_DEF_IN, HYP_H, D_XYZ, D_DRV, dl, drv, d_drv);
         consts(F.hyp_w[0], D_DEF_IN, HYP_H, D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);
     }
@@ -484,15 +550,15 @@ extern "C" int sahs_field_backward_launch(const float *flat, const float *frame,
     {
         tanh_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, dxw, g3); b.check();
         float *dbl = newdb(4);
-        b.tn(g3, 4, 3, A + act::WH + 5 * 128, AS, WARP_H, G(F.warp_fw), WARP_H);
-        b.colsum(g3, 4, 3, dbl); add_bias(dbl, F.warp_fb, 3);
+        b.tn(g3, 4, 3, A + act::WH + 5 * 128, AS, WARP_H, G(F.warp_fw), WARP_H, dbl);
+        add_bias(dbl, F.warp_fb, 3);
         b.nn(g3, 4, 3, W(F.warp_fw), WARP_H, WARP_H, gA, 256, 0, A + act::WH + 5 * 128, AS, 0.0f);
         float *cur = gA, *nxt = gB;
         for (int i = 5; i >= 1; --i) {
             float *dl = newdb(WARP_H);
             const long ldw = (i == 4) ? WARP_H + D_DEF_IN : WARP_H;
-            b.tn(cur, 256, WARP_H, A + act::WH + (i - 1) * 128, AS, WARP_H, G(F.warp_w[i]), ldw);
-            b.colsum(cur, 256, WARP_H, dl); add_bias(dl, F.warp_b[i], WARP_H);
+            b.tn(cur, 256, WARP_H, A + act::WH + (i - 1) * 128, AS, WARP_H, G(F.warp_w[i]), ldw, dl);
+            add_bias(dl, F.warp_b[i], WARP_H);
             if (i == 4) {
                 b.tn(cur, 256, WARP_H, A + act::E, AS, D_XYZ, G(F.warp_w[4]) + WARP_H, ldw);
                 consts(F.warp_w[4], ldw, WARP_H, WARP_H + D_XYZ, D_DRV, dl, drv, d_drv);
@@ -502,8 +568,8 @@ extern "C" int sahs_field_backward_launch(const float *flat, const float *frame,
             float *t = cur; cur = nxt; nxt = t;
         }
         float *dl = newdb(WARP_H);
-        b.tn(cur, 256, WARP_H, A + act::E, AS, D_XYZ, G(F.warp_w[0]), D_DEF_IN);
-        b.colsum(cur, 256, WARP_H, dl); add_bias(dl, F.warp_b[0], WARP_H);
+        b.tn(cur, 256, WARP_H, A + act::E, AS, D_XYZ, G(F.warp_w[0]), D_DEF_IN, dl);
+        add_bias(dl, F.warp_b[0], WARP_H);
         consts(F.warp_w[0], D_DEF_IN, WARP_H, D_XYZ, D_DRV, dl, drv, d_drv);
         consts(F.warp_w[0], D_DEF_IN, WARP_H, D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);
     }

@@ -207,27 +207,40 @@ class RenderRaysFn(torch.autograd.Function):
     """predict_and_render_radiance (train_utils.py:72-206) for one ray chunk, differentiable w.r.t. the model
     parameters (as the canonical flat buffer) and the audio window.
 
-    forward: the six forward launches (sahs_render_rays).  backward: per level -- re-run the field with activation
-    saving, composite backward, field backward -- then the conditioning backward; rays are processed in blocks so the
-    saved activations (19 KB per sample) stay bounded."""
+    forward: the six forward launches; chunks of at most BLOCK_RAYS rays (a training batch) keep the field activations of
+    both passes (19 KB per sample, 7.5 GB for 2048 rays x 192 samples), larger chunks only keep the depths and re-run the field
+    block by block in backward.  backward: per level -- composite backward, field backward -- then the conditioning backward."""
 
     BLOCK_RAYS = 4096
 
     @staticmethod
     def forward(ctx, flat, audio, pose, rays, bg, t_rand, noise_c, u, noise_f, packed, num_coarse, num_fine, lindisp, white_background):
         frame = fold_conditioning(flat.detach(), audio.detach(), pose)
+        none = torch.empty(0, device=rays.device)
+        ctx.cfg = (num_coarse, num_fine, bool(white_background), bg is not None, noise_c is not None, noise_f is not None)
+        ctx.kept = rays.shape[0] <= RenderRaysFn.BLOCK_RAYS and num_fine > 0
+        if ctx.kept:     # the same launch chain as sahs_render_rays, with the field activations kept
+            z_c = stratified_depths(rays, num_coarse, lindisp, t_rand)
+            raw_c, act_c = field_forward_save(packed, frame, 0, rays, z_c)
+            rgb_c, disp_c, acc_c, w_c, _ = composite_forward(raw_c, z_c, rays, noise_c, bg, white_background)
+            z_f = resample(z_c, w_c, num_fine, u)
+            raw_f, act_f = field_forward_save(packed, frame, 1, rays, z_f)
+            rgb_f, disp_f, acc_f, w_f, depth_f = composite_forward(raw_f, z_f, rays, noise_f, bg, white_background)
+            outs = (rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_f[:, -1].contiguous(), depth_f)
+            ctx.save_for_backward(flat.detach(), audio.detach(), rays, z_c, z_f, frame, packed,
+                                  *[t if t is not None else none for t in (bg, noise_c, noise_f)], raw_c, act_c, raw_f, act_f)
+            return outs
         ws = {}
         outs = render_rays(packed, frame, rays, num_coarse, num_fine, precision=SAHS_F32, lindisp=lindisp, white_background=white_background,
                            bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f, workspace=ws)
-        ctx.save_for_backward(flat.detach(), audio.detach(), rays, ws["z_c"].clone(), ws["z_f"].clone(), frame, packed,
-                              *[t if t is not None else torch.empty(0, device=rays.device) for t in (bg, noise_c, noise_f)])
-        ctx.cfg = (num_coarse, num_fine, bool(white_background), bg is not None, noise_c is not None, noise_f is not None)
-        ctx.mark_non_differentiable(outs[6]) if False else None
+        ctx.save_for_backward(flat.detach(), audio.detach(), rays, ws["z_c"].clone(), ws["z_f"].clone() if num_fine > 0 else none, frame, packed,
+                              *[t if t is not None else none for t in (bg, noise_c, noise_f)])
         return outs
 
     @staticmethod
     def backward(ctx, g_rgb_c, g_disp_c, g_acc_c, g_rgb_f, g_disp_f, g_acc_f, g_wbg, g_depth_f):
-        flat, audio, rays, z_c, z_f, frame, packed, bg, noise_c, noise_f = ctx.saved_tensors
+        flat, audio, rays, z_c, z_f, frame, packed, bg, noise_c, noise_f = ctx.saved_tensors[:10]
+        kept = dict(zip((0, 1), (ctx.saved_tensors[10:12], ctx.saved_tensors[12:14]))) if ctx.kept else None
         nc, nf, white, has_bg, has_nc, has_nf = ctx.cfg
         bg = bg if has_bg else None
         noise_c = noise_c if has_nc else None
@@ -248,7 +261,7 @@ class RenderRaysFn(torch.autograd.Function):
                 if all(g is None for g in grads):
                     continue
                 zb = z[sl].contiguous()
-                raw, act = field_forward_save(packed, frame, level, rb, zb)
+                raw, act = kept[level] if kept is not None else field_forward_save(packed, frame, level, rb, zb)
                 nb = None if noise is None else noise[sl].contiguous()
                 gb = [None if g is None else c(g[sl]) for g in grads]
                 d_raw = composite_backward(raw, zb, rb, nb, bgb, white, *gb)
