@@ -183,6 +183,158 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(int M, int N, int K, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same two GEMMs with the operand tiles moved global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPR
+// staging, no ds_write), three K-steps deep: while step t is multiplied, steps t+1 and t+2 are in flight.  One raw
+// s_barrier per K-step; the wait before it is a counted vmcnt (4 = the wave's DMA instructions of the one newer step).
+// Needs 16-byte aligned operand rows (A, B, lda, ldb multiples of 4 floats) -- the host routes everything else to
+// gemm_f32_kernel above.  Out-of-range rows/columns are fetched from a 16-byte zero page.
+//   TA : A'(m,k) = A[k*lda + m]  tile [16 k][128 m]          B(k,n) = B[k*ldb + n]  tile [16 k][128 n]
+//   !TA: A'(m,k) = A[m*lda + k]  tile [128 m][16 k] (one ds_read_b128 = 4 k of one row; the MFMA k index is
+//        permuted -- lane q takes k = 4q + r at MFMA r -- identically for both operands, so the sum is unchanged)
+// K-major tiles are XOR-swizzled by 16 floats on alternate rows (TA: k&1, !TA: (k>>2)&1 -- either way q&1 on the MFMA
+// side), so the four q groups of a ds_read_b32 hit two disjoint bank sets.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void *lds_void_t;
+typedef const __attribute__((address_space(1))) void *gbl_void_t;
+constexpr int DST = 3;                        // ring depth
+constexpr int DTILE = GK * GT;                // floats per operand tile (8 KB)
+
+template <bool TA>
+__global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, const float *__restrict__ A, long lda,
+                                                       const float *__restrict__ B, long ldb, float *__restrict__ C, long ldc, int mode,
+                                                       const float *__restrict__ mask, long ldm, float slope, int kslab,
+                                                       float *__restrict__ rowsum, int nbn, const float *__restrict__ zero)
+{
+    __shared__ __attribute__((aligned(16))) float smem[DST][2][DTILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c16 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (nbn > 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        bx = slot % nbn;
+        by = (slot / nbn) * 8 + xcd;
+        if ((long)by * GT >= M) return;
+    }
+    const long m0 = (long)by * GT;
+    const int n0 = bx * GT;
+    const long k_lo = (long)blockIdx.z * kslab;
+    const long k_hi = (k_lo + kslab < K) ? k_lo + kslab : K;
+    const int T = (int)((k_hi - k_lo + GK - 1) / GK);
+    const bool do_sum = TA && rowsum != nullptr && bx == 0;
+
+    // ---- this wave's four DMA instructions per K-step: waves 0,1 move the A tile, waves 2,3 the B tile ----
+    const int h = lane >> 5, c32 = lane & 31;
+    const float *src[4]; long step[4]; int krow[4]; bool colok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int rp = (wave & 1) * 4 + u;                 // 0..7: which 1-KB eighth of the tile
+        if (wave < 2 && !TA) {                               // A, row-major [128 m][16 k]: 4 chunks per row
+            const int chunk = rp * 64 + lane, m = chunk >> 2, kc = chunk & 3;
+            src[u] = A + (m0 + m) * lda + k_lo + 4 * kc;
+            step[u] = GK;
+            krow[u] = 4 * kc;                                // valid while k0 + krow < k_hi
+            colok[u] = m0 + m < M;
+        } else {                                             // K-major [16 k][128 cols], 32 chunks per row, two rows per instruction
+            const float *base = (wave < 2) ? A : B;
+            const long ld = (wave < 2) ? lda : ldb;
+            const long c0 = (wave < 2) ? m0 : n0;
+            const int dim = (wave < 2) ? M : N;
+            const int row = 2 * rp + h;
+            const int sw = TA ? (row & 1) : ((row >> 2) & 1);
+            const int j = c32 ^ (sw << 2);
+            src[u] = base + (k_lo + row) * ld + c0 + 4 * j;
+            step[u] = GK * ld;
+            krow[u] = row;
+            colok[u] = c0 + 4 * j < dim;
+        }
+    }
+    const int dst_off = ((wave < 2) ? 0 : DTILE) + (wave & 1) * 4 * 256;   // + u*256 floats, + lane*4 by the hardware
+    auto issue = [&](int t) {
+        float *dstb = &smem[t % DST][0][0] + dst_off;
+        const long k0 = k_lo + (long)t * GK;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float *g = (colok[u] && k0 + krow[u] < k_hi) ? src[u] + (long)t * step[u] : zero;
+            __builtin_amdgcn_global_load_lds((gbl_void_t)g, (lds_void_t)(dstb + u * 256), 16, 0, 0);
+        }
+    };
+
+    // ---- MFMA-side LDS offsets ----
+    int colA[4], colB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = 64 * wm + 16 * i + c16, n = 64 * wn + 16 * i + c16;
+        colA[i] = TA ? ((((m >> 2) ^ ((q & 1) << 2)) << 2) + (m & 3)) : (m * GK + 4 * q);
+        colB[i] = (((n >> 2) ^ ((q & 1) << 2)) << 2) + (n & 3);
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float cs = 0.0f;
+
+    issue(0);
+    if (T > 1) issue(1);
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + 2 < T) issue(t + 2);          // into the buffer every wave finished reading before the barrier above
+        const float *As = &smem[t % DST][0][0], *Bs = &smem[t % DST][1][0];
+        if (TA) {
+#pragma unroll
+            for (int s4 = 0; s4 < GK / 4; ++s4) {
+                float a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = As[(4 * s4 + q) * GT + colA[i]];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = Bs[(4 * s4 + q) * GT + colB[j]];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (do_sum && tid < GT) {
+#pragma unroll
+                for (int k = 0; k < GK; ++k) cs += As[k * GT + ((((tid >> 2) ^ ((k & 1) << 2)) << 2) + (tid & 3))];
+            }
+        } else {
+            f32x4 av[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4 *>(As + colA[i]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = Bs[(4 * q + r) * GT + colB[j]];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][r], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long m = m0 + 64 * wm + 16 * i + 4 * q + r;
+                const int n = n0 + 64 * wn + 16 * j + c16;
+                if (m < M && n < N) {
+                    float v = acc[i][j][r];
+                    if (mask != nullptr) v *= (mask[m * ldm + n] > 0.0f) ? 1.0f : slope;
+                    float *dst = C + m * ldc + n;
+                    if (mode == 0) *dst = v;
+                    else if (mode == 1) *dst += v;
+                    else atomicAdd(dst, v);
+                }
+            }
+    if (do_sum && tid < GT && m0 + tid < M) atomicAdd(rowsum + m0 + tid, cs);
+}
+
 // dst[m*ldd + n] (op)= src[m*lds + n] for n < N   (mode 0 copy, 1 add)
 __global__ void copy2d_kernel(long M, int N, const float *__restrict__ src, long lds_, float *__restrict__ dst, long ldd, int mode)
 {
@@ -325,21 +477,25 @@ __global__ void tanh_backward_kernel(long P, const float *__restrict__ actbuf, c
     }
 }
 
-// per-frame constants: dW[r][col0 + k] += db[r] * c[k];  dc[k] += sum_r W[r][col0 + k] * db[r]
+// per-frame constants: dW[r][col0 + k] += db[r] * c[k];  dc[k] += sum_r W[r][col0 + k] * db[r].  One workgroup per column k.
 __global__ void __launch_bounds__(256) const_cols_backward_kernel(int rows, int cols, const float *__restrict__ W, float *__restrict__ dW, long ld,
                                                                   int col0, const float *__restrict__ db, const float *__restrict__ c,
                                                                   float *__restrict__ dc)
 {
-    for (int k = threadIdx.x; k < cols; k += blockDim.x) {
-        float s = 0.0f;
-        const float ck = c[k];
-        for (int r = 0; r < rows; ++r) {
-            const float g = db[r];
-            s += W[(long)r * ld + col0 + k] * g;
-            dW[(long)r * ld + col0 + k] += g * ck;
-        }
-        dc[k] += s;
+    const int k = blockIdx.x;
+    const float ck = c[k];
+    float s = 0.0f;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        const float g = db[r];
+        s += W[(long)r * ld + col0 + k] * g;
+        dW[(long)r * ld + col0 + k] += g * ck;
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dc[k] += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ void axpy_kernel(int n, const float *__restrict__ x, float *__restrict__ y)
@@ -356,8 +512,12 @@ namespace {
 struct Bwd {
     hipStream_t st;
     long P;
+    const float *zero;     // 16-byte zero page (DMA source for out-of-range tile rows/columns)
+    float *wal;            // scratch for 16-byte aligned copies of weight sub-matrices (the flat parameter buffer is not aligned)
+    long walo = 0;
     int err = 0;
     void check() { if (!err) err = (int)hipGetLastError(); }
+    static bool al(const void *p, long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0; }
     // dX[P x N] (mode) = dY[P x K] * W[K x N] (* mask)
     void nn(const float *dY, long ldy, int K, const float *W, long ldw, int N, float *dX, long ldx, int mode, const float *mask = nullptr,
             long ldm = 0, float slope = 0.0f)
@@ -365,7 +525,20 @@ struct Bwd {
         const int nbn = (N + GT - 1) / GT;
         const long nbm = (P + GT - 1) / GT;
         dim3 g((unsigned)(((nbm + 7) / 8) * 8 * nbn), 1, 1);
-        gemm_f32_kernel<false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn);
+        if (K % GK == 0 && al(dY, ldy)) {
+            if (!al(W, ldw)) {
+                const long ldb = (N + 3) / 4 * 4;
+                float *dst = wal + walo;
+                walo += (long)K * ldb;
+                const long tot = (long)K * N;
+                copy2d_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(K, N, W, ldw, dst, ldb, 0);
+                check();
+                W = dst; ldw = ldb;
+            }
+            gemm_dma_kernel<false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn, zero);
+        } else {
+            gemm_f32_kernel<false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn);
+        }
         check();
     }
     // dW[M x N] += dY[P x M]^T * X[P x N];  db != null: db[M] += column sums of dY (fused: the dY tiles are staged anyway).
@@ -376,7 +549,10 @@ struct Bwd {
         long kslab = (P * tiles / 1536 + 15) / 16 * 16;
         kslab = kslab < 256 ? 256 : (kslab > 8192 ? 8192 : kslab);
         dim3 g((N + GT - 1) / GT, (M + GT - 1) / GT, (unsigned)((P + kslab - 1) / kslab));
-        gemm_f32_kernel<true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0);
+        if (al(dY, ldy) && al(X, ldx))
+            gemm_dma_kernel<true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0, zero);
+        else
+            gemm_f32_kernel<true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0);
         check();
     }
     void copy(const float *src, long lds_, int N, float *dst, long ldd, int mode)
@@ -391,7 +567,8 @@ struct Bwd {
 // Words of workspace per call: gA, gB, dfeat (P x 256 each), din (P x 96), dgridf (P x 32), dxw, dw, g3 (P x 4 each), db scratch,
 // channel-last copies of the feature grid and of its gradient accumulator
 constexpr int DB_SCRATCH = 8192;   // per-call bias-gradient scratch (all layers of one level: ~5.3 K floats)
-extern "C" long sahs_field_backward_ws_words(long P) { return P * (256L * 3 + 96 + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS; }
+constexpr long WAL_FLOATS = 2L << 20;   // aligned weight sub-matrix copies of one level (< 1.8 M floats)
+extern "C" long sahs_field_backward_ws_words(long P) { return P * (256L * 3 + 96 + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS + WAL_FLOATS; }
 
 // grad_cond: [0:76] d_driving, [80:116] d_pose36 (accumulated).  grad_flat: accumulated.  d_raw: (P,16).
 extern "C" int sahs_field_backward_launch(const float *flat, const float *frame, int level, long P, const float *actbuf, const float *d_raw,
@@ -400,6 +577,8 @@ extern "C" int sahs_field_backward_launch(const float *flat, const float *frame,
     if (P <= 0) return 0;
     if (P > 4000000L) return -3;   // gridDim.y of the P x N GEMMs; callers chunk larger batches
     Bwd b{stream, P};
+    b.zero = ws + P * (256L * 3 + 96 + 32 + 12) + DB_SCRATCH - 64;   // tail of the (zeroed) bias-gradient scratch, never written
+    b.wal = ws + P * (256L * 3 + 96 + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS;
     const FlatOffsets &F = kFlat;
     const FlatOffsets::Lvl &Lv = F.lvl[level];
     float *gA = ws, *gB = gA + P * 256, *dfeat = gB + P * 256, *din = dfeat + P * 256, *dgridf = din + P * 96, *dxw = dgridf + P * 32,
@@ -415,7 +594,7 @@ extern "C" int sahs_field_backward_launch(const float *flat, const float *frame,
     auto newdb = [&](int n) { float *p = db + dbo; dbo += (n + 3) / 4 * 4; return p; };
     auto add_bias = [&](float *dbl, long boff, int n) { axpy_kernel<<<1, 256, 0, stream>>>(n, dbl, G(boff)); b.check(); };
     auto consts = [&](long woff, long ld, int rows, int col0, int cols, const float *dbl, const float *c, float *dc) {
-        const_cols_backward_kernel<<<1, 256, 0, stream>>>(rows, cols, W(woff), G(woff), ld, col0, dbl, c, dc);
+        const_cols_backward_kernel<<<cols, 256, 0, stream>>>(rows, cols, W(woff), G(woff), ld, col0, dbl, c, dc);
         b.check();
     };
     // generic plain layer: given dY (pre-activation grads of this layer, P x out) and its input X (P x in, stride ldx):
