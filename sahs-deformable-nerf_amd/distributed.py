@@ -57,3 +57,35 @@ def render_sharded(render_fn, num_rays, group=None):
     if world > 1:
         rows = all_gather_rows(rows, num_rays, group)
     return unpack_outputs(rows)
+
+
+def all_reduce_gradients(params, group=None, average=True):
+    """Data-parallel training over rays: ONE all-reduce of all parameter gradients as a single flat
+    bucket (2,775,633 fp32 = 11.1 MB for AudioFaceModel; on xGMI a ring moves 2*(N-1)/N of that per link, ~0.13 ms at 8 GPUs),
+    issued after backward -- the HIP backward produces every gradient at once (one flat buffer), so there is nothing to
+    overlap bucket by bucket.  Parameters without a gradient contribute zeros."""
+    params = [p for p in params if p.requires_grad]
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 or not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= world
+    o = 0
+    for p in params:
+        n = p.numel()
+        g = flat[o:o + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        o += n
+
+
+def shard_batch(num_rays, group=None):
+    """This rank's slice of a training batch's ray list (every rank draws the same batch from a shared seed)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(num_rays, world, rank)
+    return slice(lo, hi)

@@ -51,12 +51,20 @@ def learning_rate(cfg, step):
 
 
 def train_step(model, optimizer, cfg, step, image, mask, pose, intrinsics, audio, background, sample_prob, generator=None,
-               regularize_spatial_embedding=False):
+               regularize_spatial_embedding=False, group=None):
     """One optimisation step on one frame.  image (H,W,3), mask (H,W,12) one-hot float, background (H,W,15).
-    Returns dict(loss, psnr, sample_prob)."""
+    Returns dict(loss, psnr, sample_prob).
+
+    Under torch.distributed (one process per GPU) the step is data-parallel over rays: every rank draws the same batch
+    (``generator`` seeded identically), renders and back-propagates its contiguous slice, and the gradients -- and the
+    per-class sampling feedback -- are averaged with one all-reduce each before the optimiser step, so the replicas stay
+    identical."""
+    import torch.distributed as dist
+    from . import distributed as D
     H, W = image.shape[:2]
     probs = semantic_ray_probs(sample_prob, mask)
     sel = sample_training_rays(probs, int(cfg.nerf.train.num_random_rays), generator)
+    sel = sel[D.shard_batch(sel.shape[0], group)]
     ro, rd = get_ray_bundle(H, W, intrinsics, pose)
     ro, rd = ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]
     target = image.reshape(-1, image.shape[-1])[sel]
@@ -68,6 +76,12 @@ def train_step(model, optimizer, cfg, step, image, mask, pose, intrinsics, audio
         loss = loss + torch.norm(model.spatial_embeddings) * 0.0005 * 10
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        D.all_reduce_gradients(model.parameters(), group)
+        stats = torch.cat([new_prob, loss.detach().reshape(1), fine_mse.detach().reshape(1)])
+        dist.all_reduce(stats, group=group)
+        stats /= dist.get_world_size(group)
+        new_prob, loss, fine_mse = stats[:-2] / stats[:-2].sum(), stats[-2], stats[-1]
     optimizer.step()
     for group in optimizer.param_groups:
         group["lr"] = learning_rate(cfg, step)

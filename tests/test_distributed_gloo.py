@@ -61,3 +61,34 @@ def test_two_rank_ray_sharding(tmp_path, flat_weights, num_rays):
     np.save(path.replace(".npz", "_ref.npy"), ref.numpy())
     port = 29500 + (os.getpid() % 2000)
     mp.start_processes(_worker, args=(2, port, num_rays, path), nprocs=2, join=True, start_method="spawn")
+
+
+def _grad_worker(rank, world, port):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib
+        D = importlib.import_module("sahs-deformable-nerf_amd.distributed")
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+        frozen = torch.nn.Parameter(torch.zeros(4), requires_grad=False)
+        x = torch.arange(40, dtype=torch.float32).reshape(8, 5) / 10
+        sl = D.shard_batch(8)
+        assert (sl.start, sl.stop) == (rank * 4, rank * 4 + 4)
+        net(x[sl]).square().mean().backward()
+        net[1].bias.grad = None                       # a parameter without gradient on this rank counts as zeros
+        D.all_reduce_gradients(list(net.parameters()) + [frozen])
+        ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+        ref.load_state_dict(net.state_dict())
+        ref(x).square().mean().backward()             # equal shards: mean of shard-mean gradients == full-batch gradient
+        for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+            want = torch.zeros_like(q.grad) if n == "1.bias" else q.grad
+            assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6), n
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce():
+    port = 31500 + (os.getpid() % 2000)
+    mp.start_processes(_grad_worker, args=(2, port), nprocs=2, join=True, start_method="spawn")
