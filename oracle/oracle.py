@@ -10,29 +10,48 @@ import subprocess
 
 import numpy as np
 
+import contextlib
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIBS = {}
+_SO = {"audio": "liboracle.so", "nerface": "liboracle_nerface.so"}   # sahs_oracle.c built with SAHS_MODEL=0 / 1
+_MODEL = "audio"
 _F = ctypes.POINTER(ctypes.c_float)
 _I64 = ctypes.POINTER(ctypes.c_int64)
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "sahs_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
-    return so
+    for name in _SO.values():
+        so = os.path.join(_HERE, name)
+        if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", name] + (["-B"] if force else []))
+    return os.path.join(_HERE, _SO["audio"])
+
+
+@contextlib.contextmanager
+def model(name):
+    """Select the architecture the calls inside the block restate: "audio" (AudioFaceModel) or "nerface" (NeRFaceModel)."""
+    global _MODEL
+    assert name in _SO, name
+    prev, _MODEL = _MODEL, name
+    try:
+        yield
+    finally:
+        _MODEL = prev
 
 
 def lib():
-    global _LIB
-    if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+    L = _LIBS.get(_MODEL)
+    if L is None:
+        so = os.path.join(_HERE, _SO[_MODEL])
         if not os.path.exists(so):
             build()
-        _LIB = ctypes.CDLL(so)
-        _LIB.oracle_param_count.restype = ctypes.c_long
-    return _LIB
+        L = ctypes.CDLL(so)
+        L.oracle_param_count.restype = ctypes.c_long
+        assert L.oracle_model() == list(_SO).index(_MODEL)
+        _LIBS[_MODEL] = L
+    return L
 
 
 def _f(a):
@@ -63,8 +82,9 @@ def get_ray_bundle(H, W, intrinsics, c2w):
 
 
 def audionet(flat, audio):
+    """AudioNet (audio model) -> driving76; for the NeRFaceModel the 76-d expression is the driving vector itself."""
     audio = _c(audio)
-    assert audio.shape == (16, 29)
+    assert audio.shape == ((16, 29) if _MODEL == "audio" else (76,))
     out = np.empty(76, np.float32)
     lib().oracle_audionet(_f(flat), _f(audio), _f(out))
     return out
@@ -95,7 +115,7 @@ def field_forward(flat, level, x, driving76, pose36, debug=False):
     P, xs = x.shape
     raw = np.empty((P, 16), np.float32)
     dx = np.empty((P, 3), np.float32) if debug else None
-    w = np.empty((P, 2), np.float32) if debug else None
+    w = np.empty((P, 2 if _MODEL == "audio" else 1), np.float32) if debug else None
     g = np.empty((P, 32), np.float32) if debug else None
     lib().oracle_field_forward(_f(flat), ctypes.c_int(int(level)), ctypes.c_long(P), _f(x), ctypes.c_int(xs),
                                _f(_c(driving76)), _f(_c(pose36)), _f(raw), _f(dx), _f(w), _f(g))

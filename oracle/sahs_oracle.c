@@ -17,25 +17,45 @@
  * the bias, which is also what a gfx950 f32 MFMA computes).  Build with -ffp-contract=off so
  * that no product/sum outside the explicit fmaf() calls is fused.
  *
- * Architecture covered: AudioFaceModel built from config/audio/person_2_auto.yml (all three
- * config/audio yml files share it): see the L_x / D_x constants.  The flat parameter buffer is the
- * model's state_dict, tensors concatenated in state_dict order (the "canonical order" of
- * sahs-deformable-nerf_amd/weights.py).
+ * Architectures covered (compile-time switch SAHS_MODEL, one shared object each):
+ *   0  AudioFaceModel built from config/audio/person_2_auto.yml (all three config/audio yml files share it);
+ *   1  NeRFaceModel built from config/expression/person_2.yml / person_3.yml (models.py:189-370): the same graph with
+ *      15-octave position encodings, a 1-D ambient coordinate encoded without its input, a 4-layer trunk fed with the
+ *      76-d expression vector instead of the pose encoding, and no AudioNet (the expression IS the driving vector).
+ * See the L_x / D_x constants.  The flat parameter buffer is the model's state_dict, tensors concatenated in state_dict
+ * order (the "canonical order" of sahs-deformable-nerf_amd/weights.py).
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef SAHS_MODEL
+#define SAHS_MODEL 0
+#endif
 /* ---- architecture constants (person_2_auto.yml + the code defaults that override it) ---- */
+#if SAHS_MODEL == 0
 #define L_XYZ 10            /* person_2_auto.yml:93  num_encoding_fn_xyz                     */
-#define L_DIR 4             /* person_2_auto.yml:100 num_encoding_fn_dir                     */
 #define L_AMB 4             /* person_2_auto.yml:62  num_encoding_fn_ambient                 */
-#define L_POSE 3            /* models.py:203-207 encode_pose_fn, include_input=False         */
 #define AMB 2               /* person_2_auto.yml:64  ambient_coord_dim                       */
-#define D_XYZ (3 + 6 * L_XYZ)          /* 63 */
+#define AMB_INC 1           /* person_2_auto.yml:60  include_input_ambient                   */
+#define TR_LAYERS 8         /* person_2_auto.yml:78                                          */
+#define TRUNK_SEES_POSE 1   /* models.py:430-470: use_pose=True, include_driving=False       */
+#define HAS_AUDIONET 1
+#else
+#define L_XYZ 15            /* expression/person_2.yml:70,85,111 num_encoding_fn_xyz          */
+#define L_AMB 15            /* expression/person_2.yml:79 num_encoding_fn_ambient             */
+#define AMB 1               /* expression/person_2.yml:81 ambient_coord_dim                   */
+#define AMB_INC 0           /* expression/person_2.yml:78 include_input_ambient: False        */
+#define TR_LAYERS 4         /* expression/person_2.yml:98 num_layers                          */
+#define TRUNK_SEES_POSE 0   /* expression/person_2.yml:124-127: include_driving True, use_pose False */
+#define HAS_AUDIONET 0
+#endif
+#define L_DIR 4             /* person_2_auto.yml:100 num_encoding_fn_dir                     */
+#define L_POSE 3            /* models.py:203-207 encode_pose_fn, include_input=False         */
+#define D_XYZ (3 + 6 * L_XYZ)          /* 63 | 93 */
 #define D_DIR (3 + 6 * L_DIR)          /* 27 */
-#define D_AMB (AMB + 2 * AMB * L_AMB)  /* 18 */
+#define D_AMB (AMB_INC * AMB + 2 * AMB * L_AMB)  /* 18 | 30 */
 #define D_POSE (2 * 6 * L_POSE)        /* 36 */
 #define D_DRV 76                       /* modules.py:44 dim_aud                               */
 #define D_GRID 32                      /* models.py:201 channels of spatial_embeddings        */
@@ -46,9 +66,9 @@
 #define DEF_LAYERS 6                   /* person_2_auto.yml:50,66                             */
 #define DEF_SKIP 4                     /* person_2_auto.yml:52,68                             */
 #define TR_H 256                       /* person_2_auto.yml:81                                */
-#define TR_LAYERS 8                    /* person_2_auto.yml:78                                */
 #define TR_SKIP 3                      /* modules.py:176 default; cfg value never forwarded   */
-#define D_TR_IN (D_XYZ + D_AMB + D_POSE)        /* 117: modules.py:203-214                   */
+#define D_TR_CONST (TRUNK_SEES_POSE ? D_POSE : D_DRV)   /* per-frame constant part of the trunk input */
+#define D_TR_IN (D_XYZ + D_AMB + D_TR_CONST)    /* 117 | 199: modules.py:203-228             */
 #define BR_H 128                       /* modules.py:232,239 hidden_size // 2                 */
 #define D_DIR_IN (TR_H + D_DIR + D_GRID)        /* 315: modules.py:234                       */
 #define N_SEG 12                       /* modules.py:244                                      */
@@ -105,14 +125,18 @@ static void model_bind(model_t *m, const float *flat)
         }
         m->lvl[l].segout_w = take(&p, N_SEG * BR_H); m->lvl[l].segout_b = take(&p, N_SEG);
     }
+#if HAS_AUDIONET
     static const int cin[4] = {29, 32, 32, 64}, cout[4] = {32, 32, 64, 64};
     for (int i = 0; i < 4; ++i) {
         m->conv_w[i] = take(&p, (long)cout[i] * cin[i] * 3); m->conv_b[i] = take(&p, cout[i]);
     }
     m->fc_w[0] = take(&p, 64 * 64); m->fc_b[0] = take(&p, 64);
     m->fc_w[1] = take(&p, D_DRV * 64); m->fc_b[1] = take(&p, D_DRV);
+#endif
     m->total = (long)(p - flat);
 }
+
+int oracle_model(void) { return SAHS_MODEL; }
 
 /* Number of floats in the flat parameter buffer (2,775,633 for person_2_auto.yml). */
 long oracle_param_count(void)
@@ -152,6 +176,7 @@ void oracle_get_ray_bundle(int H, int W, const float *intr, const float *c2w, in
  * 4 x [Conv1d(k3,s2,p1) + LeakyReLU(0.02)] -> (64,1) -> Linear 64->64, LeakyReLU(0.02),
  * Linear 64->76.
  * ---------------------------------------------------------------------------------------- */
+#if HAS_AUDIONET
 static float lrelu(float x, float slope) { return x > 0.0f ? x : x * slope; }
 
 static void audionet(const model_t *m, const float *audio, float *driving)
@@ -188,11 +213,18 @@ static void audionet(const model_t *m, const float *audio, float *driving)
         driving[o] = s;
     }
 }
+#endif
 
+/* NeRFaceModel has no AudioNet: its driving vector is the 76-d expression itself (models.py:368). */
 void oracle_audionet(const float *flat, const float *audio, float *driving)
 {
+#if HAS_AUDIONET
     model_t m; model_bind(&m, flat);
     audionet(&m, audio, driving);
+#else
+    (void)flat;
+    memcpy(driving, audio, sizeof(float) * D_DRV);
+#endif
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -249,10 +281,10 @@ static void act_relu(float *x, int n) { for (int i = 0; i < n * PB; ++i) x[i] = 
 static void act_lrelu(float *x, int n, float s) { for (int i = 0; i < n * PB; ++i) x[i] = x[i] > 0.0f ? x[i] : x[i] * s; }
 
 /* PE of a d-vector per point, transposed layout: out[(feature)][p] */
-static void pe_block(const float *x /*[d][PB]*/, int d, int L, float *out)
+static void pe_block(const float *x /*[d][PB]*/, int d, int L, int include_input, float *out)
 {
     int o = 0;
-    for (int i = 0; i < d; ++i, ++o) for (int p = 0; p < PB; ++p) out[o * PB + p] = x[i * PB + p];
+    if (include_input) for (int i = 0; i < d; ++i, ++o) for (int p = 0; p < PB; ++p) out[o * PB + p] = x[i * PB + p];
     for (int k = 0; k < L; ++k) {
         float f = (float)(1 << k);
         for (int i = 0; i < d; ++i, ++o) for (int p = 0; p < PB; ++p) out[o * PB + p] = sinf(x[i * PB + p] * f);
@@ -338,7 +370,7 @@ static void field_block(const model_t *m, int level, const float *x6, int xs, co
         for (int i = 0; i < 3; ++i) { xyz[i * PB + p] = x6[p * xs + i]; rd[i * PB + p] = x6[p * xs + 3 + i]; }
 
     /* initial = cat(PE(xyz), driving, pose): models.py:303, modules.py:372-381 */
-    pe_block(xyz, 3, L_XYZ, in175);
+    pe_block(xyz, 3, L_XYZ, 1, in175);
     for (int k = 0; k < D_DRV; ++k) for (int p = 0; p < PB; ++p) in175[(D_XYZ + k) * PB + p] = driving[k];
     for (int k = 0; k < D_POSE; ++k) for (int p = 0; p < PB; ++p) in175[(D_XYZ + D_DRV + k) * PB + p] = pose36[k];
 
@@ -364,10 +396,13 @@ static void field_block(const model_t *m, int level, const float *x6, int xs, co
         for (int c = 0; c < D_GRID; ++c) { gridf[c * PB + p] = g[c]; if (dbg_grid) dbg_grid[p * D_GRID + c] = g[c]; }
     }
     /* template input: cat(PE10(xyz'), PE4(w), pose36): models.py:332-336, modules.py:255-266 */
-    pe_block(mapped, 3, L_XYZ, in117);
-    pe_block(mapped + 3 * PB, AMB, L_AMB, in117 + D_XYZ * PB);
-    for (int k = 0; k < D_POSE; ++k) for (int p = 0; p < PB; ++p) in117[(D_XYZ + D_AMB + k) * PB + p] = pose36[k];
-    pe_block(rd, 3, L_DIR, dirpe); /* models.py:340 */
+    pe_block(mapped, 3, L_XYZ, 1, in117);
+    pe_block(mapped + 3 * PB, AMB, L_AMB, AMB_INC, in117 + D_XYZ * PB);
+    {   /* AudioFaceModel: pose36 (use_pose); NeRFaceModel: the driving vector (include_driving), modules.py:260-267 */
+        const float *cv = TRUNK_SEES_POSE ? pose36 : driving;
+        for (int k = 0; k < D_TR_CONST; ++k) for (int p = 0; p < PB; ++p) in117[(D_XYZ + D_AMB + k) * PB + p] = cv[k];
+    }
+    pe_block(rd, 3, L_DIR, 1, dirpe); /* models.py:340 */
 
     /* trunk: modules.py:267-273 */
     dense(m->lvl[level].xyz_w[0], m->lvl[level].xyz_b[0], TR_H, D_TR_IN, in117, tmp);

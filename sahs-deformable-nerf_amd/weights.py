@@ -32,8 +32,24 @@ MAC_PER_SAMPLE = 927_872
 FLOP_PER_SAMPLE = 2 * MAC_PER_SAMPLE
 
 
-def canonical_spec():
+# NeRFaceModel built from config/expression/person_2.yml / person_3.yml (models.py:189-299): 15-octave position encodings
+# (93), 1-D ambient coordinate encoded WITHOUT its input (30), 4-layer trunk fed [PE93 | PE30 | expression76]; the deformation
+# nets still take the 36-d pose encoding (modules.py:344: dim_pose = include_pose + 36 even when include_pose is False).
+NERFACE = dict(D_XYZ=93, D_AMB=30, AMB_DIM=1, TR_LAYERS=4, D_DEF_IN=93 + 76 + 36, D_TR_IN=93 + 30 + 76)
+NERFACE_MAC_PER_SAMPLE = (128 * 205 + 4 * 128 * 128 + 128 * (128 + 205) + 3 * 128) + (64 * 205 + 4 * 64 * 64 + 64 * (64 + 205) + 64) \
+    + (256 * 199 + 2 * 256 * 256 + 256 * (256 + 199) + 256 * 256 + 256) + (128 * 315 + 3 * 128 * 128 + 3 * 128) \
+    + (128 * 256 + 3 * 128 * 128 + 12 * 128)
+
+
+def canonical_spec(model="audio"):
     """[(state_dict key, shape)] in ``state_dict`` order."""
+    if model == "nerface":
+        return _spec(NERFACE["D_DEF_IN"], NERFACE["D_TR_IN"], NERFACE["AMB_DIM"], NERFACE["TR_LAYERS"], audionet=False)
+    assert model == "audio", model
+    return _spec(D_DEF_IN, D_TR_IN, 2, TR_LAYERS, audionet=True)
+
+
+def _spec(D_DEF_IN, D_TR_IN, AMB_DIM, TR_LAYERS, audionet):
     spec = [("spatial_embeddings", (1, D_GRID, G_RES, G_RES, G_RES))]
 
     def lin(name, out, inp):
@@ -47,7 +63,7 @@ def canonical_spec():
     for i in range(DEF_LAYERS):
         inp = D_DEF_IN if i == 0 else (HYP_H + D_DEF_IN if i == DEF_SKIP else HYP_H)
         lin(f"hyper_sheep_mlp.layers_ambient.{i}", HYP_H, inp)
-    lin("hyper_sheep_mlp.fc_ambient", 2, HYP_H)
+    lin("hyper_sheep_mlp.fc_ambient", AMB_DIM, HYP_H)
     for lvl in ("coarse", "fine"):
         p = f"nerf_mlps.{lvl}."
         for i in range(TR_LAYERS):
@@ -61,6 +77,8 @@ def canonical_spec():
         for i in range(4):
             lin(p + f"layers_seg.{i}", BR_H, TR_H if i == 0 else BR_H)
         lin(p + "fc_seg", N_SEG, BR_H)
+    if not audionet:
+        return spec
     for idx, (co, ci) in zip((0, 2, 4, 6), ((32, 29), (32, 32), (64, 32), (64, 64))):
         spec.append((f"audNet_head.encoder_conv.{idx}.weight", (co, ci, 3)))
         spec.append((f"audNet_head.encoder_conv.{idx}.bias", (co,)))
@@ -69,14 +87,14 @@ def canonical_spec():
     return spec
 
 
-def param_count():
-    return int(sum(int(np.prod(s)) for _, s in canonical_spec()))
+def param_count(model="audio"):
+    return int(sum(int(np.prod(s)) for _, s in canonical_spec(model)))
 
 
-def canonical_offsets():
+def canonical_offsets(model="audio"):
     """OrderedDict key -> (offset, shape) into the flat buffer."""
     out, off = OrderedDict(), 0
-    for k, s in canonical_spec():
+    for k, s in canonical_spec(model):
         out[k] = (off, s)
         off += int(np.prod(s))
     return out
@@ -108,7 +126,7 @@ def hash_normal(n, stream, seed=0):
     return (r * np.cos(2.0 * np.pi * u2)).astype(np.float32)
 
 
-def hash_state_dict(seed=0, density_bias=0.0, density_gain=1.0):
+def hash_state_dict(seed=0, density_bias=0.0, density_gain=1.0, model="audio"):
     """Deterministic synthetic ``state_dict`` (numpy fp32 arrays, state_dict order).
 
     ``density_bias``/``density_gain`` give the *density-boosted* variant of SURVEY.md section 8(d):
@@ -117,12 +135,13 @@ def hash_state_dict(seed=0, density_bias=0.0, density_gain=1.0):
     importance-sampling stages are actually exercised.
     """
     sd = OrderedDict()
-    for t, (k, shape) in enumerate(canonical_spec()):
+    spec = canonical_spec(model)
+    for t, (k, shape) in enumerate(spec):
         n = int(np.prod(shape))
         if k == "spatial_embeddings":
             v = hash_normal(n, t, seed) * np.float32(0.01)
         else:
-            wshape = shape if k.endswith(".weight") else dict(canonical_spec())[k[:-5] + ".weight"]
+            wshape = shape if k.endswith(".weight") else dict(spec)[k[:-5] + ".weight"]
             fan_in = int(np.prod(wshape[1:]))
             bound = np.float32(1.0 / np.sqrt(fan_in))
             v = (hash_uniform(n, t, seed) * np.float32(2.0) - np.float32(1.0)) * bound
@@ -135,10 +154,10 @@ def hash_state_dict(seed=0, density_bias=0.0, density_gain=1.0):
     return sd
 
 
-def flatten_state_dict(sd):
+def flatten_state_dict(sd, model="audio"):
     """Concatenate a ``state_dict`` (numpy arrays or torch tensors) into the canonical flat buffer."""
     parts = []
-    for k, shape in canonical_spec():
+    for k, shape in canonical_spec(model):
         v = sd[k]
         if hasattr(v, "detach"):
             v = v.detach().cpu().numpy()

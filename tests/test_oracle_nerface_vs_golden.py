@@ -1,0 +1,94 @@
+"""Pin the NeRFaceModel build of the CPU oracle (oracle/sahs_oracle.c with SAHS_MODEL=1) to the real reference
+(tests/golden/nerface_*.npz, written by tests/golden/make_golden_nerface.py from nerf.models.NeRFaceModel built from
+config/expression/person_2.yml).
+
+Tolerances: as test_oracle_vs_golden.py, but this model encodes positions with 15 octaves: sin/cos(2^14 x') amplifies a 1e-7
+round-off difference in the warp output (ATen's vectorised GEMM vs the oracle's sequential chain) to ~2e-3 in the top PE
+features, 32x the audio model's, and the ambient coordinate (also 15 octaves) likewise; what reaches `raw` is that
+times the first-layer weights (|W| <= 1/sqrt(199))."""
+import numpy as np
+import pytest
+
+from conftest import golden_rand, load_golden, pkg
+from oracle import oracle
+from test_oracle_vs_golden import close
+
+
+@pytest.fixture(scope="module")
+def nf_flat():
+    W = pkg("weights")
+    cache = {}
+
+    def get(seed=0, density_bias=0.0, density_gain=1.0):
+        key = (int(seed), float(density_bias), float(density_gain))
+        if key not in cache:
+            cache[key] = W.flatten_state_dict(W.hash_state_dict(*key, model="nerface"), model="nerface")
+        return cache[key]
+
+    return get
+
+
+def test_param_count():
+    with oracle.model("nerface"):
+        assert oracle.param_count() == pkg("weights").param_count("nerface") == 2_311_140
+    assert oracle.param_count() == 2_775_633
+
+
+def test_positional_encodings():
+    g = load_golden("nerface_pe")
+    # fl(2^k x) is exact, so both sides evaluate sin/cos at the same argument (up to 2^14 * 0.9 rad): 1-ulp libm vs SLEEF
+    close(oracle.positional_encoding(g["x"], 15), g["pe_xyz"], 1e-6, 1e-6, "pe_xyz")
+    close(oracle.positional_encoding(g["w"], 15, include_input=False), g["pe_amb"], 1e-6, 1e-6, "pe_amb")
+
+
+@pytest.mark.parametrize("variant", ["default", "boosted"])
+def test_field(nf_flat, variant):
+    g = load_golden("nerface_field")
+    kw = dict(default=dict(), boosted=dict(density_bias=8.0, density_gain=30.0))[variant]
+    flat = nf_flat(**kw)
+    with oracle.model("nerface"):
+        drv = oracle.audionet(flat, g["expression"])
+        assert np.array_equal(drv, g["expression"])
+        p36 = oracle.pose_encoding(g["pose"])
+        raw_c, dx, w, grid = oracle.field_forward(flat, 0, g["x"], drv, p36, debug=True)
+        raw_f = oracle.field_forward(flat, 1, g["x"], drv, p36)
+    assert w.shape == g[variant + "_w"].shape == (256, 1)
+    close(dx, g[variant + "_dx"], 1e-4, 2e-6, "dx")
+    close(w, g[variant + "_w"], 1e-4, 2e-6, "ambient w")
+    close(grid, g[variant + "_grid_coarse"], 1e-3, 2e-6, "grid features")
+    scale = 30.0 if variant == "boosted" else 1.0
+    for lvl, raw in (("coarse", raw_c), ("fine", raw_f)):
+        close(raw[:, :15], g[variant + "_raw_" + lvl][:, :15], 2e-3, 2e-3, "raw rgb/seg " + lvl)
+        close(raw[:, 15], g[variant + "_raw_" + lvl][:, 15], 2e-3, 2e-3 * scale, "raw sigma " + lvl)
+
+
+@pytest.mark.parametrize("name", ["nerface_e2e_val", "nerface_e2e_det"])
+def test_end_to_end(nf_flat, name):
+    """The fine pass of this model is ill-conditioned in the resampled depths: sigma contains sin/cos(2^14 x'), so a 1e-5
+    difference in a depth (round-off level of the inverse cdf, cf. test_sample_pdf) turns the top octaves by 0.16 rad.  The
+    stages are therefore pinned separately -- coarse pass tight, resampled depths to the inverse-cdf bound, fine pass tight
+    on the REFERENCE's own depths -- and the chained result to the looser bound that follows."""
+    g = load_golden(name)
+    flat = nf_flat(int(g["weights_seed"]), float(g["weights_density_bias"]), float(g["weights_density_gain"]))
+    log = golden_rand(g)
+    rand = dict(zip(["t_rand", "u"], [a for _, a in log])) if log else {}
+    N = int(g["H"]) * int(g["W"])
+    with oracle.model("nerface"):
+        ro, rd = oracle.get_ray_bundle(int(g["H"]), int(g["W"]), g["intrinsics"], g["pose"])
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        rays = np.concatenate([ro, rd, np.full((N, 1), g["near"], np.float32), np.full((N, 1), g["far"], np.float32)], 1).astype(np.float32)
+        p36 = oracle.pose_encoding(g["pose"])
+        o = oracle.render_rays(flat, rays, 64, 64, g["expression"], p36, bg=g["bg"], t_rand=rand.get("t_rand"), u=rand.get("u"), want_aux=True)
+        # fine pass on the reference's own depths
+        zf = g["z_fine"]
+        pts = np.concatenate([ro[:, None, :] + rd[:, None, :] * zf[..., None], np.broadcast_to(rd[:, None, :], (N, 128, 3))], -1)
+        raw = oracle.field_forward(flat, 1, pts.reshape(-1, 6).astype(np.float32), g["expression"], p36).reshape(N, 128, 16)
+        rgb, disp, acc, wts, depth = oracle.composite(raw, zf, rd, bg=g["bg"])
+    for nm in ("rgb_c", "disp_c", "acc_c"):
+        close(o[nm], g["out_" + nm].reshape(o[nm].shape), 2e-4, 1e-4, name + ":" + nm)
+    close(o["z_fine"], zf, 1e-5, 6e-4, "resampled depths")   # inverse cdf over denominators down to 1e-5 (observed 3.9e-4 on one sample)
+    for nm, v in (("rgb_f", rgb), ("disp_f", disp), ("acc_f", acc), ("depth_f", depth), ("w_bg", wts[:, -1])):
+        close(v, g["out_" + nm].reshape(v.shape), 5e-4, 1e-4, name + ": fine pass on reference depths: " + nm)
+    for nm in ("rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"):
+        close(o[nm], g["out_" + nm].reshape(o[nm].shape), 1e-2, 3e-3, name + ": chained " + nm)
+    assert float(np.mean(g["out_w_bg"])) < 0.5
