@@ -8,7 +8,7 @@ from . import weights, cfgnode                      # noqa: F401  (pure python, 
 from . import _lib, ops                             # noqa: F401  (binds libsahs_nerf.so lazily, fails loudly)
 from . import models, nerf_helpers, train_utils, volume_rendering_utils, distributed, training, evaluation   # noqa: F401
 from .cfgnode import CfgNode, default_config        # noqa: F401
-from .models import AudioFaceModel                  # noqa: F401
+from .models import AudioFaceModel, NeRFaceModel    # noqa: F401
 from .train_utils import run_one_iter_of_nerf, predict_and_render_radiance, run_network   # noqa: F401
 from .volume_rendering_utils import volume_render_radiance_field                        # noqa: F401
 from .nerf_helpers import get_ray_bundle, sample_pdf_2, mse2psnr                        # noqa: F401

@@ -35,7 +35,9 @@ class CfgNode(dict):
             return cls(yaml.safe_load(f))
 
 
-def default_config():
-    """The hot-path subset of ``config/audio/person_2_auto.yml`` (same keys, same values)."""
+def default_config(kind="audio"):
+    """The hot-path subset of ``config/audio/person_2_auto.yml`` (kind="audio") or of ``config/expression/person_2.yml``
+    (kind="expression": NeRFaceModel) -- same keys, same values."""
     import os
-    return CfgNode.load_yaml(os.path.join(os.path.dirname(__file__), "config", "audio_hotpath.yml"))
+    return CfgNode.load_yaml(os.path.join(os.path.dirname(__file__), "config", {"audio": "audio_hotpath.yml",
+                                                                                "expression": "expression_hotpath.yml"}[kind]))

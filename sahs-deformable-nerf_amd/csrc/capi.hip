@@ -33,6 +33,15 @@ int sahs_composite_forward_launch(long N, int S, const float *raw, const float *
                                   float *depth, float *w_last, hipStream_t stream);
 int sahs_resample_launch(long N, int S, int nf, int from_z, const float *z, const float *weights, const float *u, float *z_samples,
                          float *z_out, long long *inds, hipStream_t stream);
+// the NeRFaceModel build of pack.hip / field_f32.hip (sahs_model.hpp: SAHS_MODEL=1, suffix _nf)
+long sahs_layout_param_count_nf(void);
+long sahs_layout_packed_words_f32_nf(void);
+long sahs_layout_frame_words_nf(void);
+int sahs_pack_weights_f32_launch_nf(const float *flat, float *packed, hipStream_t stream);
+int sahs_fold_conditioning_launch_nf(const float *flat, const float *expression, const float *pose, int pose_ld, float *frame,
+                                     hipStream_t stream);
+int sahs_field_forward_f32_launch_nf(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
+                                     const float *zvals, float *raw, float *dbg, float *actbuf, int num_cu, hipStream_t stream);
 }
 
 static thread_local char g_err[512] = "";
@@ -191,32 +200,88 @@ int sahs_conditioning_backward(const float *flat_params, const float *audio, con
     return e ? hip_fail("sahs_conditioning_backward", e) : 0;
 }
 
+typedef int (*field_fn_t)(const void *, const float *, int, long, int, const float *, int, const float *, float *, float *, int, void *);
+
+static int render_rays_chain(field_fn_t field, const char *who, const void *packed, const float *frame, int precision, long N,
+                             const float *rays, int ray_stride, int Sc, int nf, int lindisp, int white_background, const float *bg,
+                             const float *t_rand, const float *noise_c, const float *u, const float *noise_f, float *z_c, float *z_f,
+                             float *raw, float *weights, float *rgb_c, float *disp_c, float *acc_c, float *rgb_f, float *disp_f,
+                             float *acc_f, float *w_bg, float *depth_f, void *stream)
+{
+    REQUIRE(packed && frame && rays && z_c && raw && weights && rgb_c && disp_c && acc_c && w_bg && depth_f, who);
+    REQUIRE(nf == 0 || (z_f && rgb_f && disp_f && acc_f), who);
+    hipStream_t st = (hipStream_t)stream;
+    int e;
+    if ((e = sahs_stratified_depths(N, Sc, rays, ray_stride, lindisp, t_rand, z_c, stream))) return e;
+    if ((e = field(packed, frame, 0, N, Sc, rays, ray_stride, z_c, raw, nullptr, precision, stream))) return e;
+    REQUIRE(Sc <= 256, who);
+    // depth_f doubles as the coarse depth scratch when there is no fine pass (the reference returns depth_fine only)
+    e = sahs_composite_forward_launch(N, Sc, raw, z_c, rays, ray_stride, noise_c, bg, white_background, rgb_c, disp_c, acc_c, weights,
+                                      depth_f, nf == 0 ? w_bg : nullptr, st);
+    if (e) return hip_fail(who, e);
+    if (nf > 0) {
+        const int Sf = Sc + nf;
+        REQUIRE(Sf <= 256, who);
+        if ((e = sahs_resample(N, Sc, nf, z_c, weights, u, nullptr, z_f, nullptr, stream))) return e;
+        if ((e = field(packed, frame, 1, N, Sf, rays, ray_stride, z_f, raw, nullptr, precision, stream))) return e;
+        e = sahs_composite_forward_launch(N, Sf, raw, z_f, rays, ray_stride, noise_f, bg, white_background, rgb_f, disp_f, acc_f,
+                                          weights, depth_f, w_bg, st);
+        if (e) return hip_fail(who, e);
+    }
+    return 0;
+}
+
 int sahs_render_rays(const void *packed, const float *frame, int precision, long N, const float *rays, int ray_stride, int Sc, int nf,
                      int lindisp, int white_background, const float *bg, const float *t_rand, const float *noise_c, const float *u,
                      const float *noise_f, float *z_c, float *z_f, float *raw, float *weights, float *rgb_c, float *disp_c,
                      float *acc_c, float *rgb_f, float *disp_f, float *acc_f, float *w_bg, float *depth_f, void *stream)
 {
-    REQUIRE(packed && frame && rays && z_c && raw && weights && rgb_c && disp_c && acc_c && w_bg && depth_f, "sahs_render_rays");
-    REQUIRE(nf == 0 || (z_f && rgb_f && disp_f && acc_f), "sahs_render_rays(fine outputs)");
-    hipStream_t st = (hipStream_t)stream;
-    int e;
-    if ((e = sahs_stratified_depths(N, Sc, rays, ray_stride, lindisp, t_rand, z_c, stream))) return e;
-    if ((e = sahs_field_forward(packed, frame, 0, N, Sc, rays, ray_stride, z_c, raw, nullptr, precision, stream))) return e;
-    REQUIRE(Sc <= 256, "sahs_render_rays(Sc <= 256)");
-    // depth_f doubles as the coarse depth scratch when there is no fine pass (the reference returns depth_fine only)
-    e = sahs_composite_forward_launch(N, Sc, raw, z_c, rays, ray_stride, noise_c, bg, white_background, rgb_c, disp_c, acc_c, weights,
-                                      depth_f, nf == 0 ? w_bg : nullptr, st);
-    if (e) return hip_fail("sahs_render_rays(composite coarse)", e);
-    if (nf > 0) {
-        const int Sf = Sc + nf;
-        REQUIRE(Sf <= 256, "sahs_render_rays(Sc + nf <= 256)");
-        if ((e = sahs_resample(N, Sc, nf, z_c, weights, u, nullptr, z_f, nullptr, stream))) return e;
-        if ((e = sahs_field_forward(packed, frame, 1, N, Sf, rays, ray_stride, z_f, raw, nullptr, precision, stream))) return e;
-        e = sahs_composite_forward_launch(N, Sf, raw, z_f, rays, ray_stride, noise_f, bg, white_background, rgb_f, disp_f, acc_f,
-                                          weights, depth_f, w_bg, st);
-        if (e) return hip_fail("sahs_render_rays(composite fine)", e);
-    }
-    return 0;
+    return render_rays_chain(sahs_field_forward, "sahs_render_rays", packed, frame, precision, N, rays, ray_stride, Sc, nf, lindisp,
+                             white_background, bg, t_rand, noise_c, u, noise_f, z_c, z_f, raw, weights, rgb_c, disp_c, acc_c, rgb_f, disp_f,
+                             acc_f, w_bg, depth_f, stream);
+}
+
+// ---- NeRFaceModel (expression configs): same boundary, its own weight/frame layouts; fp32 forward ----
+long sahs_nerface_param_count(void) { return sahs_layout_param_count_nf(); }
+long sahs_nerface_packed_words(int precision) { return precision == SAHS_F32 ? sahs_layout_packed_words_f32_nf() : -1; }
+long sahs_nerface_frame_words(void) { return sahs_layout_frame_words_nf(); }
+
+int sahs_nerface_pack_weights(const float *flat_params, void *packed, int precision, void *stream)
+{
+    REQUIRE(flat_params && packed && ALIGNED16(packed), "sahs_nerface_pack_weights");
+    if (precision != SAHS_F32) return fail(2, "sahs_nerface_pack_weights: only SAHS_F32 is built for this model %s%ld", "", precision);
+    int e = sahs_pack_weights_f32_launch_nf(flat_params, (float *)packed, (hipStream_t)stream);
+    return e ? hip_fail("sahs_nerface_pack_weights", e) : 0;
+}
+
+int sahs_nerface_fold_conditioning(const float *flat_params, const float *expression, const float *pose, int pose_ld, float *frame,
+                                   void *stream)
+{
+    REQUIRE(flat_params && expression && pose && frame && pose_ld >= 4 && ALIGNED16(frame), "sahs_nerface_fold_conditioning");
+    int e = sahs_fold_conditioning_launch_nf(flat_params, expression, pose, pose_ld, frame, (hipStream_t)stream);
+    return e ? hip_fail("sahs_nerface_fold_conditioning", e) : 0;
+}
+
+int sahs_nerface_field_forward(const void *packed, const float *frame, int level, long N, int S, const float *rays, int ray_stride,
+                               const float *z, float *raw, float *dbg, int precision, void *stream)
+{
+    REQUIRE(packed && frame && rays && z && raw, "sahs_nerface_field_forward");
+    REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_nerface_field_forward(shape)");
+    REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_nerface_field_forward(alignment)");
+    if (precision != SAHS_F32) return fail(2, "sahs_nerface_field_forward: only SAHS_F32 is built for this model %s%ld", "", precision);
+    int e = sahs_field_forward_f32_launch_nf((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, nullptr, num_cus(),
+                                             (hipStream_t)stream);
+    return e ? hip_fail("sahs_nerface_field_forward", e) : 0;
+}
+
+int sahs_nerface_render_rays(const void *packed, const float *frame, int precision, long N, const float *rays, int ray_stride, int Sc, int nf,
+                             int lindisp, int white_background, const float *bg, const float *t_rand, const float *noise_c, const float *u,
+                             const float *noise_f, float *z_c, float *z_f, float *raw, float *weights, float *rgb_c, float *disp_c,
+                             float *acc_c, float *rgb_f, float *disp_f, float *acc_f, float *w_bg, float *depth_f, void *stream)
+{
+    return render_rays_chain(sahs_nerface_field_forward, "sahs_nerface_render_rays", packed, frame, precision, N, rays, ray_stride, Sc, nf,
+                             lindisp, white_background, bg, t_rand, noise_c, u, noise_f, z_c, z_f, raw, weights, rgb_c, disp_c, acc_c, rgb_f,
+                             disp_f, acc_f, w_bg, depth_f, stream);
 }
 
 }  // extern "C"

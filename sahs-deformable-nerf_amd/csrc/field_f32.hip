@@ -24,7 +24,7 @@
 #include "sahs_common.hpp"
 #include "sahs_layout.hpp"
 
-namespace sahs {
+namespace SAHS_NS {
 
 constexpr int F32_THREADS = 512;
 constexpr int F32_PTS_PER_WAVE = 16;
@@ -192,22 +192,24 @@ __device__ __forceinline__ float sin_octave(RevArg u, float scale, int fn)
 #endif
 }
 
-template <int D, int L, int NB>
+template <int D, int L, int NB, int INC = 1>   // INC: include_input (the raw coordinates come first)
 __device__ __forceinline__ void pe_blocks(const float *v, int q, f32x4 *out)
 {
-    constexpr int W = D + 2 * D * L;
+    constexpr int D0 = INC ? D : 0;
+    constexpr int W = D0 + 2 * D * L;
     // plain scalars, selected with ternaries: an array of structs indexed by the lane-dependent axis ends up in scratch
-    const RevArg u0 = rev_arg(v[0]), u1 = rev_arg(v[1]), u2 = rev_arg(v[D > 2 ? 2 : 0]);
+    const float v0 = v[0], v1 = v[D > 1 ? 1 : 0], v2 = v[D > 2 ? 2 : 0];
+    const RevArg u0 = rev_arg(v0), u1 = rev_arg(v1), u2 = rev_arg(v2);
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f = 16 * b + 4 * q + r;
             float val = 0.0f;
-            if (f < D) {
-                val = (f == 0) ? v[0] : ((f == 1) ? v[1] : v[D > 2 ? 2 : 0]);
+            if (f < D0) {
+                val = (f == 0) ? v0 : ((f == 1) ? v1 : v2);
             } else if (f < W) {
-                const int g = f - D;
+                const int g = f - D0;
                 const int k = g / (2 * D), rem = g % (2 * D);
                 const int fn = rem / D, ax = rem % D;
                 RevArg a;
@@ -291,30 +293,37 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         float *dsl = dbg + p * DBG_STRIDE;
         float *sv = (SAVE && p_raw < P) ? actbuf + p * (long)act::STRIDE + 4 * q : nullptr;   // this lane's slot in its sample's row
 #define SV(off) (SAVE && sv != nullptr ? sv + (off) : nullptr)
-        f32x4 pe_x[4];
+        f32x4 pe_x[KB_XYZ];
         float x[3];
         {
             const float *rp = rays + (p / S) * ray_stride;
             const float z = zvals[p];
 #pragma unroll
             for (int i = 0; i < 3; ++i) x[i] = rp[i] + rp[3 + i] * z;          // train_utils.py:115
-            pe_blocks<3, 10, 4>(x, q, pe_x);
+            pe_blocks<3, L_XYZ, KB_XYZ>(x, q, pe_x);
             if (SAVE && sv != nullptr) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4 *>(sv + act::E + 16 * b) = pe_x[b];
+                for (int b = 0; b < KB_XYZ; ++b) *reinterpret_cast<f32x4 *>(sv + act::E + 16 * b) = pe_x[b];
             }
         }
         // ---- warp field: dx = tanh(MLP) (modules.py:371-390) ----
         {
             f32x4 h[8], hn[8];
-            dense<4, 0, 8, CHF(L_W1)>(cx, pe_x, nullptr, h, Ly[L_W0].bias_off, false, 0.0f, SV(act::WH));
+            dense<KB_XYZ, 0, 8, CHF(L_W1)>(cx, pe_x, nullptr, h, Ly[L_W0].bias_off, false, 0.0f, SV(act::WH));
+            // W1..W3; the chunk after each is W2, W3, W4B.  One rolled loop where those have the same size (AudioFaceModel: 32 KB)
+            constexpr int W_ROLLED = (CHF(L_W4B) == CHF(L_W2)) ? 3 : 2;
 #pragma unroll 1
-            for (int l = 0; l < 3; ++l) {      // W1..W3 (the chunk after each is 32 KB: W2, W3, W4B)
+            for (int l = 0; l < W_ROLLED; ++l) {
                 dense<8, 0, 8, CHF(L_W2)>(cx, h, nullptr, hn, Ly[L_W1].bias_off + 128 * l, false, 0.0f, SV(act::WH + 128 * (l + 1)));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) h[i] = hn[i];
             }
-            dense<4, 0, 8, CHF(L_W4A)>(cx, pe_x, nullptr, hn, Ly[L_W4B].bias_off, false, 1.0f);
+            if (W_ROLLED == 2) {
+                dense<8, 0, 8, CHF(L_W4B)>(cx, h, nullptr, hn, Ly[L_W3].bias_off, false, 0.0f, SV(act::WH + 128 * 3));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) h[i] = hn[i];
+            }
+            dense<KB_XYZ, 0, 8, CHF(L_W4A)>(cx, pe_x, nullptr, hn, Ly[L_W4B].bias_off, false, 1.0f);
             dense<8, 0, 8, CHF(L_W5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::WH + 4 * 128));
             dense<8, 0, 8, CHF(L_WF)>(cx, hn, nullptr, h, Ly[L_W5].bias_off, false, 0.0f, SV(act::WH + 5 * 128));
             f32x4 o[1];
@@ -331,21 +340,27 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         // ---- hyper sheet: ambient w (modules.py:444-462) ----
         {
             f32x4 h[4], hn[4];
-            dense<4, 0, 4, CHF(L_H1)>(cx, pe_x, nullptr, h, Ly[L_H0].bias_off, false, 0.0f, SV(act::HH));
+            dense<KB_XYZ, 0, 4, CHF(L_H1)>(cx, pe_x, nullptr, h, Ly[L_H0].bias_off, false, 0.0f, SV(act::HH));
+            constexpr int H_ROLLED = (CHF(L_H4B) == CHF(L_H2)) ? 3 : 2;   // H1..H3 (next chunks: H2, H3, H4B)
 #pragma unroll 1
-            for (int l = 0; l < 3; ++l) {      // H1..H3 (next chunks: H2, H3, H4B, all 16 KB)
+            for (int l = 0; l < H_ROLLED; ++l) {
                 dense<4, 0, 4, CHF(L_H2)>(cx, h, nullptr, hn, Ly[L_H1].bias_off + 64 * l, false, 0.0f, SV(act::HH + 64 * (l + 1)));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) h[i] = hn[i];
             }
-            dense<4, 0, 4, CHF(L_H4A)>(cx, pe_x, nullptr, hn, Ly[L_H4B].bias_off, false, 1.0f);
+            if (H_ROLLED == 2) {
+                dense<4, 0, 4, CHF(L_H4B)>(cx, h, nullptr, hn, Ly[L_H3].bias_off, false, 0.0f, SV(act::HH + 64 * 3));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = hn[i];
+            }
+            dense<KB_XYZ, 0, 4, CHF(L_H4A)>(cx, pe_x, nullptr, hn, Ly[L_H4B].bias_off, false, 1.0f);
             dense<4, 0, 4, CHF(L_H5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::HH + 4 * 64));
             dense<4, 0, 4, CHF(L_HF)>(cx, hn, nullptr, h, Ly[L_H5].bias_off, false, 0.0f, SV(act::HH + 5 * 64));
             f32x4 o[1];
             dense<4, 0, 1, CHF(L_T0)>(cx, h, nullptr, o, Ly[L_HF].bias_off, false, 1.0f);
-            if (q == 0) {
-                stash[3] = o[0][0]; stash[4] = o[0][1];
-                if (SAVE && sv != nullptr) { sv[act::AW] = o[0][0]; sv[act::AW + 1] = o[0][1]; }
+            if (q == 0) {      // rows 0..AMB_DIM-1 of the one output tile
+                stash[3] = o[0][0]; stash[4] = (AMB_DIM > 1) ? o[0][1] : 0.0f;
+                if (SAVE && sv != nullptr) { sv[act::AW] = o[0][0]; sv[act::AW + 1] = stash[4]; }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -357,15 +372,15 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         {
             f32x4 h[16];
             {
-                f32x4 in_tr[6];
+                f32x4 in_tr[KB_XYZ + KB_AMB];
                 const float xw[3] = {stash[0], stash[1], stash[2]}, amb[2] = {stash[3], stash[4]};
-                pe_blocks<3, 10, 4>(xw, q, in_tr);
-                pe_blocks<2, 4, 2>(amb, q, in_tr + 4);
+                pe_blocks<3, L_XYZ, KB_XYZ>(xw, q, in_tr);
+                pe_blocks<AMB_DIM, L_AMB, KB_AMB, AMB_INC>(amb, q, in_tr + KB_XYZ);
                 if (SAVE && sv != nullptr) {
 #pragma unroll
-                    for (int b = 0; b < 6; ++b) *reinterpret_cast<f32x4 *>(sv + act::PEX + 16 * b) = in_tr[b];   // PEX (4 blocks) then PEW (2)
+                    for (int b = 0; b < KB_XYZ + KB_AMB; ++b) *reinterpret_cast<f32x4 *>(sv + act::PEX + 16 * b) = in_tr[b];   // PEX blocks then PEW
                 }
-                dense<4, 2, 16, CHF(L_T1)>(cx, in_tr, in_tr + 4, h, Ly[L_T0].bias_off, false, 0.01f, SV(act::T));
+                dense<KB_XYZ, KB_AMB, 16, CHF(L_T1)>(cx, in_tr, in_tr + KB_XYZ, h, Ly[L_T0].bias_off, false, 0.01f, SV(act::T));
             }
             if (dump) dsl[5] = h[0][0];
             dense<16, 0, 16, CHF(L_T2)>(cx, h, nullptr, feat, Ly[L_T1].bias_off, false, 0.01f, SV(act::T + 256));
@@ -377,16 +392,21 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
 #pragma unroll
             for (int i = 0; i < 16; ++i) h[i] = feat[i];
             {   // skip layer: the re-injected encoding is rebuilt here instead of staying live (24 VGPRs) through T1, T2
-                f32x4 in_tr[6];
+                f32x4 in_tr[KB_XYZ + KB_AMB];
                 const float xw[3] = {stash[0], stash[1], stash[2]}, amb[2] = {stash[3], stash[4]};
-                pe_blocks<3, 10, 4>(xw, q, in_tr);
-                pe_blocks<2, 4, 2>(amb, q, in_tr + 4);
-                dense<4, 2, 16, CHF(L_T3A)>(cx, in_tr, in_tr + 4, feat, Ly[L_T3B].bias_off, false, 1.0f);
+                pe_blocks<3, L_XYZ, KB_XYZ>(xw, q, in_tr);
+                pe_blocks<AMB_DIM, L_AMB, KB_AMB, AMB_INC>(amb, q, in_tr + KB_XYZ);
+                dense<KB_XYZ, KB_AMB, 16, CHF(L_T3A)>(cx, in_tr, in_tr + KB_XYZ, feat, Ly[L_T3B].bias_off, false, 1.0f);
             }
+#if SAHS_MODEL == 0
             dense<16, 0, 16, CHF(L_T4)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768));
+#else           // 4-layer trunk: the skip layer is the last one, fc_feat follows
+            dense<16, 0, 16, CHF(L_FEAT)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768));
+#endif
             if (dump) dsl[8] = feat[0][0];
 #pragma unroll
             for (int i = 0; i < 16; ++i) h[i] = feat[i];
+#if SAHS_MODEL == 0
 #pragma unroll 1
             for (int l = 4; l <= 7; ++l) {     // T4..T7 (next chunks: T5, T6, T7, FEAT, all 32 KB)
                 dense<16, 0, 16, CHF(L_T5)>(cx, h, nullptr, feat, Ly[L_T4].bias_off + 256 * (l - 4), false, 0.01f, SV(act::T + 256 * l));
@@ -394,6 +414,7 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
 #pragma unroll
                 for (int i = 0; i < 16; ++i) h[i] = feat[i];
             }
+#endif
             dense<16, 0, 16, CHF(L_ALPHA)>(cx, h, nullptr, feat, Ly[L_FEAT].bias_off, false, 1.0f, SV(act::FEAT));
             if (dump) dsl[13] = feat[0][0];
         }
@@ -451,12 +472,12 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
     }
 }
 
-}  // namespace sahs
+}  // namespace SAHS_NS
 
-using namespace sahs;
+using namespace SAHS_NS;
 
 // dbg (optional, may be null): [P x 24: see DBG_STRIDE][P x 32: grid features]
-extern "C" int sahs_field_forward_f32_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays,
+extern "C" int SAHS_SYM(sahs_field_forward_f32_launch)(const float *packed, const float *frame, int level, long P, int S, const float *rays,
                                              int ray_stride, const float *zvals, float *raw, float *dbg, float *actbuf, int num_cu,
                                              hipStream_t stream)
 {

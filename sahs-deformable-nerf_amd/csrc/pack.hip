@@ -10,7 +10,7 @@
 #include "sahs_common.hpp"
 #include "sahs_layout.hpp"
 
-namespace sahs {
+namespace SAHS_NS {
 
 __device__ const Program dProg = make_program();
 __device__ const FlatOffsets dFlat = make_flat_offsets();
@@ -143,6 +143,11 @@ __global__ void __launch_bounds__(256) fold_conditioning_kernel(const float *__r
 {
     __shared__ float a[64 * 16], b[64 * 16], drv[D_DRV], p36[D_POSE];
     const int tid = threadIdx.x;
+#if SAHS_MODEL == 1
+    // NeRFaceModel: the driving vector is the 76-d expression itself (models.py:368); `audio` points at it
+    (void)a; (void)b;
+    if (tid < D_DRV) { drv[tid] = audio[tid]; frame[FRAME_DRV_OFF + tid] = audio[tid]; }
+#else
     // AudioNet: rows 0:16 of the window, permuted to (29,16) (modules.py:69-70)
     for (int e = tid; e < 29 * 16; e += 256) { int c = e / 16, t = e % 16; a[c * 16 + t] = audio[t * 29 + c]; }
     __syncthreads();
@@ -179,6 +184,7 @@ __global__ void __launch_bounds__(256) fold_conditioning_kernel(const float *__r
         drv[tid] = s;
         frame[FRAME_DRV_OFF + tid] = s;
     }
+#endif
     // pose -> euler + translation -> PE(L=3, no input) (models.py:482-504, 203-207)
     if (tid < D_POSE) {
         const int kf = tid / 12, fn = (tid % 12) / 6, i = tid % 6;
@@ -216,11 +222,11 @@ __global__ void __launch_bounds__(256) fold_conditioning_kernel(const float *__r
     }
 }
 
-}  // namespace sahs
+}  // namespace SAHS_NS
 
-using namespace sahs;
+using namespace SAHS_NS;
 
-extern "C" int sahs_pack_weights_f32_launch(const float *flat, float *packed, hipStream_t stream)
+extern "C" int SAHS_SYM(sahs_pack_weights_f32_launch)(const float *flat, float *packed, hipStream_t stream)
 {
     pack_stream_f32_kernel<<<2048, 256, 0, stream>>>(flat, packed);
     pack_grid_f32_kernel<<<1024, 256, 0, stream>>>(flat, packed);
@@ -228,7 +234,7 @@ extern "C" int sahs_pack_weights_f32_launch(const float *flat, float *packed, hi
     return (int)hipGetLastError();
 }
 
-extern "C" int sahs_pack_weights_bf16_launch(const float *flat, float *packed, hipStream_t stream)
+extern "C" int SAHS_SYM(sahs_pack_weights_bf16_launch)(const float *flat, float *packed, hipStream_t stream)
 {
     pack_stream_bf16_kernel<<<1024, 256, 0, stream>>>(flat, packed);
     pack_grid_f32_kernel<<<1024, 256, 0, stream>>>(flat, packed);    // grid stays fp32, channel-last, at the same offset
@@ -236,9 +242,14 @@ extern "C" int sahs_pack_weights_bf16_launch(const float *flat, float *packed, h
     return (int)hipGetLastError();
 }
 
-extern "C" int sahs_fold_conditioning_launch(const float *flat, const float *audio, const float *pose, int pose_ld, float *frame,
+extern "C" int SAHS_SYM(sahs_fold_conditioning_launch)(const float *flat, const float *audio, const float *pose, int pose_ld, float *frame,
                                              hipStream_t stream)
 {
     fold_conditioning_kernel<<<1, 256, 0, stream>>>(flat, audio, pose, pose_ld, frame);
     return (int)hipGetLastError();
 }
+
+// sizes of this model's buffers, for the C ABI (capi.hip is built once and cannot see both models' constants)
+extern "C" long SAHS_SYM(sahs_layout_param_count)(void) { return kFlat.total; }
+extern "C" long SAHS_SYM(sahs_layout_packed_words_f32)(void) { return PACK_FLOATS; }
+extern "C" long SAHS_SYM(sahs_layout_frame_words)(void) { return FRAME_FLOATS; }

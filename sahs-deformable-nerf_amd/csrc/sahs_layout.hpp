@@ -16,14 +16,32 @@
 // of the replication traffic.  Algorithmic FLOPs are still counted as the reference writes them.
 #pragma once
 #include <cstdint>
+#include "sahs_model.hpp"
 
-namespace sahs {
+namespace SAHS_NS {
 
-// ---- architecture (AudioFaceModel, config/audio/person_2_auto.yml) ----
-constexpr int D_XYZ = 63, D_DIR = 27, D_AMB = 18, D_POSE = 36, D_DRV = 76, D_GRID = 32, G_RES = 32;
+// ---- architecture ----
+#if SAHS_MODEL == 0
+// AudioFaceModel, config/audio/person_2_auto.yml: 10-octave position encoding, 2-D ambient coordinate
+// encoded with its input (4 octaves), 8-layer trunk fed [PE63(x') | PE18(w) | pose36]; driving = AudioNet(audio window).
+constexpr int L_XYZ = 10, AMB_DIM = 2, L_AMB = 4, AMB_INC = 1, TR_LAYERS = 8;
+constexpr bool TRUNK_SEES_POSE = true, HAS_AUDIONET = true;
+#else
+// NeRFaceModel, config/expression/person_2.yml / person_3.yml (models.py:189-299): 15 octaves, 1-D ambient coordinate
+// encoded WITHOUT its input (15 octaves), 4-layer trunk fed [PE93(x') | PE30(w) | expression76] (include_driving, no
+// pose); the deformation nets still take [PE93 | expression76 | pose36] (modules.py:344: dim_pose = include_pose + 36).
+constexpr int L_XYZ = 15, AMB_DIM = 1, L_AMB = 15, AMB_INC = 0, TR_LAYERS = 4;
+constexpr bool TRUNK_SEES_POSE = false, HAS_AUDIONET = false;
+#endif
+constexpr int D_XYZ = 3 + 6 * L_XYZ;                             // 63 | 93
+constexpr int D_AMB = AMB_INC * AMB_DIM + 2 * AMB_DIM * L_AMB;   // 18 | 30
+constexpr int KB_XYZ = (D_XYZ + 15) / 16, KB_AMB = (D_AMB + 15) / 16;   // 16-feature k-blocks: 4 | 6, 2 | 2
+constexpr int D_DIR = 27, D_POSE = 36, D_DRV = 76, D_GRID = 32, G_RES = 32;
 constexpr int WARP_H = 128, HYP_H = 64, TR_H = 256, BR_H = 128, N_SEG = 12, D_RAW = 16;
-constexpr int D_DEF_IN = D_XYZ + D_DRV + D_POSE;   // 175
-constexpr int D_TR_IN = D_XYZ + D_AMB + D_POSE;    // 117
+constexpr int D_TR_CONST = TRUNK_SEES_POSE ? D_POSE : D_DRV;    // the per-frame constant the trunk sees
+constexpr int TR_CONST_WHICH = TRUNK_SEES_POSE ? 1 : 0;         // Fold::which
+constexpr int D_DEF_IN = D_XYZ + D_DRV + D_POSE;   // 175 | 205
+constexpr int D_TR_IN = D_XYZ + D_AMB + D_TR_CONST;    // 117 | 199
 constexpr int D_DIR_IN = TR_H + D_DIR + D_GRID;    // 315
 constexpr long GRID_FLOATS = (long)D_GRID * G_RES * G_RES * G_RES;
 
@@ -54,9 +72,9 @@ constexpr FlatOffsets make_flat_offsets()
         int in = (i == 0) ? D_DEF_IN : (i == 4 ? HYP_H + D_DEF_IN : HYP_H);
         f.hyp_w[i] = p; p += (long)HYP_H * in; f.hyp_b[i] = p; p += HYP_H;
     }
-    f.hyp_fw = p; p += 2 * HYP_H; f.hyp_fb = p; p += 2;
+    f.hyp_fw = p; p += AMB_DIM * HYP_H; f.hyp_fb = p; p += AMB_DIM;
     for (int l = 0; l < 2; ++l) {
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < TR_LAYERS; ++i) {
             int in = (i == 0) ? D_TR_IN : (i == 3 ? TR_H + D_TR_IN : TR_H);
             f.lvl[l].xyz_w[i] = p; p += (long)TR_H * in; f.lvl[l].xyz_b[i] = p; p += TR_H;
         }
@@ -73,15 +91,17 @@ constexpr FlatOffsets make_flat_offsets()
         }
         f.lvl[l].segout_w = p; p += N_SEG * BR_H; f.lvl[l].segout_b = p; p += N_SEG;
     }
-    constexpr int cin[4] = {29, 32, 32, 64}, cout[4] = {32, 32, 64, 64};
-    for (int i = 0; i < 4; ++i) { f.conv_w[i] = p; p += (long)cout[i] * cin[i] * 3; f.conv_b[i] = p; p += cout[i]; }
-    f.fc_w[0] = p; p += 64 * 64; f.fc_b[0] = p; p += 64;
-    f.fc_w[1] = p; p += D_DRV * 64; f.fc_b[1] = p; p += D_DRV;
+    if (HAS_AUDIONET) {
+        constexpr int cin[4] = {29, 32, 32, 64}, cout[4] = {32, 32, 64, 64};
+        for (int i = 0; i < 4; ++i) { f.conv_w[i] = p; p += (long)cout[i] * cin[i] * 3; f.conv_b[i] = p; p += cout[i]; }
+        f.fc_w[0] = p; p += 64 * 64; f.fc_b[0] = p; p += 64;
+        f.fc_w[1] = p; p += D_DRV * 64; f.fc_b[1] = p; p += D_DRV;
+    }
     f.total = p;
     return f;
 }
 constexpr FlatOffsets kFlat = make_flat_offsets();
-static_assert(kFlat.total == 2775633, "flat parameter count must match the reference state_dict");
+static_assert(kFlat.total == (SAHS_MODEL == 0 ? 2775633 : 2311140), "flat parameter count must match the reference state_dict");
 
 // ---- layer program -------------------------------------------------------------------------
 // A layer consumes up to 2 input segments (each a whole number of 16-feature k-blocks, zero
@@ -98,7 +118,11 @@ struct Fold { int src_col; int count; int which; };          // which: 0 = drivi
 enum LayerId {   // enum order == execution order == stream order
     L_W0, L_W1, L_W2, L_W3, L_W4B, L_W4A, L_W5, L_WF,
     L_H0, L_H1, L_H2, L_H3, L_H4B, L_H4A, L_H5, L_HF,
-    L_T0, L_T1, L_T2, L_T3B, L_T3A, L_T4, L_T5, L_T6, L_T7, L_FEAT, L_ALPHA,
+    L_T0, L_T1, L_T2, L_T3B, L_T3A,
+#if SAHS_MODEL == 0
+    L_T4, L_T5, L_T6, L_T7,
+#endif
+    L_FEAT, L_ALPHA,
     L_D0B, L_D0A, L_D1, L_D2, L_D3, L_RGB,
     L_S0, L_S1, L_S2, L_S3, L_SEG,
     NUM_LAYERS
@@ -162,32 +186,37 @@ constexpr Program make_program()
     // skip layer 4: [h | PE63 | driving76 | pose36]  (modules.py:372-387, 445-459)
     auto warp = [&](int i, int ld) { return Src{f.warp_w[i], f.warp_w[i], f.warp_b[i], f.warp_b[i], ld, WARP_H}; };
     auto hyp = [&](int i, int ld) { return Src{f.hyp_w[i], f.hyp_w[i], f.hyp_b[i], f.hyp_b[i], ld, HYP_H}; };
-    L[L_W0] = mk(warp(0, D_DEF_IN), 1, 0, 8, {4, 0, 63}, {0, 0, 0}, {63, 76, 0}, {139, 36, 1});
+    L[L_W0] = mk(warp(0, D_DEF_IN), 1, 0, 8, {KB_XYZ, 0, D_XYZ}, {0, 0, 0}, {D_XYZ, D_DRV, 0}, {D_XYZ + D_DRV, D_POSE, 1});
     L[L_W1] = mk(warp(1, WARP_H), 1, 0, 8, {8, 0, 128});
     L[L_W2] = mk(warp(2, WARP_H), 1, 0, 8, {8, 0, 128});
     L[L_W3] = mk(warp(3, WARP_H), 1, 0, 8, {8, 0, 128});
-    L[L_W4B] = mk(warp(4, WARP_H + D_DEF_IN), 1, 0, 8, {4, 128, 63}, {0, 0, 0}, {191, 76, 0}, {267, 36, 1});
+    L[L_W4B] = mk(warp(4, WARP_H + D_DEF_IN), 1, 0, 8, {KB_XYZ, WARP_H, D_XYZ}, {0, 0, 0}, {WARP_H + D_XYZ, D_DRV, 0},
+                  {WARP_H + D_XYZ + D_DRV, D_POSE, 1});
     L[L_W4A] = mk(warp(4, WARP_H + D_DEF_IN), 0, 0, 8, {8, 0, 128});
     L[L_W5] = mk(warp(5, WARP_H), 1, 0, 8, {8, 0, 128});
     L[L_WF] = mk(Src{f.warp_fw, f.warp_fw, f.warp_fb, f.warp_fb, WARP_H, 3}, 1, 0, 1, {8, 0, 128});
-    L[L_H0] = mk(hyp(0, D_DEF_IN), 1, 0, 4, {4, 0, 63}, {0, 0, 0}, {63, 76, 0}, {139, 36, 1});
+    L[L_H0] = mk(hyp(0, D_DEF_IN), 1, 0, 4, {KB_XYZ, 0, D_XYZ}, {0, 0, 0}, {D_XYZ, D_DRV, 0}, {D_XYZ + D_DRV, D_POSE, 1});
     L[L_H1] = mk(hyp(1, HYP_H), 1, 0, 4, {4, 0, 64});
     L[L_H2] = mk(hyp(2, HYP_H), 1, 0, 4, {4, 0, 64});
     L[L_H3] = mk(hyp(3, HYP_H), 1, 0, 4, {4, 0, 64});
-    L[L_H4B] = mk(hyp(4, HYP_H + D_DEF_IN), 1, 0, 4, {4, 64, 63}, {0, 0, 0}, {127, 76, 0}, {203, 36, 1});
+    L[L_H4B] = mk(hyp(4, HYP_H + D_DEF_IN), 1, 0, 4, {KB_XYZ, HYP_H, D_XYZ}, {0, 0, 0}, {HYP_H + D_XYZ, D_DRV, 0},
+                  {HYP_H + D_XYZ + D_DRV, D_POSE, 1});
     L[L_H4A] = mk(hyp(4, HYP_H + D_DEF_IN), 0, 0, 4, {4, 0, 64});
     L[L_H5] = mk(hyp(5, HYP_H), 1, 0, 4, {4, 0, 64});
-    L[L_HF] = mk(Src{f.hyp_fw, f.hyp_fw, f.hyp_fb, f.hyp_fb, HYP_H, 2}, 1, 0, 1, {4, 0, 64});
-    // radiance trunk.  Source columns: [PE63(x') | PE18(w) | pose36]; skip layer 3: [h | same]
+    L[L_HF] = mk(Src{f.hyp_fw, f.hyp_fw, f.hyp_fb, f.hyp_fb, HYP_H, AMB_DIM}, 1, 0, 1, {4, 0, 64});
+    // radiance trunk.  Source columns: [PE(x') | PE(w) | pose36 or driving76 (model)]; skip layer 3: [h | same]
     // (modules.py:255-273; skip index is NeRFMLP's default 3, models.py never forwards the YAML's 4)
     const FlatOffsets::Lvl &c = f.lvl[0], &n = f.lvl[1];
     auto tr = [&](int i, int ld) { return Src{c.xyz_w[i], n.xyz_w[i], c.xyz_b[i], n.xyz_b[i], ld, TR_H}; };
-    L[L_T0] = mk(tr(0, D_TR_IN), 1, 0, 16, {4, 0, 63}, {2, 63, 18}, {81, 36, 1});
+    L[L_T0] = mk(tr(0, D_TR_IN), 1, 0, 16, {KB_XYZ, 0, D_XYZ}, {KB_AMB, D_XYZ, D_AMB}, {D_XYZ + D_AMB, D_TR_CONST, TR_CONST_WHICH});
     L[L_T1] = mk(tr(1, TR_H), 1, 0, 16, {16, 0, 256});
     L[L_T2] = mk(tr(2, TR_H), 1, 0, 16, {16, 0, 256});
-    L[L_T3B] = mk(tr(3, TR_H + D_TR_IN), 1, 0, 16, {4, 256, 63}, {2, 319, 18}, {337, 36, 1});
+    L[L_T3B] = mk(tr(3, TR_H + D_TR_IN), 1, 0, 16, {KB_XYZ, TR_H, D_XYZ}, {KB_AMB, TR_H + D_XYZ, D_AMB},
+                  {TR_H + D_XYZ + D_AMB, D_TR_CONST, TR_CONST_WHICH});
     L[L_T3A] = mk(tr(3, TR_H + D_TR_IN), 0, 0, 16, {16, 0, 256});
+#if SAHS_MODEL == 0
     for (int i = 4; i < 8; ++i) L[L_T4 + (i - 4)] = mk(tr(i, TR_H), 1, 0, 16, {16, 0, 256});
+#endif
     L[L_FEAT] = mk(Src{c.feat_w, n.feat_w, c.feat_b, n.feat_b, TR_H, TR_H}, 1, 0, 16, {16, 0, 256});
     L[L_ALPHA] = mk(Src{c.alpha_w, n.alpha_w, c.alpha_b, n.alpha_b, TR_H, 1}, 1, 15, 1, {16, 0, 256});
     // colour branch: [feat256 | dirPE27 | grid32] (modules.py:276-287)
@@ -237,7 +266,7 @@ constexpr long PACK_FLOATS = PACK_TABLE_OFF + ((NUM_CHUNKS + 1 + 3) / 4) * 4;
 constexpr int FRAME_DRV_OFF = 0, FRAME_POSE_OFF = 80, FRAME_BIAS_OFF = 128;
 constexpr int FRAME_FLOATS = FRAME_BIAS_OFF + 2 * BIAS_FLOATS;
 
-}  // namespace sahs
+}  // namespace SAHS_NS
 
 // =============================================================================================
 // bf16 program (field_bf16.hip).  Same network, same bias array (the per-frame fold is shared), but
@@ -248,13 +277,17 @@ constexpr int FRAME_FLOATS = FRAME_BIAS_OFF + 2 * BIAS_FLOATS;
 // W[32t+i][32b + 16s + 8(j>>2) + 4h + (j&3)], j = 0..7: the k order in which a 32x32 accumulator
 // tile turns into the next MFMA's B operand without moving between lanes.
 // =============================================================================================
-namespace sahs {
+namespace SAHS_NS {
 namespace hb {
 
 enum LayerIdH {
     H_W0, H_W1, H_W2, H_W3, H_W4, H_W5, H_WF,
     H_H0, H_H1, H_H2, H_H3, H_H4, H_H5, H_HF,
-    H_T0, H_T1, H_T2, H_T3, H_T4, H_T5, H_T6, H_T7, H_FEAT, H_ALPHA,
+    H_T0, H_T1, H_T2, H_T3,
+#if SAHS_MODEL == 0
+    H_T4, H_T5, H_T6, H_T7,
+#endif
+    H_FEAT, H_ALPHA,
     H_D0, H_D1, H_D2, H_D3, H_RGB,
     H_S0, H_S1, H_S2, H_S3, H_SEG,
     NUM_LAYERS_H
@@ -314,7 +347,9 @@ constexpr ProgramH make_program_h()
     H[H_H4] = from2(L[L_H4B], L[L_H4A]); H[H_H5] = from1(L[L_H5]); H[H_HF] = from1(L[L_HF]);
     H[H_T0] = from1(L[L_T0]); H[H_T1] = from1(L[L_T1]); H[H_T2] = from1(L[L_T2]);
     H[H_T3] = from2(L[L_T3B], L[L_T3A]);
+#if SAHS_MODEL == 0
     H[H_T4] = from1(L[L_T4]); H[H_T5] = from1(L[L_T5]); H[H_T6] = from1(L[L_T6]); H[H_T7] = from1(L[L_T7]);
+#endif
     H[H_FEAT] = from1(L[L_FEAT]); H[H_ALPHA] = from1(L[L_ALPHA]);
     H[H_D0] = from2(L[L_D0B], L[L_D0A]); H[H_D1] = from1(L[L_D1]); H[H_D2] = from1(L[L_D2]); H[H_D3] = from1(L[L_D3]);
     H[H_RGB] = from1(L[L_RGB]);
@@ -340,7 +375,7 @@ constexpr long PACKH_TABLE_OFF = PACKH_STREAM_OFF + STREAM_HW;       // 2 levels
 constexpr long PACKH_WORDS = PACKH_TABLE_OFF + ((NUM_CHUNKS_H + 1 + 3) / 4) * 4;
 
 }  // namespace hb
-}  // namespace sahs
+}  // namespace SAHS_NS
 
 // =============================================================================================
 // Saved activations for the backward pass (field_bwd.hip).  One row per sample, fp32, every entry a whole number
@@ -349,22 +384,22 @@ constexpr long PACKH_WORDS = PACKH_TABLE_OFF + ((NUM_CHUNKS_H + 1 + 3) / 4) * 4;
 // derivative mask is recovered from them); PE rows hold sin and cos of every octave, so the PE derivative needs
 // no trigonometry.
 // =============================================================================================
-namespace sahs {
+namespace SAHS_NS {
 namespace act {
-constexpr int E = 0;                    // PE63(x), 64
-constexpr int WH = E + 64;              // warp hidden h0..h5, 6 x 128
+constexpr int E = 0;                    // PE(x), KB_XYZ blocks
+constexpr int WH = E + 16 * KB_XYZ;     // warp hidden h0..h5, 6 x 128
 constexpr int DX = WH + 6 * 128;        // dx = tanh(.), 3 (+13 pad)
 constexpr int HH = DX + 16;             // hyper hidden g0..g5, 6 x 64
-constexpr int AW = HH + 6 * 64;         // ambient w, 2 (+14 pad)
+constexpr int AW = HH + 6 * 64;         // ambient w, AMB_DIM (+pad to 16)
 constexpr int XW = AW + 16;             // warped point x', 3 (+13 pad)
-constexpr int PEX = XW + 16;            // PE63(x'), 64
-constexpr int PEW = PEX + 64;           // PE18(w), 32
-constexpr int T = PEW + 32;             // trunk t0..t7, 8 x 256
-constexpr int FEAT = T + 8 * 256;       // 256
+constexpr int PEX = XW + 16;            // PE(x'), KB_XYZ blocks
+constexpr int PEW = PEX + 16 * KB_XYZ;  // PE(w), KB_AMB blocks
+constexpr int T = PEW + 16 * KB_AMB;    // trunk t0.., TR_LAYERS x 256
+constexpr int FEAT = T + TR_LAYERS * 256;   // 256
 constexpr int DIR = FEAT + 256;         // PE27(rd), 32
 constexpr int GRID = DIR + 32;          // grid features, 32
 constexpr int C = GRID + 32;            // colour hidden c0..c3, 4 x 128
 constexpr int S = C + 4 * 128;          // seg hidden s0..s3, 4 x 128
-constexpr int STRIDE = S + 4 * 128;     // 4768 floats = 19 KB per sample
+constexpr int STRIDE = S + 4 * 128;     // AudioFaceModel: 4768 floats = 19 KB per sample
 }  // namespace act
-}  // namespace sahs
+}  // namespace SAHS_NS

@@ -18,22 +18,22 @@ def _holder(out_f, in_f):
 
 
 class _DeformMLP(nn.Module):
-    def __init__(self, list_name, final_name, hidden, out_dim, num_layers, skip):
+    def __init__(self, list_name, final_name, hidden, out_dim, num_layers, skip, d_in):
         super().__init__()
         layers = nn.ModuleList()
         for i in range(num_layers):
-            inp = W.D_DEF_IN if i == 0 else (hidden + W.D_DEF_IN if i == skip else hidden)
+            inp = d_in if i == 0 else (hidden + d_in if i == skip else hidden)
             layers.append(_holder(hidden, inp))
         setattr(self, list_name, layers)
         setattr(self, final_name, _holder(out_dim, hidden))
 
 
 class _RadianceMLP(nn.Module):
-    def __init__(self):
+    def __init__(self, num_layers, d_in):
         super().__init__()
         self.layers_xyz = nn.ModuleList()
-        for i in range(W.TR_LAYERS):
-            inp = W.D_TR_IN if i == 0 else (W.TR_H + W.D_TR_IN if i == W.TR_SKIP else W.TR_H)
+        for i in range(num_layers):
+            inp = d_in if i == 0 else (W.TR_H + d_in if i == W.TR_SKIP else W.TR_H)
             self.layers_xyz.append(_holder(W.TR_H, inp))
         self.fc_feat = _holder(W.TR_H, W.TR_H)
         self.fc_alpha = _holder(1, W.TR_H)
@@ -52,35 +52,52 @@ class _AudioNet(nn.Module):
         self.encoder_fc1 = nn.Sequential(nn.Linear(64, 64), act(), nn.Linear(64, W.D_DRV))
 
 
-def _check_cfg(cfg):
-    """The kernels are specialised to the architecture every config/audio/*.yml describes."""
+def _common_cfg(m):
+    return [(m.warp.use_warp, True), (m.warp.num_layers, 6), (m.warp.hidden_size, 128), (m.warp.skip_connect_every, 4),
+            (m.hyper.use_ambient, True), (m.hyper.slice_method, "bendy_sheet"), (m.hyper.num_layers, 6), (m.hyper.hidden_size, 64),
+            (m.hyper.skip_connect_every, 4), (m.hyper.include_driving, True), (m.coarse.hidden_size, 256),
+            (m.coarse.include_input_xyz, True), (m.coarse.num_encoding_fn_dir, 4), (m.coarse.include_input_dir, True),
+            (m.coarse.use_viewdirs, True), (m.coarse.use_spatial_embeddings, True)]
+
+
+def _check_cfg(cfg, arch):
+    """The kernels are specialised to the two architectures the reference's configs describe: config/audio/*.yml
+    (AudioFaceModel) and config/expression/person_2.yml / person_3.yml (NeRFaceModel with warp and hyper sheet)."""
     m = cfg.models
-    want = [(m.warp.use_warp, True), (m.warp.num_layers, 6), (m.warp.hidden_size, 128), (m.warp.skip_connect_every, 4),
-            (m.warp.num_encoding_fn_xyz, 10), (m.hyper.use_ambient, True), (m.hyper.slice_method, "bendy_sheet"),
-            (m.hyper.ambient_coord_dim, 2), (m.hyper.num_layers, 6), (m.hyper.hidden_size, 64), (m.hyper.skip_connect_every, 4),
-            (m.hyper.num_encoding_fn_ambient, 4), (m.hyper.include_input_ambient, True), (m.hyper.include_driving, True),
-            (m.coarse.num_layers, 8), (m.coarse.hidden_size, 256), (m.coarse.num_encoding_fn_xyz, 10), (m.coarse.include_input_xyz, True),
-            (m.coarse.num_encoding_fn_dir, 4), (m.coarse.include_input_dir, True), (m.coarse.use_viewdirs, True),
-            (m.coarse.use_spatial_embeddings, True), (m.coarse.use_pose, True), (m.coarse.include_driving, False)]
+    if arch == "audio":
+        want = _common_cfg(m) + [(m.warp.num_encoding_fn_xyz, 10), (m.hyper.ambient_coord_dim, 2), (m.hyper.num_encoding_fn_ambient, 4),
+                                 (m.hyper.include_input_ambient, True), (m.coarse.num_layers, 8), (m.coarse.num_encoding_fn_xyz, 10),
+                                 (m.coarse.use_pose, True), (m.coarse.include_driving, False)]
+    else:
+        want = _common_cfg(m) + [(m.warp.num_encoding_fn_xyz, 15), (m.hyper.num_encoding_fn_xyz, 15), (m.hyper.ambient_coord_dim, 1),
+                                 (m.hyper.num_encoding_fn_ambient, 15), (m.hyper.include_input_ambient, False), (m.coarse.num_layers, 4),
+                                 (m.coarse.num_encoding_fn_xyz, 15), (m.coarse.use_pose, False), (m.coarse.include_driving, True)]
     bad = [(a, b) for a, b in want if a != b]
     if bad or not hasattr(m, "fine"):
-        raise NotImplementedError("this build covers the AudioFaceModel architecture of config/audio/*.yml; the expression "
-                                  "(NeRFaceModel) variants are SURVEY.md section 8(f)-3. Mismatches: %r" % (bad,))
+        raise NotImplementedError("this build covers AudioFaceModel (config/audio/*.yml) and NeRFaceModel with warp + hyper sheet "
+                                  "(config/expression/person_2.yml, person_3.yml); the no-warp/no-hyper ablation (person_1.yml) is "
+                                  "not built. Mismatches (got, want): %r" % (bad,))
 
 
-class AudioFaceModel(nn.Module):
-    def __init__(self, cfg, precision="fp32"):
-        super().__init__()
-        _check_cfg(cfg)
+class _FieldModel(nn.Module):
+    """Shared plumbing: parameters in the reference's state_dict layout, packed lazily for the HIP field kernel."""
+    arch = "audio"
+
+    def _build(self, cfg, precision):
+        _check_cfg(cfg, self.arch)
         self.num_coarse = cfg.nerf.train.num_coarse
         self.num_fine = cfg.nerf.train.num_fine
         self.precision = ops.PRECISIONS[precision]
+        nf = W.NERFACE
+        d_def, d_tr, amb, trl = ((W.D_DEF_IN, W.D_TR_IN, 2, W.TR_LAYERS) if self.arch == "audio"
+                                 else (nf["D_DEF_IN"], nf["D_TR_IN"], nf["AMB_DIM"], nf["TR_LAYERS"]))
         self.spatial_embeddings = nn.Parameter(torch.randn(1, W.D_GRID, W.G_RES, W.G_RES, W.G_RES) * 0.01)   # models.py:199-201
-        self.warp_field_mlp = _DeformMLP("layers_xyz", "fc_final", W.WARP_H, 3, W.DEF_LAYERS, W.DEF_SKIP)
-        self.hyper_sheep_mlp = _DeformMLP("layers_ambient", "fc_ambient", W.HYP_H, 2, W.DEF_LAYERS, W.DEF_SKIP)
-        self.nerf_mlps = nn.ModuleDict({"coarse": _RadianceMLP(), "fine": _RadianceMLP()})
-        self.audNet_head = _AudioNet()
-        keys = [k for k, _ in W.canonical_spec()]
+        self.warp_field_mlp = _DeformMLP("layers_xyz", "fc_final", W.WARP_H, 3, W.DEF_LAYERS, W.DEF_SKIP, d_def)
+        self.hyper_sheep_mlp = _DeformMLP("layers_ambient", "fc_ambient", W.HYP_H, amb, W.DEF_LAYERS, W.DEF_SKIP, d_def)
+        self.nerf_mlps = nn.ModuleDict({"coarse": _RadianceMLP(trl, d_tr), "fine": _RadianceMLP(trl, d_tr)})
+        if self.arch == "audio":
+            self.audNet_head = _AudioNet()
+        keys = [k for k, _ in W.canonical_spec(self.arch)]
         assert list(self.state_dict().keys()) == keys, "state_dict layout drifted from the reference's"
         self._cache = {}
 
@@ -89,14 +106,14 @@ class AudioFaceModel(nn.Module):
         """Canonical flat buffer (state_dict order).  differentiable=True keeps the autograd link to the parameters, so a
         gradient w.r.t. the flat buffer (RenderRaysFn.backward) is scattered back to every nn.Parameter by torch.cat's backward."""
         sd = dict(self.named_parameters())
-        flat = torch.cat([sd[k].reshape(-1) for k, _ in W.canonical_spec()]).float().contiguous()
+        flat = torch.cat([sd[k].reshape(-1) for k, _ in W.canonical_spec(self.arch)]).float().contiguous()
         return flat if differentiable else flat.detach()
 
     def load_flat(self, flat):
         off = 0
         with torch.no_grad():
             sd = dict(self.named_parameters())
-            for k, shape in W.canonical_spec():
+            for k, shape in W.canonical_spec(self.arch):
                 n = sd[k].numel()
                 sd[k].copy_(torch.as_tensor(flat[off:off + n]).reshape(shape))
                 off += n
@@ -110,31 +127,49 @@ class AudioFaceModel(nn.Module):
         hit = self._cache.get("packed")
         if hit is None or hit[0] != key:
             flat = self.flat_params()
-            hit = (key, ops.pack_weights(flat, precision), flat)
+            hit = (key, ops.pack_weights(flat, precision, arch=self.arch), flat)
             self._cache["packed"] = hit
         return hit[1], hit[2]
 
-    def frame(self, audio, pose):
-        """Per-frame conditioning buffer (AudioNet + pose encoding + folded biases): models.py:517-521."""
+    def frame(self, driving, pose):
+        """Per-frame conditioning buffer (driving vector + pose encoding + folded biases): models.py:367-370 / 517-521."""
         _, flat = self.packed()
-        return ops.fold_conditioning(flat, audio.to(torch.float32), pose.to(torch.float32))
+        return ops.fold_conditioning(flat, driving.to(torch.float32), pose.to(torch.float32), arch=self.arch)
 
     # ---- B2 seam ----
-    def forward(self, level, x, audio=None, pose=None, pose_c=None, latent_code=None, **kwargs):
-        """models.py:514-528: x (P, >=6) rows [xyz, raw ray direction, ...] -> (P, 16) [rgb3, seg12, sigma]."""
+    def forward(self, level, x, driving=None, pose=None, pose_c=None, latent_code=None, **kwargs):
+        """models.py:366-378 / 514-528: x (P, >=6) rows [xyz, raw ray direction, ...] -> (P, 16) [rgb3, seg12, sigma]."""
         if latent_code is not None:
-            raise NotImplementedError("latent codes are not used by the shipped audio configs (latent_code_dim=0)")
-        ops._no_grad_needed(x, audio, *self.parameters())
+            raise NotImplementedError("latent codes are not used by the shipped configs (latent_code_dim=0)")
+        driving = kwargs.get("audio", driving)
+        ops._no_grad_needed(x, driving, *self.parameters())
         packed, _ = self.packed()
-        frame = self.frame(audio, pose)
+        frame = self.frame(driving, pose)
         P = x.shape[0]
         # a point is a zero-length ray: ro = xyz, z = 0  =>  ro + rd*0 == xyz exactly
         rays = torch.zeros(P, 8, dtype=torch.float32, device=x.device)
         rays[:, :6] = x[:, :6]
         z = torch.zeros(P, 1, dtype=torch.float32, device=x.device)
-        raw = ops.field_forward(packed, frame, 0 if level == "coarse" else 1, rays, z, precision=self.precision)
+        raw = ops.field_forward(packed, frame, 0 if level == "coarse" else 1, rays, z, precision=self.precision, arch=self.arch)
         return raw.view(P, 16)
 
 
-# The reference builds the model with getattr(models, cfg.models.mask.type)(cfg); NeRFaceModel
-# (expression-driven, different widths) is the next scope row and is not provided here.
+class AudioFaceModel(_FieldModel):
+    """models.py:381-528: audio-driven (driving = AudioNet(16x29 DeepSpeech window))."""
+    arch = "audio"
+
+    def __init__(self, cfg, precision="fp32"):
+        super().__init__()
+        self._build(cfg, precision)
+
+
+class NeRFaceModel(_FieldModel):
+    """models.py:189-378: expression-driven (driving = the 76-d expression vector); config/expression/person_2|3.yml.
+    fp32 forward (rendering) in this round; training and bf16 stay with the AudioFaceModel."""
+    arch = "nerface"
+
+    def __init__(self, cfg, precision="fp32"):
+        super().__init__()
+        if precision != "fp32":
+            raise NotImplementedError("NeRFaceModel: only the fp32 kernel is built in this round")
+        self._build(cfg, precision)

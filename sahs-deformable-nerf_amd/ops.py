@@ -42,31 +42,46 @@ def _no_grad_needed(*tensors):
                                   "(wrap the call in torch.no_grad())")
 
 
-def param_count():
-    return int(_lib.lib().sahs_param_count())
+ARCHS = ("audio", "nerface")   # AudioFaceModel (config/audio) | NeRFaceModel (config/expression person_2/3)
 
 
-def pack_weights(flat, precision=SAHS_F32):
+def _fn(name, arch="audio"):
+    """C-ABI entry point `name` of the architecture's family (sahs_<name> | sahs_nerface_<name>)."""
+    if arch not in ARCHS:
+        raise _lib.SahsError("unknown architecture %r" % (arch,))
+    full = "sahs_" + ("nerface_" if arch == "nerface" else "") + name
+    return getattr(_lib.lib(), full), full
+
+
+def param_count(arch="audio"):
+    return int(_fn("param_count", arch)[0]())
+
+
+def pack_weights(flat, precision=SAHS_F32, arch="audio"):
     flat = _req(flat, "flat_params")
-    if flat.numel() != param_count():
-        raise _lib.SahsError("flat_params has %d values, expected %d" % (flat.numel(), param_count()))
-    words = _lib.lib().sahs_packed_words(precision)
+    if flat.numel() != param_count(arch):
+        raise _lib.SahsError("flat_params has %d values, expected %d" % (flat.numel(), param_count(arch)))
+    words = _fn("packed_words", arch)[0](precision)
     if words <= 0:
-        raise _lib.SahsError("precision %r is not built" % (precision,))
+        raise _lib.SahsError("precision %r is not built for architecture %r" % (precision, arch))
     packed = torch.empty(words, dtype=torch.float32, device=flat.device)
-    check(_lib.lib().sahs_pack_weights(_p(flat), _p(packed), precision, _stream()), "sahs_pack_weights")
+    f, name = _fn("pack_weights", arch)
+    check(f(_p(flat), _p(packed), precision, _stream()), name)
     return packed
 
 
-def fold_conditioning(flat, audio, pose):
+def fold_conditioning(flat, audio, pose, arch="audio"):
+    """audio: the (16, 29) DeepSpeech window (AudioFaceModel) or the 76-d expression vector (NeRFaceModel)."""
     flat, audio = _req(flat, "flat_params"), _req(audio, "audio")
     pose = _req(pose, "pose")
-    if tuple(audio.shape) != (16, 29):
-        raise _lib.SahsError("audio must be (16, 29), got %s" % (tuple(audio.shape),))
+    want = (16, 29) if arch == "audio" else (76,)
+    if tuple(audio.shape) != want:
+        raise _lib.SahsError("driving input must be %s for %r, got %s" % (want, arch, tuple(audio.shape)))
     if pose.dim() != 2 or pose.shape[0] < 3 or pose.shape[1] != 4:
         raise _lib.SahsError("pose must be (3|4, 4), got %s" % (tuple(pose.shape),))
-    frame = torch.empty(_lib.lib().sahs_frame_words(), dtype=torch.float32, device=flat.device)
-    check(_lib.lib().sahs_fold_conditioning(_p(flat), _p(audio), _p(pose), 4, _p(frame), _stream()), "sahs_fold_conditioning")
+    frame = torch.empty(_fn("frame_words", arch)[0](), dtype=torch.float32, device=flat.device)
+    f, name = _fn("fold_conditioning", arch)
+    check(f(_p(flat), _p(audio), _p(pose), 4, _p(frame), _stream()), name)
     return frame
 
 
@@ -89,7 +104,7 @@ def stratified_depths(rays, num_samples, lindisp=False, t_rand=None):
     return z
 
 
-def field_forward(packed, frame, level, rays, z, precision=SAHS_F32, debug=False, out=None):
+def field_forward(packed, frame, level, rays, z, precision=SAHS_F32, debug=False, out=None, arch="audio"):
     """raw (N,S,16) for level 0/1 at points ro + rd*z.  debug=True also returns (dx, w, grid)."""
     packed, frame, rays, z = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays"), _req(z, "z")
     N, S = z.shape
@@ -97,8 +112,8 @@ def field_forward(packed, frame, level, rays, z, precision=SAHS_F32, debug=False
         raise _lib.SahsError("rays must be (N, >=8) with N == z.shape[0]")
     raw = out if out is not None else torch.empty(N, S, 16, dtype=torch.float32, device=z.device)
     dbg = torch.zeros(N * S * 88, dtype=torch.float32, device=z.device) if debug else None
-    check(_lib.lib().sahs_field_forward(_p(packed), _p(frame), int(level), N, S, _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(dbg),
-                                         precision, _stream()), "sahs_field_forward")
+    f, name = _fn("field_forward", arch)
+    check(f(_p(packed), _p(frame), int(level), N, S, _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(dbg), precision, _stream()), name)
     if debug == "full":
         return raw, dbg[: N * S * 56].view(N * S, 56), dbg[N * S * 56:].view(N * S, 32)
     if debug:
@@ -141,7 +156,7 @@ def sample_pdf(bins, weights, num_samples, u=None, want_inds=False):
 
 
 def render_rays(packed, frame, rays, num_coarse, num_fine, precision=SAHS_F32, lindisp=False, white_background=False, bg=None,
-                t_rand=None, noise_c=None, u=None, noise_f=None, workspace=None):
+                t_rand=None, noise_c=None, u=None, noise_f=None, workspace=None, arch="audio"):
     """predict_and_render_radiance for one ray chunk -> the reference's 8-tuple (flat shapes)."""
     packed, frame, rays = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays")
     bg, t_rand, noise_c, u, noise_f = (_req(t, n) for t, n in ((bg, "background_prior"), (t_rand, "t_rand"), (noise_c, "noise_c"),
@@ -162,10 +177,11 @@ def render_rays(packed, frame, rays, num_coarse, num_fine, precision=SAHS_F32, l
     raw, weights = buf("raw", N, Sf, 16), buf("weights", N, Sf)
     rgb_c, rgb_f = (torch.empty(N, 15, dtype=torch.float32, device=dev) for _ in range(2))
     disp_c, acc_c, disp_f, acc_f, w_bg, depth_f = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(6))
-    check(_lib.lib().sahs_render_rays(_p(packed), _p(frame), precision, N, _p(rays), int(rays.shape[1]), int(num_coarse), int(num_fine),
-                                       int(bool(lindisp)), int(bool(white_background)), _p(bg), _p(t_rand), _p(noise_c), _p(u), _p(noise_f),
-                                       _p(z_c), _p(z_f), _p(raw), _p(weights), _p(rgb_c), _p(disp_c), _p(acc_c), _p(rgb_f), _p(disp_f),
-                                       _p(acc_f), _p(w_bg), _p(depth_f), _stream()), "sahs_render_rays")
+    f, name = _fn("render_rays", arch)
+    check(f(_p(packed), _p(frame), precision, N, _p(rays), int(rays.shape[1]), int(num_coarse), int(num_fine),
+            int(bool(lindisp)), int(bool(white_background)), _p(bg), _p(t_rand), _p(noise_c), _p(u), _p(noise_f),
+            _p(z_c), _p(z_f), _p(raw), _p(weights), _p(rgb_c), _p(disp_c), _p(acc_c), _p(rgb_f), _p(disp_f),
+            _p(acc_f), _p(w_bg), _p(depth_f), _stream()), name)
     if num_fine > 0:
         return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_bg, depth_f
     return rgb_c, disp_c, acc_c, None, None, None, w_bg, depth_f

@@ -53,6 +53,9 @@ def predict_and_render_radiance(ray_batch, model, options, mode="train", driving
         if background_prior.shape[-1] != 15:
             raise NotImplementedError("background_prior must have 15 channels (rgb3 + seg12)")
         bg = background_prior.to(torch.float32)
+    arch = getattr(model, "arch", "audio")
+    if needs_grad and arch != "audio":
+        raise NotImplementedError("the HIP backward covers the AudioFaceModel; render the NeRFaceModel under torch.no_grad()")
     if needs_grad:
         # training step (train_stage_rays_auto.py:437-499): differentiable op, fp32; its backward runs the HIP backward kernels
         if model.precision != ops.SAHS_F32:
@@ -62,7 +65,7 @@ def predict_and_render_radiance(ray_batch, model, options, mode="train", driving
                                       packed, nc, nf, bool(opt.lindisp), bool(opt.white_background))
     return ops.render_rays(packed, frame, rays, nc, nf, precision=model.precision, lindisp=bool(opt.lindisp),
                            white_background=bool(opt.white_background), bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f,
-                           workspace=_workspace)
+                           workspace=_workspace, arch=arch)
 
 
 def run_one_iter_of_nerf(height, width, focal_length, model, ray_origins, ray_directions, options, mode="train", driving=None,

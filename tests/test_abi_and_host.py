@@ -166,3 +166,27 @@ def test_eval_postprocessing_vs_reference():
     assert np.array_equal(E.label2color(torch.from_numpy(g["seg"])).numpy(), g["seg_color"])
     assert np.array_equal(E.shrink(g["onehot"]), g["shrink"])
     assert np.array_equal(E.cast_to_disparity_image(disp), g["disp_img"])
+
+
+def test_nerface_model_state_dict_and_config_guard():
+    """NeRFaceModel (config/expression/person_2|3.yml): reference state_dict layout (pinned against the real reference by
+    tests/golden/make_golden_nerface.py), and configs outside the two built architectures are refused."""
+    sahs = pkg()
+    W = pkg("weights")
+    cfg = sahs.default_config("expression")
+    m = sahs.NeRFaceModel(cfg)
+    spec = W.canonical_spec("nerface")
+    assert [k for k, _ in spec] == list(m.state_dict().keys())
+    assert all(tuple(m.state_dict()[k].shape) == tuple(s) for k, s in spec)
+    assert sum(p.numel() for p in m.parameters()) == W.param_count("nerface") == 2_311_140
+    assert "audNet_head.encoder_fc1.0.weight" not in m.state_dict()
+    assert m.state_dict()["nerf_mlps.coarse.layers_xyz.0.weight"].shape == (256, 93 + 30 + 76)
+    assert m.state_dict()["hyper_sheep_mlp.fc_ambient.weight"].shape == (1, 64)
+    fw = W.flatten_state_dict(W.hash_state_dict(model="nerface"), model="nerface")
+    assert torch.equal(m.load_flat(fw).flat_params(), torch.from_numpy(fw))
+    bad = sahs.default_config("expression")
+    bad.models.warp.use_warp = False               # config/expression/person_1.yml (no deformation): not built
+    with pytest.raises(NotImplementedError):
+        sahs.NeRFaceModel(bad)
+    with pytest.raises(NotImplementedError):
+        sahs.AudioFaceModel(cfg)

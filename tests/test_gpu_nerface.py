@@ -1,0 +1,154 @@
+"""SURVEY.md section 8f-3 on the MI355X: the expression-driven NeRFaceModel (config/expression/person_2|3.yml) through the same
+C ABI family (sahs_nerface_*), against the reference's golden vectors (tests/golden/nerface_*.npz) and against the NeRFaceModel
+build of the CPU oracle.
+
+Tolerances: this model encodes positions with 15 octaves, so round-off in the warp output (1e-7) is amplified 2^14-fold in
+the top PE features (vs 2^9 for the audio model): `raw` agrees to 2e-3, and the fine pass is additionally ill-conditioned in
+the resampled depths -- the stages are pinned separately, as in tests/test_oracle_nerface_vs_golden.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_rand, load_golden, pkg
+from test_gpu_parity import FeedRand, T, close, dev
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return pkg("ops")
+
+
+@pytest.fixture(scope="module")
+def nf():
+    W = pkg("weights")
+    ops = pkg("ops")
+    cache = {}
+
+    def get(seed=0, density_bias=0.0, density_gain=1.0):
+        key = (int(seed), float(density_bias), float(density_gain))
+        if key not in cache:
+            fw = W.flatten_state_dict(W.hash_state_dict(*key, model="nerface"), model="nerface")
+            flat = T(fw)
+            cache[key] = (fw, flat, ops.pack_weights(flat, arch="nerface"))
+        return cache[key]
+
+    return get
+
+
+def test_sizes_and_errors(ops):
+    assert ops.param_count("nerface") == 2_311_140 and ops.param_count() == 2_775_633
+    with pytest.raises(Exception):
+        ops.pack_weights(torch.zeros(2_775_633, device=dev()), arch="nerface")        # the audio model's buffer
+    with pytest.raises(Exception):
+        ops.pack_weights(torch.zeros(2_311_140, device=dev()), precision=ops.SAHS_BF16, arch="nerface")
+
+
+@pytest.mark.parametrize("variant", ["default", "boosted"])
+def test_field_vs_golden(ops, nf, variant):
+    g = load_golden("nerface_field")
+    kw = dict(default=dict(), boosted=dict(density_bias=8.0, density_gain=30.0))[variant]
+    fw, flat, packed = nf(**kw)
+    frame = ops.fold_conditioning(flat, T(g["expression"]), T(g["pose"]), arch="nerface")
+    assert torch.equal(frame[:76].cpu(), torch.from_numpy(g["expression"]))
+    x = g["x"]
+    P = x.shape[0]
+    rays = np.zeros((P, 8), np.float32)
+    rays[:, :6] = x
+    z = torch.zeros(P, 1, device=dev())
+    raw_c, dx, w, grid = ops.field_forward(packed, frame, 0, T(rays), z, debug=True, arch="nerface")
+    raw_f = ops.field_forward(packed, frame, 1, T(rays), z, arch="nerface")
+    close(dx.view(P, 3), g[variant + "_dx"], 1e-4, 2e-6, "dx")
+    close(w.view(P, 2)[:, :1], g[variant + "_w"], 1e-4, 2e-6, "w")
+    close(grid.view(P, 32), g[variant + "_grid_coarse"], 1e-3, 2e-6, "grid")
+    scale = 30.0 if variant == "boosted" else 1.0
+    for lvl, raw in (("coarse", raw_c), ("fine", raw_f)):
+        raw = raw.view(P, 16)
+        close(raw[:, :15], g[variant + "_raw_" + lvl][:, :15], 2e-3, 2e-3, "raw rgb/seg " + lvl)
+        close(raw[:, 15], g[variant + "_raw_" + lvl][:, 15], 2e-3, 2e-3 * scale, "raw sigma " + lvl)
+
+
+@pytest.mark.parametrize("N,S", [(37, 64), (19, 128), (5, 1), (3, 192)])
+def test_field_vs_oracle(ops, nf, N, S):
+    """Ragged sizes, both levels, rays + depths input (the product entry point), against the NeRFaceModel oracle."""
+    rng = np.random.default_rng(N * 1000 + S)
+    g = load_golden("nerface_field")
+    fw, flat, packed = nf(density_bias=8.0, density_gain=30.0)
+    frame = ops.fold_conditioning(flat, T(g["expression"]), T(g["pose"]), arch="nerface")
+    rays = np.zeros((N, 20), np.float32)
+    rays[:, 0:3] = rng.normal(0, 0.05, (N, 3)) + np.array([0, 0, 0.5])
+    rays[:, 3:6] = rng.normal(0, 0.15, (N, 3)) + np.array([0, 0, -1.0])
+    rays[:, 6], rays[:, 7] = 0.2, 0.8
+    z = np.sort(rng.uniform(0.2, 0.8, (N, S)).astype(np.float32), axis=1)
+    x6 = np.concatenate([rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None], np.broadcast_to(rays[:, None, 3:6], (N, S, 3))], axis=-1)
+    x6 = x6.reshape(-1, 6).astype(np.float32)
+    with oracle.model("nerface"):
+        p36 = oracle.pose_encoding(g["pose"])
+        refs = [oracle.field_forward(fw, level, x6, g["expression"], p36, debug=True) for level in (0, 1)]
+    for level in (0, 1):
+        ref, rdx, rw, rgrid = refs[level]
+        raw, dx, w, grid = ops.field_forward(packed, frame, level, T(rays), T(z), debug=True, arch="nerface")
+        close(dx.reshape(-1, 3), rdx, 1e-4, 2e-6, "dx")
+        close(w.reshape(-1, 2)[:, :1], rw, 1e-4, 2e-6, "w")
+        close(grid.reshape(-1, 32), rgrid, 1e-3, 2e-6, "grid")
+        raw = raw.reshape(-1, 16)
+        close(raw[:, :15], ref[:, :15], 2e-3, 2e-3, "raw rgb/seg level %d" % level)
+        close(raw[:, 15], ref[:, 15], 2e-3, 6e-2, "raw sigma level %d" % level)
+
+
+@pytest.mark.parametrize("name", ["nerface_e2e_val", "nerface_e2e_det"])
+def test_end_to_end_vs_golden(ops, nf, name):
+    sahs = pkg()
+    g = load_golden(name)
+    cfg = sahs.default_config("expression")
+    node = cfg.nerf.validation
+    node.perturb, node.radiance_field_noise_std = bool(g["perturb"]), float(g["noise_std"])
+    assert abs(cfg.dataset.near - float(g["near"])) < 1e-7 and abs(cfg.dataset.far - float(g["far"])) < 1e-7
+    fw, flat, packed = nf(int(g["weights_seed"]), float(g["weights_density_bias"]), float(g["weights_density_gain"]))
+    model = sahs.NeRFaceModel(cfg).to(dev()).load_flat(fw)
+    pose = T(g["pose"])
+    H, Wd = int(g["H"]), int(g["W"])
+    ro, rd = sahs.get_ray_bundle(H, Wd, g["intrinsics"], pose)
+    with torch.no_grad(), FeedRand(golden_rand(g)) as feed:
+        outs = sahs.run_one_iter_of_nerf(H, Wd, g["intrinsics"], model, ro, rd, cfg, mode="validation", driving=T(g["expression"]),
+                                         pose=pose, pose_c=None, background_prior=T(g["bg"]), latent_code=None,
+                                         inHead=torch.zeros(H, Wd, 12, device=dev()))
+        assert not feed.log, "the driver must consume exactly the reference's random draws"
+    names = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"]
+    o = dict(zip(names, outs))
+    for nm in names:
+        assert tuple(o[nm].shape) == tuple(g["out_" + nm].shape), (nm, o[nm].shape)
+    for nm in ("rgb_c", "disp_c", "acc_c"):
+        close(o[nm], g["out_" + nm], 2e-4, 1e-4, name + ":" + nm)
+    for nm in ("rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"):
+        close(o[nm], g["out_" + nm], 1e-2, 3e-3, name + ": chained " + nm)
+    # fine pass on the reference's own depths: field + composite, tight
+    N = H * Wd
+    rays = torch.cat([ro.reshape(-1, 3), rd.reshape(-1, 3), torch.full((N, 1), float(g["near"]), device=dev()),
+                      torch.full((N, 1), float(g["far"]), device=dev())], 1).contiguous()
+    frame = model.frame(T(g["expression"]), pose)
+    zf = T(g["z_fine"])
+    raw = ops.field_forward(packed, frame, 1, rays, zf, arch="nerface")
+    rgb, disp, acc, wts, depth = ops.composite_forward(raw, zf, rays, None, T(g["bg"]), False)
+    for nm, v in (("rgb_f", rgb), ("disp_f", disp), ("acc_f", acc), ("depth_f", depth), ("w_bg", wts[:, -1])):
+        close(v.reshape(g["out_" + nm].shape), g["out_" + nm], 5e-4, 1e-4, name + ": fine pass on reference depths: " + nm)
+
+
+def test_model_seam_and_training_guard(nf):
+    sahs = pkg()
+    cfg = sahs.default_config("expression")
+    fw, flat, packed = nf(density_bias=8.0, density_gain=30.0)
+    model = sahs.NeRFaceModel(cfg).to(dev()).load_flat(fw)
+    g = load_golden("nerface_field")
+    x = T(np.concatenate([g["x"], np.zeros((256, 12), np.float32)], 1))
+    with torch.no_grad():
+        raw = model("coarse", x, T(g["expression"]), T(g["pose"]), None)
+    close(raw[:, :15], g["boosted_raw_coarse"][:, :15], 2e-3, 2e-3, "model(...) seam")
+    with pytest.raises(NotImplementedError):
+        sahs.run_one_iter_of_nerf(0, 0, None, model.train(), x[:8, :3], x[:8, 3:6], cfg, mode="train", driving=T(g["expression"]),
+                                  pose=T(g["pose"]))
+    with pytest.raises(NotImplementedError):
+        sahs.NeRFaceModel(sahs.default_config("audio"))
