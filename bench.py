@@ -31,19 +31,28 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FLOP_PER_SAMPLE = 1_855_744          # BASELINE.md section 3 (GEMM work as the reference writes it)
+FLOP_PER_SAMPLE_NERFACE = 2 * 719_168   # the same count for NeRFaceModel (config/expression/person_2.yml): weights.NERFACE_MAC_PER_SAMPLE
 PEAK_TFLOPS = {"fp32": 157.3,        # MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
                "bf16": 2500.0}       # dense BF16 MFMA peak (never the 2:1-sparse figure)
 KERNEL = {"fp32": "field_forward_f32_kernel", "bf16": "field_forward_bf16_kernel"}
 
 
-def build_inputs(pkg, dev, size, precision, seed=42):
-    cfg = pkg.default_config()
+def build_inputs(pkg, dev, size, precision, seed=42, arch="audio"):
     W = pkg.weights
-    fw = W.flatten_state_dict(W.hash_state_dict(0, 8.0, 30.0))
-    model = pkg.AudioFaceModel(cfg, precision=precision).to(dev).load_flat(fw)
     rng = np.random.default_rng(seed)
-    audio = torch.from_numpy(rng.standard_normal((16, 29)).astype(np.float32)).to(dev)
-    pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], axis=1).astype(np.float32)).to(dev)
+    if arch == "audio":
+        cfg = pkg.default_config()
+        fw = W.flatten_state_dict(W.hash_state_dict(0, 8.0, 30.0))
+        model = pkg.AudioFaceModel(cfg, precision=precision).to(dev).load_flat(fw)
+        audio = torch.from_numpy(rng.standard_normal((16, 29)).astype(np.float32)).to(dev)
+        cam_z = 0.8
+    else:   # expression-driven NeRFaceModel: driving = 76-d expression, near/far 0.2/0.8 (config/expression/person_2.yml:43-45)
+        cfg = pkg.default_config("expression")
+        fw = W.flatten_state_dict(W.hash_state_dict(0, 8.0, 30.0, model="nerface"), model="nerface")
+        model = pkg.NeRFaceModel(cfg, precision=precision).to(dev).load_flat(fw)
+        audio = torch.from_numpy((rng.standard_normal(76) * 0.5).astype(np.float32)).to(dev)
+        cam_z = 0.5
+    pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [cam_z]]], axis=1).astype(np.float32)).to(dev)
     intr = np.array([1200.0 * size / 512, 1200.0 * size / 512, 0.5, 0.5], np.float32)
     R = size * size
     bg = np.concatenate([rng.uniform(0, 1, (R, 3)), np.ones((R, 1)), np.zeros((R, 11))], axis=1).astype(np.float32)
@@ -79,9 +88,10 @@ def main():
     H = W = args.size
     R = H * W
 
-    def measure(precision, steps, warmup):
+    def measure(precision, steps, warmup, arch="audio"):
         """Timed frames of the W512 workload at one precision -> (rays/s, ms/step, roofline dict, inputs)."""
-        cfg, model, fw, audio, pose, intr, bg_all = build_inputs(pkg, dev, args.size, precision)
+        cfg, model, fw, audio, pose, intr, bg_all = build_inputs(pkg, dev, args.size, precision, arch=arch)
+        flop_per_sample = FLOP_PER_SAMPLE if arch == "audio" else FLOP_PER_SAMPLE_NERFACE
         prec = model.precision
         opt = cfg.nerf.validation
         nc, nf, chunk = int(opt.num_coarse), int(opt.num_fine), int(opt.chunksize)
@@ -109,14 +119,14 @@ def main():
                 z_c = ops.stratified_depths(rb, nc, False, t_rand)
                 e0, e1, e2, e3 = ev(), ev(), ev(), ev()
                 e0.record()
-                raw = ops.field_forward(packed, frame, 0, rb, z_c, precision=prec, out=ws.get(("raw", N, nc)))
+                raw = ops.field_forward(packed, frame, 0, rb, z_c, precision=prec, out=ws.get(("raw", N, nc)), arch=arch)
                 e1.record()
                 ws[("raw", N, nc)] = raw
                 rgb_c, disp_c, acc_c, wts, _ = ops.composite_forward(raw, z_c, rb, bg=bgb)
                 u = torch.rand((N, nf), device=dev)
                 z_f = ops.resample(z_c, wts, nf, u=u)
                 e2.record()
-                raw_f = ops.field_forward(packed, frame, 1, rb, z_f, precision=prec, out=ws.get(("raw", N, nc + nf)))
+                raw_f = ops.field_forward(packed, frame, 1, rb, z_f, precision=prec, out=ws.get(("raw", N, nc + nf)), arch=arch)
                 e3.record()
                 ws[("raw", N, nc + nf)] = raw_f
                 rgb_f, disp_f, acc_f, wts_f, depth_f = ops.composite_forward(raw_f, z_f, rb, bg=bgb)
@@ -148,11 +158,11 @@ def main():
             dt = float(t.item())
         assert bool(torch.isfinite(out).all())
         field_ms = sum(a.elapsed_time(b) for a, b, _ in field_events)
-        field_flop = sum(p for _, _, p in field_events) * FLOP_PER_SAMPLE
+        field_flop = sum(p for _, _, p in field_events) * flop_per_sample
         achieved = field_flop / (field_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": KERNEL[precision], "achieved": achieved, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
                 "frac": achieved / PEAK_TFLOPS[precision], "traffic": None, "launches": len(field_events),
-                "avg_launch_ms": field_ms / len(field_events), "flop_per_sample": FLOP_PER_SAMPLE, "field_time_share": field_ms * 1e-3 / dt}
+                "avg_launch_ms": field_ms / len(field_events), "flop_per_sample": flop_per_sample, "field_time_share": field_ms * 1e-3 / dt}
         return R * steps / dt, dt / steps * 1e3, roof, (cfg, fw, audio, pose, intr, bg_all, nc, nf, chunk, near, far)
 
     value, ms_per_step, roof, (cfg, fw, audio, pose, intr, bg_all, nc, nf, chunk, near, far) = measure(args.precision, args.steps, args.warmup)
@@ -176,6 +186,12 @@ def main():
         v2, ms2, roof2, _ = measure("bf16", max(args.steps, 5), 2)
         roof2["traffic"] = 1.074e9 + 0.09e9
         result["bf16"] = {"value": v2, "unit": "rays/s", "ms_per_step": ms2, "dtype": "bf16", "roofline": roof2}
+        # the expression-driven NeRFaceModel (config/expression/person_2.yml: 15-octave encodings, 4x256
+        # trunk) on the same 512x512 / 64+128 frame, fp32 -- a separate model, reported beside the headline
+        v3, ms3, roof3, _ = measure("fp32", args.steps, args.warmup, arch="nerface")
+        result["nerface_fp32"] = {"value": v3, "unit": "rays/s", "ms_per_step": ms3, "dtype": "f32",
+                                  "workload": "512x512 rays, 64+128 evaluations/ray, NeRFaceModel deform(6x128+6x64)+radiance(4x256)",
+                                  "roofline": roof3}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle   # cpu_baseline leg only: the oracle is the thing timed here, never the product path
