@@ -98,7 +98,7 @@ def main():
         lo, hi = pkg.distributed.shard_bounds(R, world, rank)     # this rank's contiguous ray block
         near, far = float(cfg.dataset.near), float(cfg.dataset.far)
         packed, _ = model.packed()
-        torch.manual_seed(cfg.experiment.randomseed + rank)
+        seed = int(cfg.experiment.randomseed)
         ev = lambda: torch.cuda.Event(enable_timing=True)
         field_events = []
         ws = {}
@@ -115,7 +115,7 @@ def main():
                 bgb = bg_all[lo + s: lo + s + rb.shape[0]]
                 N = rb.shape[0]
                 # same launches, in the same order, as sahs_render_rays / predict_and_render_radiance
-                t_rand = torch.rand((N, nc), device=dev)
+                t_rand = ops.ray_uniforms(seed, 0, lo + s, N, nc, dev)     # keyed by global ray index: the frame does not depend on N GPUs
                 z_c = ops.stratified_depths(rb, nc, False, t_rand)
                 e0, e1, e2, e3 = ev(), ev(), ev(), ev()
                 e0.record()
@@ -123,7 +123,7 @@ def main():
                 e1.record()
                 ws[("raw", N, nc)] = raw
                 rgb_c, disp_c, acc_c, wts, _ = ops.composite_forward(raw, z_c, rb, bg=bgb)
-                u = torch.rand((N, nf), device=dev)
+                u = ops.ray_uniforms(seed, 1, lo + s, N, nf, dev)
                 z_f = ops.resample(z_c, wts, nf, u=u)
                 e2.record()
                 raw_f = ops.field_forward(packed, frame, 1, rb, z_f, precision=prec, out=ws.get(("raw", N, nc + nf)), arch=arch)

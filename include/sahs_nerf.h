@@ -54,6 +54,12 @@ int sahs_fold_conditioning(const float *flat_params, const float *audio, const f
 int sahs_get_ray_bundle(int H, int W, float fx, float fy, float cx, float cy, const float *c2w, int ld, float *ro, float *rd,
                         void *stream);
 
+/* Uniform draws in [0,1) for rays [ray0, ray0+N) x S samples -> out (N,S), as a pure function of (seed, stream_id, GLOBAL ray
+ * index, sample index) (Philox4x32-10): the partition-invariant alternative to the reference's `torch.rand(z_vals.shape)`
+ * (train_utils.py:110) and `torch.rand(...)` in sample_pdf_2 (nerf_helpers.py:469), whose values depend on how a frame is
+ * chunked or sharded over GPUs.  stream_id separates the draws of one ray (0: t_rand, 1: u). */
+int sahs_ray_uniforms(uint64_t seed, int stream_id, long ray0, long N, int S, float *out, void *stream);
+
 /* Coarse depths (train_utils.py:93-113). t_rand (N,S) uniform draws or NULL (perturb off). z: (N,S). */
 int sahs_stratified_depths(long N, int S, const float *rays, int ray_stride, int lindisp, const float *t_rand, float *z,
                            void *stream);

@@ -122,6 +122,14 @@ def field_forward(flat, level, x, driving76, pose36, debug=False):
     return (raw, dx, w, g) if debug else raw
 
 
+def ray_uniforms(seed, stream_id, ray0, N, S):
+    """sahs_ray_uniforms restated: (N,S) uniforms keyed by (seed, stream, global ray index, sample)."""
+    out = np.empty((N, S), np.float32)
+    lib().oracle_ray_uniforms(ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), ctypes.c_int(int(stream_id)), ctypes.c_long(int(ray0)),
+                              ctypes.c_long(int(N)), ctypes.c_int(int(S)), _f(out))
+    return out
+
+
 def stratified_depths(near, far, S, lindisp=False, t_rand=None):
     near = _c(np.asarray(near).reshape(-1))
     far = _c(np.asarray(far).reshape(-1))

@@ -487,6 +487,28 @@ void oracle_field_forward(const float *flat, int level, long P, const float *x, 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Partition-invariant uniforms (sahs_ray_uniforms): Philox4x32-10 (Salmon et al. 2011; the published round function and
+ * constants), key = seed, counter = (global ray lo, hi, sample / 4, stream id); word s % 4, top 24 bits -> [0,1).
+ * ---------------------------------------------------------------------------------------- */
+void oracle_ray_uniforms(uint64_t seed, int stream_id, long ray0, long N, int S, float *out)
+{
+    for (long r = 0; r < N; ++r)
+        for (int b = 0; b < (S + 3) / 4; ++b) {
+            uint64_t gr = (uint64_t)(ray0 + r);
+            uint32_t c[4] = {(uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)b, (uint32_t)stream_id};
+            uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+            for (int round = 0; round < 10; ++round) {
+                uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+                uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+                c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+                k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+            }
+            for (int i = 0; i < 4; ++i)
+                if (4 * b + i < S) out[r * S + 4 * b + i] = (float)(c[i] >> 8) * 5.9604644775390625e-08f;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Coarse depths: train_utils.py:93-113.  t=linspace(0,1,S); z=near*(1-t)+far*t (or lindisp);
  * perturb: mids, upper/lower, z = lower + (upper-lower)*t_rand.
  * torch.linspace(0,1,S): step=(1-0)/(S-1); i<S/2 ? start+step*i : end-step*(S-1-i).

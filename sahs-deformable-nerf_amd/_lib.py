@@ -26,6 +26,7 @@ SIGNATURES = {
     "sahs_pack_weights": (_I, [_P, _P, _I, _P]),
     "sahs_fold_conditioning": (_I, [_P, _P, _P, _I, _P, _P]),
     "sahs_get_ray_bundle": (_I, [_I, _I, _F, _F, _F, _F, _P, _I, _P, _P, _P]),
+    "sahs_ray_uniforms": (_I, [ctypes.c_uint64, _I, _L, _L, _I, _P, _P]),
     "sahs_stratified_depths": (_I, [_L, _I, _P, _I, _I, _P, _P, _P]),
     "sahs_field_forward": (_I, [_P, _P, _I, _L, _I, _P, _I, _P, _P, _P, _I, _P]),
     "sahs_composite_forward": (_I, [_L, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P]),

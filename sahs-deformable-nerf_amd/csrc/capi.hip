@@ -33,6 +33,7 @@ int sahs_composite_forward_launch(long N, int S, const float *raw, const float *
                                   float *depth, float *w_last, hipStream_t stream);
 int sahs_resample_launch(long N, int S, int nf, int from_z, const float *z, const float *weights, const float *u, float *z_samples,
                          float *z_out, long long *inds, hipStream_t stream);
+int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, long N, int S, float *out, hipStream_t stream);
 // the NeRFaceModel build of pack.hip / field_f32.hip (sahs_model.hpp: SAHS_MODEL=1, suffix _nf)
 long sahs_layout_param_count_nf(void);
 long sahs_layout_packed_words_f32_nf(void);
@@ -105,6 +106,13 @@ int sahs_get_ray_bundle(int H, int W, float fx, float fy, float cx, float cy, co
     REQUIRE(H > 0 && W > 0 && c2w && ro && rd && ld >= 4, "sahs_get_ray_bundle");
     int e = sahs_ray_bundle_launch(H, W, fx, fy, cx, cy, c2w, ld, ro, rd, (hipStream_t)stream);
     return e ? hip_fail("sahs_get_ray_bundle", e) : 0;
+}
+
+int sahs_ray_uniforms(uint64_t seed, int stream_id, long ray0, long N, int S, float *out, void *stream)
+{
+    REQUIRE(out && N >= 0 && S >= 1 && ray0 >= 0, "sahs_ray_uniforms");
+    int e = sahs_ray_uniforms_launch(seed, stream_id, ray0, N, S, out, (hipStream_t)stream);
+    return e ? hip_fail("sahs_ray_uniforms", e) : 0;
 }
 
 int sahs_stratified_depths(long N, int S, const float *rays, int ray_stride, int lindisp, const float *t_rand, float *z, void *stream)

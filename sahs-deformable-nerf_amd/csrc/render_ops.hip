@@ -30,6 +30,39 @@ __global__ void ray_bundle_kernel(int H, int W, float fx, float fy, float cx, fl
     }
 }
 
+// ---- partition-invariant uniform draws -------------------------------------------
+// The reference draws t_rand / u with torch.rand over the rays of a chunk, so the value a ray gets depends on how the frame
+// was chunked or sharded.  Here a draw is a pure function of (seed, stream id, GLOBAL ray index, sample index):
+// Philox4x32-10 (Salmon et al., SC'11) with key = seed, counter = (ray lo, ray hi, sample / 4, stream id); element s of a ray
+// is word s % 4 of that block, mapped to [0,1) by its top 24 bits.  Integer work: bit-exact against the oracle.
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c[4])
+{
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+        const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += W0; k1 += W1;
+    }
+}
+
+__global__ void ray_uniforms_kernel(unsigned long long seed, int stream_id, long ray0, long N, int S, float *__restrict__ out)
+{
+    const int S4 = (S + 3) / 4;
+    const long total = N * S4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / S4; const int b = (int)(e % S4);
+        const unsigned long long gr = (unsigned long long)(ray0 + r);
+        uint32_t c[4] = {(uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)b, (uint32_t)stream_id};
+        philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * b + i < S) out[r * S + 4 * b + i] = (float)(c[i] >> 8) * 5.9604644775390625e-08f;   // 2^-24
+    }
+}
+
 // ---- coarse depths: train_utils.py:93-113 ----------------------------------------------------
 __device__ __forceinline__ float linspace01(int i, int n)   // torch.linspace(0, 1, n)[i]
 {
@@ -289,5 +322,13 @@ extern "C" int sahs_resample_launch(long N, int S, int nf, int from_z, const flo
     if (S < 3 || S > RS_MAX || nf < 1 || nf > RS_MAX) return -2;
     resample_kernel<<<blocks_for(N, RS_WAVES, 8192), RS_WAVES * 64, 0, stream>>>(N, S, nf, from_z, z, weights, u, z_samples, z_out,
                                                                                  inds);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, long N, int S, float *out, hipStream_t stream)
+{
+    if (N <= 0) return 0;
+    const long total = N * ((S + 3) / 4);
+    ray_uniforms_kernel<<<(unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096), 256, 0, stream>>>(seed, stream_id, ray0, N, S, out);
     return (int)hipGetLastError();
 }

@@ -95,6 +95,15 @@ def get_ray_bundle(height, width, intrinsics, c2w):
     return ro, rd
 
 
+def ray_uniforms(seed, stream_id, ray0, num_rays, num_samples, device):
+    """(num_rays, num_samples) uniforms in [0,1) keyed by (seed, stream_id, global ray index ray0 + r, sample): the same ray
+    gets the same draws however the frame is chunked or sharded."""
+    out = torch.empty(int(num_rays), int(num_samples), dtype=torch.float32, device=device)
+    check(_lib.lib().sahs_ray_uniforms(int(seed) & (2 ** 64 - 1), int(stream_id), int(ray0), int(num_rays), int(num_samples), _p(out), _stream()),
+          "sahs_ray_uniforms")
+    return out
+
+
 def stratified_depths(rays, num_samples, lindisp=False, t_rand=None):
     rays, t_rand = _req(rays, "rays"), _req(t_rand, "t_rand")
     N = rays.shape[0]

@@ -8,10 +8,28 @@ computed once per call instead of once per 131072-point chunk.  Random draws are
 torch.rand/torch.randn in the reference's order and shapes per ray chunk, so a
 seeded generator on the same device gives the same stream.
 """
+import contextlib
+
 import torch
 
 from . import ops
 from .nerf_helpers import get_minibatches
+
+_RAY_RNG = None   # None: torch.rand (the reference's stream) | (seed, first global ray index of the rays passed in)
+
+
+@contextlib.contextmanager
+def partition_invariant_rng(seed, ray_offset=0):
+    """Inside the block the depth-perturbation and importance-sampling draws come from ``ops.ray_uniforms`` -- a pure function of
+    (seed, global ray index, sample) -- instead of ``torch.rand`` over the chunk (train_utils.py:110, nerf_helpers.py:469), so
+    a frame rendered in other chunk sizes or sharded over N GPUs (``ray_offset`` = first ray of this rank's block) is
+    bit-identical.  The radiance noise of training mode stays on torch.randn."""
+    global _RAY_RNG
+    prev, _RAY_RNG = _RAY_RNG, (int(seed), int(ray_offset))
+    try:
+        yield
+    finally:
+        _RAY_RNG = prev
 
 
 def run_network(level, network_fn, pts, ray_batch, chunksize, use_viewdirs, driving=None, pose=None, pose_c=None,
@@ -28,7 +46,7 @@ def run_network(level, network_fn, pts, ray_batch, chunksize, use_viewdirs, driv
 
 def predict_and_render_radiance(ray_batch, model, options, mode="train", driving=None, pose=None, pose_c=None,
                                 background_prior=None, latent_code=None, spatial_embeddings=None, ray_dirs_fake=None,
-                                _frame=None, _workspace=None):
+                                _frame=None, _workspace=None, _ray0=0):
     """train_utils.py:72-206 for one ray chunk -> the 8-tuple
     (rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine, weights_fine[:, -1], depth_fine)."""
     if latent_code is not None:
@@ -44,9 +62,13 @@ def predict_and_render_radiance(ray_batch, model, options, mode="train", driving
     noise_std = float(opt.radiance_field_noise_std)
     nc, nf = int(opt.num_coarse), int(opt.num_fine)
     # draw order of the reference: rand(N,nc) [perturb] -> randn(N,nc) [noise] -> rand(N,nf) [perturb] -> randn(N,nc+nf) [noise]
-    t_rand = torch.rand((N, nc), dtype=torch.float32, device=dev) if opt.perturb else None
+    if _RAY_RNG is None:
+        uniform = lambda stream, n: torch.rand((N, n), dtype=torch.float32, device=dev)
+    else:
+        uniform = lambda stream, n: ops.ray_uniforms(_RAY_RNG[0], stream, _RAY_RNG[1] + _ray0, N, n, dev)
+    t_rand = uniform(0, nc) if opt.perturb else None
     noise_c = torch.randn((N, nc), dtype=torch.float32, device=dev) * noise_std if noise_std > 0.0 else None
-    u = torch.rand((N, nf), dtype=torch.float32, device=dev) if (nf > 0 and opt.perturb != 0.0) else None
+    u = uniform(1, nf) if (nf > 0 and opt.perturb != 0.0) else None
     noise_f = torch.randn((N, nc + nf), dtype=torch.float32, device=dev) * noise_std if (nf > 0 and noise_std > 0.0) else None
     bg = None
     if background_prior is not None:
@@ -89,7 +111,8 @@ def run_one_iter_of_nerf(height, width, focal_length, model, ray_origins, ray_di
     workspace = {}
     pred = [predict_and_render_radiance(b, model, options, mode, driving=driving, pose=pose, pose_c=pose_c,
                                         background_prior=bgs[i] if bgs is not None else None, latent_code=latent_code,
-                                        _frame=frame, _workspace=workspace if len(batches) == 1 or b.shape[0] == chunk else None)
+                                        _frame=frame, _workspace=workspace if len(batches) == 1 or b.shape[0] == chunk else None,
+                                        _ray0=i * chunk)
             for i, b in enumerate(batches)]
     images = [torch.cat(im, dim=0) if im[0] is not None else None for im in zip(*pred)]
     if mode == "validation":

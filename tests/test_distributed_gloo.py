@@ -24,9 +24,9 @@ def _worker(rank, world, port, num_rays, path):
         data = np.load(path)
         from oracle import oracle
 
-        def render(lo, hi):
+        def render(lo, hi):   # draws keyed by GLOBAL ray index (sahs_ray_uniforms restated): no random tensor is shipped or sliced
             o = oracle.render_rays(data["flat"], data["rays"][lo:hi], 8, 8, data["drv"], data["p36"], bg=data["bg"][lo:hi],
-                                   t_rand=data["t_rand"][lo:hi], u=data["u"][lo:hi])
+                                   t_rand=oracle.ray_uniforms(42, 0, lo, hi - lo, 8), u=oracle.ray_uniforms(42, 1, lo, hi - lo, 8))
             return tuple(torch.from_numpy(o[k]) for k in ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"])
 
         full = D.render_sharded(render, num_rays)
@@ -51,11 +51,11 @@ def test_two_rank_ray_sharding(tmp_path, flat_weights, num_rays):
     audio = rng.standard_normal((16, 29)).astype(np.float32)
     pose = np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], axis=1).astype(np.float32)
     d = dict(flat=flat, rays=rays, drv=oracle.audionet(flat, audio), p36=oracle.pose_encoding(pose),
-             bg=rng.uniform(0, 1, (num_rays, 15)).astype(np.float32), t_rand=rng.uniform(0, 1, (num_rays, 8)).astype(np.float32),
-             u=rng.uniform(0, 1, (num_rays, 8)).astype(np.float32))
+             bg=rng.uniform(0, 1, (num_rays, 15)).astype(np.float32))
     path = str(tmp_path / "shard.npz")
     np.savez(path, **d)
-    o = oracle.render_rays(flat, rays, 8, 8, d["drv"], d["p36"], bg=d["bg"], t_rand=d["t_rand"], u=d["u"])
+    o = oracle.render_rays(flat, rays, 8, 8, d["drv"], d["p36"], bg=d["bg"], t_rand=oracle.ray_uniforms(42, 0, 0, num_rays, 8),
+                           u=oracle.ray_uniforms(42, 1, 0, num_rays, 8))
     ref = D.pack_outputs(tuple(torch.from_numpy(o[k]) for k in ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"]))
     assert ref.shape == (num_rays, D.OUT_COLUMNS)
     np.save(path.replace(".npz", "_ref.npy"), ref.numpy())

@@ -361,3 +361,41 @@ def test_gradients_vs_golden(flat_weights, weights_mod):
     ga = audio.grad.cpu().numpy()
     assert float(np.abs(ga - g["grad_audio"]).max()) <= 1e-2 * float(np.abs(g["grad_audio"]).max())
     print("worst gradient error relative to tensor scale: %.3e" % worst)
+
+
+@pytest.mark.parametrize("S,ray0,N", [(64, 0, 1000), (13, 123456789012, 77), (1, 5, 3), (128, 2 ** 40, 130)])
+def test_ray_uniforms_bit_exact(ops, S, ray0, N):
+    """Integer work (Philox4x32-10 keyed by global ray index): bit-exact against the oracle."""
+    for stream in (0, 1):
+        got = ops.ray_uniforms(0x1234567890ABCDEF, stream, ray0, N, S, dev()).cpu().numpy()
+        assert np.array_equal(got, oracle.ray_uniforms(0x1234567890ABCDEF, stream, ray0, N, S))
+
+
+def test_partition_invariant_render(flat_weights):
+    """with the keyed draws a perturbed frame is bit-identical however it is chunked or sharded."""
+    sahs = pkg()
+    TU = pkg("train_utils")
+    cfg = sahs.default_config()
+    model = sahs.AudioFaceModel(cfg).to(dev()).load_flat(flat_weights(0, 8.0, 30.0))
+    g = load_golden("e2e_boosted_val")
+    pose = T(g["pose"])
+    H, Wd = 12, 12
+    ro, rd = sahs.get_ray_bundle(H, Wd, g["intrinsics"], pose)
+    kw = dict(mode="validation", driving=T(g["audio"]), pose=pose, background_prior=T(g["bg"]))
+    with torch.no_grad():
+        with TU.partition_invariant_rng(99):
+            full = sahs.run_one_iter_of_nerf(H, Wd, g["intrinsics"], model, ro, rd, cfg, **kw)
+            cfg.nerf.validation.chunksize = 40                      # 144 rays in chunks of 40: other chunking, same draws
+            chunked = sahs.run_one_iter_of_nerf(H, Wd, g["intrinsics"], model, ro, rd, cfg, **kw)
+            cfg.nerf.validation.chunksize = 131072
+        parts = []
+        for lo, hi in ((0, 50), (50, 144)):                         # two "ranks"
+            with TU.partition_invariant_rng(99, ray_offset=lo):
+                kw2 = dict(kw, background_prior=T(g["bg"])[lo:hi])
+                parts.append(sahs.run_one_iter_of_nerf(H, Wd, g["intrinsics"], model, ro.reshape(-1, 3)[lo:hi], rd.reshape(-1, 3)[lo:hi], cfg, **kw2))
+        other = sahs.run_one_iter_of_nerf(H, Wd, g["intrinsics"], model, ro, rd, cfg, **kw)     # torch.rand: a different frame
+    for i in range(8):
+        a = full[i].reshape(144, -1)
+        assert torch.equal(a, chunked[i].reshape(144, -1)), i
+        assert torch.equal(a, torch.cat([p[i].reshape(p[i].shape[0] if p[i].dim() else 1, -1) for p in parts], 0).reshape(144, -1)), i
+    assert not torch.equal(full[3], other[3])

@@ -142,3 +142,16 @@ def test_end_to_end(flat_weights, name, nchunks):
         close(o, ref, 2e-3, 2e-4, name + ":" + nm)
     if "boosted" in name:
         assert float(np.mean(g["out_w_bg"])) < 0.5, "density-boosted fixture should terminate rays before the background"
+
+
+def test_ray_uniforms_known_answer_and_partition_invariance():
+    """Philox4x32-10: Random123's published known-answer vector for the all-zero counter and key
+    (6627e8d5 e169c58d bc57ac4c 9b00dbd8); a draw is the top 24 bits of its word."""
+    u = oracle.ray_uniforms(0, 0, 0, 1, 4)[0]
+    assert [int(round(float(v) * 2 ** 24)) for v in u] == [w >> 8 for w in (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)]
+    full = oracle.ray_uniforms(7, 1, 0, 10, 13)
+    assert np.array_equal(full[4:], oracle.ray_uniforms(7, 1, 4, 6, 13))          # a shard starting at ray 4 sees the same draws
+    assert np.array_equal(full[:, :8], oracle.ray_uniforms(7, 1, 0, 10, 8))       # and so does a shorter sample count
+    assert not np.array_equal(full, oracle.ray_uniforms(7, 0, 0, 10, 13)) and not np.array_equal(full, oracle.ray_uniforms(8, 1, 0, 10, 13))
+    u = oracle.ray_uniforms(42, 0, 0, 4096, 64)
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1 / 12) < 1e-3
