@@ -119,26 +119,34 @@ int sahs_composite_backward(long N, int S, const float *raw, const float *z, con
 int sahs_conditioning_backward(const float *flat_params, const float *audio, const float *grad_cond, float *grad_flat,
                                float *grad_audio, void *stream);
 
-/* ---- NeRFaceModel: the expression-driven variant of the same path ----
- * Replaces, for `models.type: NeRFaceModel` built from config/expression/person_2.yml / person_3.yml (models.py:189-378:
- * warp + hyper sheet on, 15-octave encodings, 1-D ambient coordinate, 4-layer trunk fed with the 76-d expression), the same
- * seams as the functions above: flat_params is that model's state_dict in order (2,311,140 values; no AudioNet),
- * `expression` (76) takes the place of the audio window (models.py:368 `driving.repeat`), rays/depths/outputs are unchanged,
- * and the model-independent entry points (sahs_get_ray_bundle, sahs_stratified_depths, sahs_composite_forward, sahs_resample,
- * sahs_sample_pdf) are shared.  fp32 (SAHS_F32) forward only in this round. */
-long sahs_nerface_param_count(void);
-long sahs_nerface_packed_words(int precision);
-long sahs_nerface_frame_words(void);
-int sahs_nerface_pack_weights(const float *flat_params, void *packed, int precision, void *stream);
-int sahs_nerface_fold_conditioning(const float *flat_params, const float *expression, const float *pose, int pose_ld, float *frame,
-                                   void *stream);
-int sahs_nerface_field_forward(const void *packed, const float *frame, int level, long N, int S, const float *rays, int ray_stride,
-                               const float *z, float *raw, float *dbg, int precision, void *stream);
-int sahs_nerface_render_rays(const void *packed, const float *frame, int precision, long N, const float *rays, int ray_stride, int Sc,
-                             int nf, int lindisp, int white_background, const float *bg, const float *t_rand, const float *noise_c,
-                             const float *u, const float *noise_f, float *z_c, float *z_f, float *raw, float *weights, float *rgb_c,
-                             float *disp_c, float *acc_c, float *rgb_f, float *disp_f, float *acc_f, float *w_bg, float *depth_f,
-                             void *stream);
+/* ---- every built architecture behind one family ----
+ * The reference builds its field model with getattr(models, cfg.models.mask.type)(cfg) (eval_stage_rays.py:299,
+ * train_stage_rays_auto.py:116); the same path serves
+ *   SAHS_MODEL_AUDIO           AudioFaceModel, config/audio/*.yml (models.py:381-528) -- the functions above;
+ *   SAHS_MODEL_NERFACE         NeRFaceModel, config/expression/person_2.yml / person_3.yml (models.py:189-378): warp + hyper
+ *                              sheet on, 15-octave encodings, 1-D ambient coordinate, 4-layer trunk fed with the expression;
+ *   SAHS_MODEL_NERFACE_STATIC  NeRFaceModel, config/expression/person_1.yml: use_warp False, use_ambient False.
+ * flat_params is that model's state_dict in order (2,775,633 / 2,311,140 / 2,066,976 values); `driving` is the (16,29) audio
+ * window for the AudioFaceModel and the 76-d expression vector (models.py:368 `driving.repeat`) for the NeRFaceModels;
+ * rays, depths and outputs are the same, and sahs_get_ray_bundle, sahs_ray_uniforms, sahs_stratified_depths,
+ * sahs_composite_forward, sahs_resample, sahs_sample_pdf are model-independent.  The NeRFaceModels are built for SAHS_F32
+ * forward (rendering) in this round. */
+#define SAHS_MODEL_AUDIO 0
+#define SAHS_MODEL_NERFACE 1
+#define SAHS_MODEL_NERFACE_STATIC 2
+long sahs_model_param_count(int model);
+long sahs_model_packed_words(int model, int precision);
+long sahs_model_frame_words(int model);
+int sahs_model_pack_weights(int model, const float *flat_params, void *packed, int precision, void *stream);
+int sahs_model_fold_conditioning(int model, const float *flat_params, const float *driving, const float *pose, int pose_ld, float *frame,
+                                 void *stream);
+int sahs_model_field_forward(int model, const void *packed, const float *frame, int level, long N, int S, const float *rays,
+                             int ray_stride, const float *z, float *raw, float *dbg, int precision, void *stream);
+int sahs_model_render_rays(int model, const void *packed, const float *frame, int precision, long N, const float *rays, int ray_stride,
+                           int Sc, int nf, int lindisp, int white_background, const float *bg, const float *t_rand, const float *noise_c,
+                           const float *u, const float *noise_f, float *z_c, float *z_f, float *raw, float *weights, float *rgb_c,
+                           float *disp_c, float *acc_c, float *rgb_f, float *disp_f, float *acc_f, float *w_bg, float *depth_f,
+                           void *stream);
 
 #ifdef __cplusplus
 }

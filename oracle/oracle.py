@@ -14,7 +14,7 @@ import contextlib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
-_SO = {"audio": "liboracle.so", "nerface": "liboracle_nerface.so"}   # sahs_oracle.c built with SAHS_MODEL=0 / 1
+_SO = {"audio": "liboracle.so", "nerface": "liboracle_nerface.so", "nerface_static": "liboracle_nerface_static.so"}   # SAHS_MODEL=0/1/2
 _MODEL = "audio"
 _F = ctypes.POINTER(ctypes.c_float)
 _I64 = ctypes.POINTER(ctypes.c_int64)
@@ -115,7 +115,7 @@ def field_forward(flat, level, x, driving76, pose36, debug=False):
     P, xs = x.shape
     raw = np.empty((P, 16), np.float32)
     dx = np.empty((P, 3), np.float32) if debug else None
-    w = np.empty((P, 2 if _MODEL == "audio" else 1), np.float32) if debug else None
+    w = np.empty((P, {"audio": 2, "nerface": 1, "nerface_static": 0}[_MODEL]), np.float32) if debug else None
     g = np.empty((P, 32), np.float32) if debug else None
     lib().oracle_field_forward(_f(flat), ctypes.c_int(int(level)), ctypes.c_long(P), _f(x), ctypes.c_int(xs),
                                _f(_c(driving76)), _f(_c(pose36)), _f(raw), _f(dx), _f(w), _f(g))

@@ -19,6 +19,7 @@
  *
  * Architectures covered (compile-time switch SAHS_MODEL, one shared object each):
  *   0  AudioFaceModel built from config/audio/person_2_auto.yml (all three config/audio yml files share it);
+ *   2  NeRFaceModel built from config/expression/person_1.yml: no deformation nets, 10 octaves, trunk fed [PE63 | expression];
  *   1  NeRFaceModel built from config/expression/person_2.yml / person_3.yml (models.py:189-370): the same graph with
  *      15-octave position encodings, a 1-D ambient coordinate encoded without its input, a 4-layer trunk fed with the
  *      76-d expression vector instead of the pose encoding, and no AudioNet (the expression IS the driving vector).
@@ -42,7 +43,8 @@
 #define TR_LAYERS 8         /* person_2_auto.yml:78                                          */
 #define TRUNK_SEES_POSE 1   /* models.py:430-470: use_pose=True, include_driving=False       */
 #define HAS_AUDIONET 1
-#else
+#define USE_DEFORM 1
+#elif SAHS_MODEL == 1
 #define L_XYZ 15            /* expression/person_2.yml:70,85,111 num_encoding_fn_xyz          */
 #define L_AMB 15            /* expression/person_2.yml:79 num_encoding_fn_ambient             */
 #define AMB 1               /* expression/person_2.yml:81 ambient_coord_dim                   */
@@ -50,6 +52,16 @@
 #define TR_LAYERS 4         /* expression/person_2.yml:98 num_layers                          */
 #define TRUNK_SEES_POSE 0   /* expression/person_2.yml:124-127: include_driving True, use_pose False */
 #define HAS_AUDIONET 0
+#define USE_DEFORM 1
+#else                       /* 2: NeRFaceModel, config/expression/person_1.yml: use_warp False (:67), use_ambient False (:78) */
+#define L_XYZ 10
+#define L_AMB 0
+#define AMB 0
+#define AMB_INC 0
+#define TR_LAYERS 4
+#define TRUNK_SEES_POSE 0
+#define HAS_AUDIONET 0
+#define USE_DEFORM 0        /* models.py:231,244: no warp_field_mlp / hyper_sheep_mlp modules; map_points returns the points */
 #endif
 #define L_DIR 4             /* person_2_auto.yml:100 num_encoding_fn_dir                     */
 #define L_POSE 3            /* models.py:203-207 encode_pose_fn, include_input=False         */
@@ -97,6 +109,7 @@ static void model_bind(model_t *m, const float *flat)
 {
     const float *p = flat;
     m->grid = take(&p, (long)D_GRID * G_RES * G_RES * G_RES);
+#if USE_DEFORM
     for (int i = 0; i < DEF_LAYERS; ++i) {
         int in = (i == 0) ? D_DEF_IN : (i == DEF_SKIP ? WARP_H + D_DEF_IN : WARP_H);
         m->warp_w[i] = take(&p, (long)WARP_H * in); m->warp_b[i] = take(&p, WARP_H);
@@ -107,6 +120,7 @@ static void model_bind(model_t *m, const float *flat)
         m->hyp_w[i] = take(&p, (long)HYP_H * in); m->hyp_b[i] = take(&p, HYP_H);
     }
     m->hyp_fw = take(&p, AMB * HYP_H); m->hyp_fb = take(&p, AMB);
+#endif
     for (int l = 0; l < 2; ++l) {
         for (int i = 0; i < TR_LAYERS; ++i) {
             int in = (i == 0) ? D_TR_IN : (i == TR_SKIP ? TR_H + D_TR_IN : TR_H);
@@ -277,7 +291,9 @@ static void dense(const float *W, const float *b, int out, int in, const float *
     }
 }
 
+#if USE_DEFORM
 static void act_relu(float *x, int n) { for (int i = 0; i < n * PB; ++i) x[i] = x[i] > 0.0f ? x[i] : 0.0f; }
+#endif
 static void act_lrelu(float *x, int n, float s) { for (int i = 0; i < n * PB; ++i) x[i] = x[i] > 0.0f ? x[i] : x[i] * s; }
 
 /* PE of a d-vector per point, transposed layout: out[(feature)][p] */
@@ -294,6 +310,7 @@ static void pe_block(const float *x /*[d][PB]*/, int d, int L, int include_input
 
 /* WarpFieldMLP / HyperSheetMLP trunk: modules.py:371-388 / 444-460. relu MLP with the
  * skip layer consuming cat(h, initial). */
+#if USE_DEFORM
 static void deform_mlp(const float *const *W, const float *const *B, int hid, const float *in175, float *h /*[hid+175][PB]*/, float *tmp)
 {
     /* layer 0 */
@@ -312,6 +329,7 @@ static void deform_mlp(const float *const *W, const float *const *B, int hid, co
     }
     memcpy(h, tmp, sizeof(float) * hid * PB);
 }
+#endif
 
 /* 5-D grid_sample, bilinear, zeros padding, align_corners=True: models.py:346-365 calling
  * torch.nn.functional.grid_sample (ATen GridSampler.cpp grid_sampler_3d_cpu_impl):
@@ -369,6 +387,7 @@ static void field_block(const model_t *m, int level, const float *x6, int xs, co
     for (int p = 0; p < PB; ++p)
         for (int i = 0; i < 3; ++i) { xyz[i * PB + p] = x6[p * xs + i]; rd[i * PB + p] = x6[p * xs + 3 + i]; }
 
+#if USE_DEFORM
     /* initial = cat(PE(xyz), driving, pose): models.py:303, modules.py:372-381 */
     pe_block(xyz, 3, L_XYZ, 1, in175);
     for (int k = 0; k < D_DRV; ++k) for (int p = 0; p < PB; ++p) in175[(D_XYZ + k) * PB + p] = driving[k];
@@ -389,6 +408,14 @@ static void field_block(const model_t *m, int level, const float *x6, int xs, co
         mapped[(3 + i) * PB + p] = tmp[i * PB + p];
         if (dbg_w) dbg_w[p * AMB + i] = tmp[i * PB + p];
     }
+#else
+    /* use_warp False, use_ambient False: map_points returns the points unchanged (models.py:316-327) */
+    (void)in175; (void)pose36; (void)dbg_w;
+    for (int i = 0; i < 3; ++i) for (int p = 0; p < PB; ++p) {
+        mapped[i * PB + p] = xyz[i * PB + p];
+        if (dbg_dx) dbg_dx[p * 3 + i] = 0.0f;
+    }
+#endif
     /* grid features at the warped point: models.py:525 */
     for (int p = 0; p < PB; ++p) {
         float g[D_GRID];
@@ -397,7 +424,7 @@ static void field_block(const model_t *m, int level, const float *x6, int xs, co
     }
     /* template input: cat(PE10(xyz'), PE4(w), pose36): models.py:332-336, modules.py:255-266 */
     pe_block(mapped, 3, L_XYZ, 1, in117);
-    pe_block(mapped + 3 * PB, AMB, L_AMB, AMB_INC, in117 + D_XYZ * PB);
+    if (AMB > 0) pe_block(mapped + 3 * PB, AMB, L_AMB, AMB_INC, in117 + D_XYZ * PB);
     {   /* AudioFaceModel: pose36 (use_pose); NeRFaceModel: the driving vector (include_driving), modules.py:260-267 */
         const float *cv = TRUNK_SEES_POSE ? pose36 : driving;
         for (int k = 0; k < D_TR_CONST; ++k) for (int p = 0; p < PB; ++p) in117[(D_XYZ + D_AMB + k) * PB + p] = cv[k];

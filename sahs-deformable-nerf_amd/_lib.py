@@ -39,13 +39,13 @@ SIGNATURES = {
     "sahs_field_backward": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
     "sahs_composite_backward": (_I, [_L, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "sahs_conditioning_backward": (_I, [_P, _P, _P, _P, _P, _P]),
-    "sahs_nerface_param_count": (_L, []),
-    "sahs_nerface_packed_words": (_L, [_I]),
-    "sahs_nerface_frame_words": (_L, []),
-    "sahs_nerface_pack_weights": (_I, [_P, _P, _I, _P]),
-    "sahs_nerface_fold_conditioning": (_I, [_P, _P, _P, _I, _P, _P]),
-    "sahs_nerface_field_forward": (_I, [_P, _P, _I, _L, _I, _P, _I, _P, _P, _P, _I, _P]),
-    "sahs_nerface_render_rays": (_I, [_P, _P, _I, _L, _P, _I, _I, _I, _I, _I] + [_P] * 18),
+    "sahs_model_param_count": (_L, [_I]),
+    "sahs_model_packed_words": (_L, [_I, _I]),
+    "sahs_model_frame_words": (_L, [_I]),
+    "sahs_model_pack_weights": (_I, [_I, _P, _P, _I, _P]),
+    "sahs_model_fold_conditioning": (_I, [_I, _P, _P, _P, _I, _P, _P]),
+    "sahs_model_field_forward": (_I, [_I, _P, _P, _I, _L, _I, _P, _I, _P, _P, _P, _I, _P]),
+    "sahs_model_render_rays": (_I, [_I, _P, _P, _I, _L, _P, _I, _I, _I, _I, _I] + [_P] * 18),
 }
 
 _lib = None

@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsahs_nerf.so")
 SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "field_f32.hip", "field_bf16.hip", "field_bwd.hip", "train_bwd.hip"]
-# sources built a second time for the NeRFaceModel architecture (csrc/sahs_model.hpp: -DSAHS_MODEL=1, symbols suffixed _nf)
-MODEL1_SOURCES = ["pack.hip", "field_f32.hip"]
+# sources built again for the NeRFaceModel architectures (csrc/sahs_model.hpp: -DSAHS_MODEL=1 / 2, symbols suffixed _nf / _ns)
+MODEL_SOURCES = ["pack.hip", "field_f32.hip"]
 # field kernels: no sNaN-quieting v_max before every fmaxf (activations); NaNs still propagate through the MFMAs
 FIELD_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-math-errno", "-Wall", "-Wno-unused-function"]
@@ -37,10 +37,10 @@ def build(force=False, verbose=False, defines=(), out=None):
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     procs = []
-    for src, model in [(s, 0) for s in SOURCES] + [(s, 1) for s in MODEL1_SOURCES]:
-        obj = os.path.join(HERE, "build", (os.path.basename(out) + "." if out else "") + src.replace(".hip", ".m1.o" if model else ".o"))
+    for src, model in [(s, 0) for s in SOURCES] + [(s, m) for m in (1, 2) for s in MODEL_SOURCES]:
+        obj = os.path.join(HERE, "build", (os.path.basename(out) + "." if out else "") + src.replace(".hip", ".m%d.o" % model if model else ".o"))
         objs.append(obj)
-        extra = (FIELD_FLAGS if src.startswith("field_") else []) + (["-DSAHS_MODEL=1"] if model else [])
+        extra = (FIELD_FLAGS if src.startswith("field_") else []) + (["-DSAHS_MODEL=%d" % model] if model else [])
         cmd = [hipcc] + FLAGS + extra + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -37,7 +37,14 @@ class CfgNode(dict):
 
 def default_config(kind="audio"):
     """The hot-path subset of ``config/audio/person_2_auto.yml`` (kind="audio") or of ``config/expression/person_2.yml``
-    (kind="expression": NeRFaceModel) -- same keys, same values."""
+    (kind="expression": NeRFaceModel with warp + hyper sheet) or of ``config/expression/person_1.yml`` (kind="expression_static":
+    both off) -- same keys, same values."""
     import os
-    return CfgNode.load_yaml(os.path.join(os.path.dirname(__file__), "config", {"audio": "audio_hotpath.yml",
-                                                                                "expression": "expression_hotpath.yml"}[kind]))
+    cfg = CfgNode.load_yaml(os.path.join(os.path.dirname(__file__), "config", {"audio": "audio_hotpath.yml", "expression": "expression_hotpath.yml",
+                                                                               "expression_static": "expression_hotpath.yml"}[kind]))
+    if kind == "expression_static":   # person_1.yml differs from person_2.yml in exactly these keys (the hot path reads)
+        cfg.models.warp.use_warp, cfg.models.hyper.use_ambient = False, False
+        for node in (cfg.models.warp, cfg.models.hyper, cfg.models.coarse, cfg.models.fine):
+            node.num_encoding_fn_xyz = 10
+        cfg.models.hyper.num_encoding_fn_ambient = 4
+    return cfg

@@ -34,15 +34,20 @@ int sahs_composite_forward_launch(long N, int S, const float *raw, const float *
 int sahs_resample_launch(long N, int S, int nf, int from_z, const float *z, const float *weights, const float *u, float *z_samples,
                          float *z_out, long long *inds, hipStream_t stream);
 int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, long N, int S, float *out, hipStream_t stream);
-// the NeRFaceModel build of pack.hip / field_f32.hip (sahs_model.hpp: SAHS_MODEL=1, suffix _nf)
-long sahs_layout_param_count_nf(void);
-long sahs_layout_packed_words_f32_nf(void);
-long sahs_layout_frame_words_nf(void);
-int sahs_pack_weights_f32_launch_nf(const float *flat, float *packed, hipStream_t stream);
-int sahs_fold_conditioning_launch_nf(const float *flat, const float *expression, const float *pose, int pose_ld, float *frame,
-                                     hipStream_t stream);
-int sahs_field_forward_f32_launch_nf(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
-                                     const float *zvals, float *raw, float *dbg, float *actbuf, int num_cu, hipStream_t stream);
+// the NeRFaceModel builds of pack.hip / field_f32.hip (sahs_model.hpp: SAHS_MODEL=1 suffix _nf, SAHS_MODEL=2 suffix _ns)
+#define SAHS_DECLARE_MODEL(sfx)                                                                                                      \
+    long sahs_layout_param_count##sfx(void);                                                                                        \
+    long sahs_layout_packed_words_f32##sfx(void);                                                                                   \
+    long sahs_layout_frame_words##sfx(void);                                                                                        \
+    int sahs_pack_weights_f32_launch##sfx(const float *flat, float *packed, hipStream_t stream);                                   \
+    int sahs_fold_conditioning_launch##sfx(const float *flat, const float *driving, const float *pose, int pose_ld, float *frame,  \
+                                           hipStream_t stream);                                                                     \
+    int sahs_field_forward_f32_launch##sfx(const float *packed, const float *frame, int level, long P, int S, const float *rays,   \
+                                           int ray_stride, const float *zvals, float *raw, float *dbg, float *actbuf, int num_cu,   \
+                                           hipStream_t stream);
+SAHS_DECLARE_MODEL()
+SAHS_DECLARE_MODEL(_nf)
+SAHS_DECLARE_MODEL(_ns)
 }
 
 static thread_local char g_err[512] = "";
@@ -249,47 +254,89 @@ int sahs_render_rays(const void *packed, const float *frame, int precision, long
                              acc_f, w_bg, depth_f, stream);
 }
 
-// ---- NeRFaceModel (expression configs): same boundary, its own weight/frame layouts; fp32 forward ----
-long sahs_nerface_param_count(void) { return sahs_layout_param_count_nf(); }
-long sahs_nerface_packed_words(int precision) { return precision == SAHS_F32 ? sahs_layout_packed_words_f32_nf() : -1; }
-long sahs_nerface_frame_words(void) { return sahs_layout_frame_words_nf(); }
+// ---- every built architecture behind one family: sahs_model_*(model, ...) ----
+// model: SAHS_MODEL_AUDIO (the functions above), SAHS_MODEL_NERFACE (config/expression/person_2|3.yml),
+// SAHS_MODEL_NERFACE_STATIC (config/expression/person_1.yml: no warp, no hyper sheet).  fp32 forward for the NeRFaceModels.
+struct ModelFns {
+    long (*param_count)(void);
+    long (*packed_words_f32)(void);
+    long (*frame_words)(void);
+    int (*pack_f32)(const float *, float *, hipStream_t);
+    int (*fold)(const float *, const float *, const float *, int, float *, hipStream_t);
+    int (*field_f32)(const float *, const float *, int, long, int, const float *, int, const float *, float *, float *, float *, int, hipStream_t);
+};
+static const ModelFns kModels[3] = {
+    {sahs_layout_param_count, sahs_layout_packed_words_f32, sahs_layout_frame_words, sahs_pack_weights_f32_launch,
+     sahs_fold_conditioning_launch, sahs_field_forward_f32_launch},
+    {sahs_layout_param_count_nf, sahs_layout_packed_words_f32_nf, sahs_layout_frame_words_nf, sahs_pack_weights_f32_launch_nf,
+     sahs_fold_conditioning_launch_nf, sahs_field_forward_f32_launch_nf},
+    {sahs_layout_param_count_ns, sahs_layout_packed_words_f32_ns, sahs_layout_frame_words_ns, sahs_pack_weights_f32_launch_ns,
+     sahs_fold_conditioning_launch_ns, sahs_field_forward_f32_launch_ns},
+};
+#define REQUIRE_MODEL(m, name) do { if ((m) < 0 || (m) > 2) return fail(3, "%s: unknown model %ld", name, (long)(m)); } while (0)
 
-int sahs_nerface_pack_weights(const float *flat_params, void *packed, int precision, void *stream)
+long sahs_model_param_count(int model) { return (model < 0 || model > 2) ? -1 : kModels[model].param_count(); }
+long sahs_model_packed_words(int model, int precision)
 {
-    REQUIRE(flat_params && packed && ALIGNED16(packed), "sahs_nerface_pack_weights");
-    if (precision != SAHS_F32) return fail(2, "sahs_nerface_pack_weights: only SAHS_F32 is built for this model %s%ld", "", precision);
-    int e = sahs_pack_weights_f32_launch_nf(flat_params, (float *)packed, (hipStream_t)stream);
-    return e ? hip_fail("sahs_nerface_pack_weights", e) : 0;
+    if (model < 0 || model > 2) return -1;
+    if (model == SAHS_MODEL_AUDIO) return sahs_packed_words(precision);
+    return precision == SAHS_F32 ? kModels[model].packed_words_f32() : -1;
+}
+long sahs_model_frame_words(int model) { return (model < 0 || model > 2) ? -1 : kModels[model].frame_words(); }
+
+int sahs_model_pack_weights(int model, const float *flat_params, void *packed, int precision, void *stream)
+{
+    REQUIRE_MODEL(model, "sahs_model_pack_weights");
+    if (model == SAHS_MODEL_AUDIO) return sahs_pack_weights(flat_params, packed, precision, stream);
+    REQUIRE(flat_params && packed && ALIGNED16(packed), "sahs_model_pack_weights");
+    if (precision != SAHS_F32) return fail(2, "sahs_model_pack_weights: only SAHS_F32 is built for this model %s%ld", "", precision);
+    int e = kModels[model].pack_f32(flat_params, (float *)packed, (hipStream_t)stream);
+    return e ? hip_fail("sahs_model_pack_weights", e) : 0;
 }
 
-int sahs_nerface_fold_conditioning(const float *flat_params, const float *expression, const float *pose, int pose_ld, float *frame,
-                                   void *stream)
+int sahs_model_fold_conditioning(int model, const float *flat_params, const float *driving, const float *pose, int pose_ld, float *frame,
+                                 void *stream)
 {
-    REQUIRE(flat_params && expression && pose && frame && pose_ld >= 4 && ALIGNED16(frame), "sahs_nerface_fold_conditioning");
-    int e = sahs_fold_conditioning_launch_nf(flat_params, expression, pose, pose_ld, frame, (hipStream_t)stream);
-    return e ? hip_fail("sahs_nerface_fold_conditioning", e) : 0;
+    REQUIRE_MODEL(model, "sahs_model_fold_conditioning");
+    REQUIRE(flat_params && driving && pose && frame && pose_ld >= 4 && ALIGNED16(frame), "sahs_model_fold_conditioning");
+    int e = kModels[model].fold(flat_params, driving, pose, pose_ld, frame, (hipStream_t)stream);
+    return e ? hip_fail("sahs_model_fold_conditioning", e) : 0;
 }
 
-int sahs_nerface_field_forward(const void *packed, const float *frame, int level, long N, int S, const float *rays, int ray_stride,
-                               const float *z, float *raw, float *dbg, int precision, void *stream)
+static int field_forward_model(int model, const void *packed, const float *frame, int level, long N, int S, const float *rays,
+                               int ray_stride, const float *z, float *raw, float *dbg, int precision, void *stream)
 {
-    REQUIRE(packed && frame && rays && z && raw, "sahs_nerface_field_forward");
-    REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_nerface_field_forward(shape)");
-    REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_nerface_field_forward(alignment)");
-    if (precision != SAHS_F32) return fail(2, "sahs_nerface_field_forward: only SAHS_F32 is built for this model %s%ld", "", precision);
-    int e = sahs_field_forward_f32_launch_nf((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, nullptr, num_cus(),
-                                             (hipStream_t)stream);
-    return e ? hip_fail("sahs_nerface_field_forward", e) : 0;
+    if (model == SAHS_MODEL_AUDIO) return sahs_field_forward(packed, frame, level, N, S, rays, ray_stride, z, raw, dbg, precision, stream);
+    REQUIRE(packed && frame && rays && z && raw, "sahs_model_field_forward");
+    REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_model_field_forward(shape)");
+    REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_model_field_forward(alignment)");
+    if (precision != SAHS_F32) return fail(2, "sahs_model_field_forward: only SAHS_F32 is built for this model %s%ld", "", precision);
+    int e = kModels[model].field_f32((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, nullptr, num_cus(),
+                                     (hipStream_t)stream);
+    return e ? hip_fail("sahs_model_field_forward", e) : 0;
 }
 
-int sahs_nerface_render_rays(const void *packed, const float *frame, int precision, long N, const float *rays, int ray_stride, int Sc, int nf,
-                             int lindisp, int white_background, const float *bg, const float *t_rand, const float *noise_c, const float *u,
-                             const float *noise_f, float *z_c, float *z_f, float *raw, float *weights, float *rgb_c, float *disp_c,
-                             float *acc_c, float *rgb_f, float *disp_f, float *acc_f, float *w_bg, float *depth_f, void *stream)
+int sahs_model_field_forward(int model, const void *packed, const float *frame, int level, long N, int S, const float *rays, int ray_stride,
+                             const float *z, float *raw, float *dbg, int precision, void *stream)
 {
-    return render_rays_chain(sahs_nerface_field_forward, "sahs_nerface_render_rays", packed, frame, precision, N, rays, ray_stride, Sc, nf,
-                             lindisp, white_background, bg, t_rand, noise_c, u, noise_f, z_c, z_f, raw, weights, rgb_c, disp_c, acc_c, rgb_f,
-                             disp_f, acc_f, w_bg, depth_f, stream);
+    REQUIRE_MODEL(model, "sahs_model_field_forward");
+    return field_forward_model(model, packed, frame, level, N, S, rays, ray_stride, z, raw, dbg, precision, stream);
+}
+
+static int field_nf(const void *pk, const float *fr, int lv, long N, int S, const float *r, int rs, const float *z, float *raw, float *dbg, int pr, void *st)
+{ return field_forward_model(SAHS_MODEL_NERFACE, pk, fr, lv, N, S, r, rs, z, raw, dbg, pr, st); }
+static int field_ns(const void *pk, const float *fr, int lv, long N, int S, const float *r, int rs, const float *z, float *raw, float *dbg, int pr, void *st)
+{ return field_forward_model(SAHS_MODEL_NERFACE_STATIC, pk, fr, lv, N, S, r, rs, z, raw, dbg, pr, st); }
+
+int sahs_model_render_rays(int model, const void *packed, const float *frame, int precision, long N, const float *rays, int ray_stride,
+                           int Sc, int nf, int lindisp, int white_background, const float *bg, const float *t_rand, const float *noise_c,
+                           const float *u, const float *noise_f, float *z_c, float *z_f, float *raw, float *weights, float *rgb_c,
+                           float *disp_c, float *acc_c, float *rgb_f, float *disp_f, float *acc_f, float *w_bg, float *depth_f, void *stream)
+{
+    REQUIRE_MODEL(model, "sahs_model_render_rays");
+    field_fn_t f = model == SAHS_MODEL_AUDIO ? sahs_field_forward : (model == SAHS_MODEL_NERFACE ? field_nf : field_ns);
+    return render_rays_chain(f, "sahs_model_render_rays", packed, frame, precision, N, rays, ray_stride, Sc, nf, lindisp, white_background, bg,
+                             t_rand, noise_c, u, noise_f, z_c, z_f, raw, weights, rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_bg, depth_f, stream);
 }
 
 }  // extern "C"

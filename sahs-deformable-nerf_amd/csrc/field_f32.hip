@@ -274,9 +274,9 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
     {   // per-level biases (static + folded conditioning) -> LDS, first weight chunk -> buffer 0
         const float *bsrc = frame + FRAME_BIAS_OFF + level * BIAS_FLOATS;
         for (int i = threadIdx.x; i < BIAS_FLOATS; i += F32_THREADS) lds[LDS_BIAS_OFF + i] = bsrc[i];
-        cx.begin_chunk(CHF(L_W0));
+        cx.begin_chunk(CHF(L_FIRST));
 #pragma unroll
-        for (int pc = 0; pc < (CHF(L_W0) + PIECE_FLOATS - 1) / PIECE_FLOATS; ++pc) cx.issue_piece(pc);
+        for (int pc = 0; pc < (CHF(L_FIRST) + PIECE_FLOATS - 1) / PIECE_FLOATS; ++pc) cx.issue_piece(pc);
         cx.end_chunk();
     }
     constexpr const Layer *Ly = kProg.layer;
@@ -293,13 +293,19 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         float *dsl = dbg + p * DBG_STRIDE;
         float *sv = (SAVE && p_raw < P) ? actbuf + p * (long)act::STRIDE + 4 * q : nullptr;   // this lane's slot in its sample's row
 #define SV(off) (SAVE && sv != nullptr ? sv + (off) : nullptr)
-        f32x4 pe_x[KB_XYZ];
         float x[3];
         {
             const float *rp = rays + (p / S) * ray_stride;
             const float z = zvals[p];
 #pragma unroll
             for (int i = 0; i < 3; ++i) x[i] = rp[i] + rp[3 + i] * z;          // train_utils.py:115
+        }
+#if SAHS_MODEL == 2
+        // no deformation nets (use_warp False, use_ambient False): the template is queried at the raw point (models.py:316-327)
+        if (q == 0) { stash[0] = x[0]; stash[1] = x[1]; stash[2] = x[2]; stash[3] = 0.0f; stash[4] = 0.0f; }
+#else
+        f32x4 pe_x[KB_XYZ];
+        {
             pe_blocks<3, L_XYZ, KB_XYZ>(x, q, pe_x);
             if (SAVE && sv != nullptr) {
 #pragma unroll
@@ -363,6 +369,7 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                 if (SAVE && sv != nullptr) { sv[act::AW] = o[0][0]; sv[act::AW + 1] = stash[4]; }
             }
         }
+#endif
         __builtin_amdgcn_wave_barrier();
         if (dump) { dsl[0] = stash[0] - x[0]; dsl[1] = stash[1] - x[1]; dsl[2] = stash[2] - x[2]; dsl[3] = stash[3]; dsl[4] = stash[4]; }
 
@@ -375,7 +382,11 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                 f32x4 in_tr[KB_XYZ + KB_AMB];
                 const float xw[3] = {stash[0], stash[1], stash[2]}, amb[2] = {stash[3], stash[4]};
                 pe_blocks<3, L_XYZ, KB_XYZ>(xw, q, in_tr);
+#if SAHS_MODEL != 2
                 pe_blocks<AMB_DIM, L_AMB, KB_AMB, AMB_INC>(amb, q, in_tr + KB_XYZ);
+#else
+                (void)amb;
+#endif
                 if (SAVE && sv != nullptr) {
 #pragma unroll
                     for (int b = 0; b < KB_XYZ + KB_AMB; ++b) *reinterpret_cast<f32x4 *>(sv + act::PEX + 16 * b) = in_tr[b];   // PEX blocks then PEW
@@ -395,7 +406,11 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                 f32x4 in_tr[KB_XYZ + KB_AMB];
                 const float xw[3] = {stash[0], stash[1], stash[2]}, amb[2] = {stash[3], stash[4]};
                 pe_blocks<3, L_XYZ, KB_XYZ>(xw, q, in_tr);
+#if SAHS_MODEL != 2
                 pe_blocks<AMB_DIM, L_AMB, KB_AMB, AMB_INC>(amb, q, in_tr + KB_XYZ);
+#else
+                (void)amb;
+#endif
                 dense<KB_XYZ, KB_AMB, 16, CHF(L_T3A)>(cx, in_tr, in_tr + KB_XYZ, feat, Ly[L_T3B].bias_off, false, 1.0f);
             }
 #if SAHS_MODEL == 0
@@ -466,7 +481,7 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
             }
             dense<8, 0, 8, CHF(L_SEG)>(cx, s, nullptr, sn, Ly[L_S3].bias_off, false, 0.01f, SV(act::S + 384));
             if (dump) dsl[17] = sn[0][0];
-            dense<8, 0, 1, CHF(L_W0)>(cx, sn, nullptr, fin, 0, true, 1.0f);
+            dense<8, 0, 1, CHF(L_FIRST)>(cx, sn, nullptr, fin, 0, true, 1.0f);
         }
         if (p_raw < P) *reinterpret_cast<f32x4 *>(raw + p * D_RAW + 4 * q) = fin[0];   // cat((rgb, seg, alpha)) modules.py:295
     }

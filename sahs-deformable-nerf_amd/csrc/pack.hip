@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) fold_conditioning_kernel(const float *__r
 {
     __shared__ float a[64 * 16], b[64 * 16], drv[D_DRV], p36[D_POSE];
     const int tid = threadIdx.x;
-#if SAHS_MODEL == 1
+#if SAHS_MODEL != 0
     // NeRFaceModel: the driving vector is the 76-d expression itself (models.py:368); `audio` points at it
     (void)a; (void)b;
     if (tid < D_DRV) { drv[tid] = audio[tid]; frame[FRAME_DRV_OFF + tid] = audio[tid]; }

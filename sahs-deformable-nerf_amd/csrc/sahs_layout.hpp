@@ -25,13 +25,18 @@ namespace SAHS_NS {
 // AudioFaceModel, config/audio/person_2_auto.yml: 10-octave position encoding, 2-D ambient coordinate
 // encoded with its input (4 octaves), 8-layer trunk fed [PE63(x') | PE18(w) | pose36]; driving = AudioNet(audio window).
 constexpr int L_XYZ = 10, AMB_DIM = 2, L_AMB = 4, AMB_INC = 1, TR_LAYERS = 8;
-constexpr bool TRUNK_SEES_POSE = true, HAS_AUDIONET = true;
-#else
+constexpr bool TRUNK_SEES_POSE = true, HAS_AUDIONET = true, USE_DEFORM = true;
+#elif SAHS_MODEL == 1
 // NeRFaceModel, config/expression/person_2.yml / person_3.yml (models.py:189-299): 15 octaves, 1-D ambient coordinate
 // encoded WITHOUT its input (15 octaves), 4-layer trunk fed [PE93(x') | PE30(w) | expression76] (include_driving, no
 // pose); the deformation nets still take [PE93 | expression76 | pose36] (modules.py:344: dim_pose = include_pose + 36).
 constexpr int L_XYZ = 15, AMB_DIM = 1, L_AMB = 15, AMB_INC = 0, TR_LAYERS = 4;
-constexpr bool TRUNK_SEES_POSE = false, HAS_AUDIONET = false;
+constexpr bool TRUNK_SEES_POSE = false, HAS_AUDIONET = false, USE_DEFORM = true;
+#else
+// NeRFaceModel, config/expression/person_1.yml ("nohyper_nodeform": warp.use_warp False, hyper.use_ambient False): no
+// deformation nets in the state_dict, the grid is sampled at the raw point, 4-layer trunk fed [PE63(x) | expression76].
+constexpr int L_XYZ = 10, AMB_DIM = 0, L_AMB = 0, AMB_INC = 0, TR_LAYERS = 4;
+constexpr bool TRUNK_SEES_POSE = false, HAS_AUDIONET = false, USE_DEFORM = false;
 #endif
 constexpr int D_XYZ = 3 + 6 * L_XYZ;                             // 63 | 93
 constexpr int D_AMB = AMB_INC * AMB_DIM + 2 * AMB_DIM * L_AMB;   // 18 | 30
@@ -63,16 +68,18 @@ constexpr FlatOffsets make_flat_offsets()
     FlatOffsets f{};
     long p = 0;
     f.grid = p; p += GRID_FLOATS;
-    for (int i = 0; i < 6; ++i) {
-        int in = (i == 0) ? D_DEF_IN : (i == 4 ? WARP_H + D_DEF_IN : WARP_H);
-        f.warp_w[i] = p; p += (long)WARP_H * in; f.warp_b[i] = p; p += WARP_H;
+    if (USE_DEFORM) {
+        for (int i = 0; i < 6; ++i) {
+            int in = (i == 0) ? D_DEF_IN : (i == 4 ? WARP_H + D_DEF_IN : WARP_H);
+            f.warp_w[i] = p; p += (long)WARP_H * in; f.warp_b[i] = p; p += WARP_H;
+        }
+        f.warp_fw = p; p += 3 * WARP_H; f.warp_fb = p; p += 3;
+        for (int i = 0; i < 6; ++i) {
+            int in = (i == 0) ? D_DEF_IN : (i == 4 ? HYP_H + D_DEF_IN : HYP_H);
+            f.hyp_w[i] = p; p += (long)HYP_H * in; f.hyp_b[i] = p; p += HYP_H;
+        }
+        f.hyp_fw = p; p += AMB_DIM * HYP_H; f.hyp_fb = p; p += AMB_DIM;
     }
-    f.warp_fw = p; p += 3 * WARP_H; f.warp_fb = p; p += 3;
-    for (int i = 0; i < 6; ++i) {
-        int in = (i == 0) ? D_DEF_IN : (i == 4 ? HYP_H + D_DEF_IN : HYP_H);
-        f.hyp_w[i] = p; p += (long)HYP_H * in; f.hyp_b[i] = p; p += HYP_H;
-    }
-    f.hyp_fw = p; p += AMB_DIM * HYP_H; f.hyp_fb = p; p += AMB_DIM;
     for (int l = 0; l < 2; ++l) {
         for (int i = 0; i < TR_LAYERS; ++i) {
             int in = (i == 0) ? D_TR_IN : (i == 3 ? TR_H + D_TR_IN : TR_H);
@@ -101,7 +108,8 @@ constexpr FlatOffsets make_flat_offsets()
     return f;
 }
 constexpr FlatOffsets kFlat = make_flat_offsets();
-static_assert(kFlat.total == (SAHS_MODEL == 0 ? 2775633 : 2311140), "flat parameter count must match the reference state_dict");
+static_assert(kFlat.total == (SAHS_MODEL == 0 ? 2775633 : (SAHS_MODEL == 1 ? 2311140 : 2066976)),
+              "flat parameter count must match the reference state_dict");
 
 // ---- layer program -------------------------------------------------------------------------
 // A layer consumes up to 2 input segments (each a whole number of 16-feature k-blocks, zero
@@ -116,8 +124,10 @@ static_assert(kFlat.total == (SAHS_MODEL == 0 ? 2775633 : 2311140), "flat parame
 struct Seg { int blocks; int src_col; int valid; };          // k-blocks, first source column, #valid columns
 struct Fold { int src_col; int count; int which; };          // which: 0 = driving[76], 1 = pose36
 enum LayerId {   // enum order == execution order == stream order
+#if SAHS_MODEL != 2
     L_W0, L_W1, L_W2, L_W3, L_W4B, L_W4A, L_W5, L_WF,
     L_H0, L_H1, L_H2, L_H3, L_H4B, L_H4A, L_H5, L_HF,
+#endif
     L_T0, L_T1, L_T2, L_T3B, L_T3A,
 #if SAHS_MODEL == 0
     L_T4, L_T5, L_T6, L_T7,
@@ -125,7 +135,8 @@ enum LayerId {   // enum order == execution order == stream order
     L_FEAT, L_ALPHA,
     L_D0B, L_D0A, L_D1, L_D2, L_D3, L_RGB,
     L_S0, L_S1, L_S2, L_S3, L_SEG,
-    NUM_LAYERS
+    NUM_LAYERS,
+    L_FIRST = 0      // the stream wraps from L_SEG to this layer
 };
 struct Layer {
     long w_off[2];     // offset of the weight tensor in the flat buffer, per level
@@ -184,6 +195,7 @@ constexpr Program make_program()
     Layer *L = P.layer;
     // deformation nets (shared by both levels).  Source columns: [PE63 | driving76 | pose36],
     // skip layer 4: [h | PE63 | driving76 | pose36]  (modules.py:372-387, 445-459)
+#if SAHS_MODEL != 2
     auto warp = [&](int i, int ld) { return Src{f.warp_w[i], f.warp_w[i], f.warp_b[i], f.warp_b[i], ld, WARP_H}; };
     auto hyp = [&](int i, int ld) { return Src{f.hyp_w[i], f.hyp_w[i], f.hyp_b[i], f.hyp_b[i], ld, HYP_H}; };
     L[L_W0] = mk(warp(0, D_DEF_IN), 1, 0, 8, {KB_XYZ, 0, D_XYZ}, {0, 0, 0}, {D_XYZ, D_DRV, 0}, {D_XYZ + D_DRV, D_POSE, 1});
@@ -204,6 +216,7 @@ constexpr Program make_program()
     L[L_H4A] = mk(hyp(4, HYP_H + D_DEF_IN), 0, 0, 4, {4, 0, 64});
     L[L_H5] = mk(hyp(5, HYP_H), 1, 0, 4, {4, 0, 64});
     L[L_HF] = mk(Src{f.hyp_fw, f.hyp_fw, f.hyp_fb, f.hyp_fb, HYP_H, AMB_DIM}, 1, 0, 1, {4, 0, 64});
+#endif
     // radiance trunk.  Source columns: [PE(x') | PE(w) | pose36 or driving76 (model)]; skip layer 3: [h | same]
     // (modules.py:255-273; skip index is NeRFMLP's default 3, models.py never forwards the YAML's 4)
     const FlatOffsets::Lvl &c = f.lvl[0], &n = f.lvl[1];
@@ -281,8 +294,10 @@ namespace SAHS_NS {
 namespace hb {
 
 enum LayerIdH {
+#if SAHS_MODEL != 2
     H_W0, H_W1, H_W2, H_W3, H_W4, H_W5, H_WF,
     H_H0, H_H1, H_H2, H_H3, H_H4, H_H5, H_HF,
+#endif
     H_T0, H_T1, H_T2, H_T3,
 #if SAHS_MODEL == 0
     H_T4, H_T5, H_T6, H_T7,
@@ -341,10 +356,12 @@ constexpr ProgramH make_program_h()
     ProgramH P{};
     const Layer *L = kProg.layer;
     LayerH *H = P.layer;
+#if SAHS_MODEL != 2
     H[H_W0] = from1(L[L_W0]); H[H_W1] = from1(L[L_W1]); H[H_W2] = from1(L[L_W2]); H[H_W3] = from1(L[L_W3]);
     H[H_W4] = from2(L[L_W4B], L[L_W4A]); H[H_W5] = from1(L[L_W5]); H[H_WF] = from1(L[L_WF]);
     H[H_H0] = from1(L[L_H0]); H[H_H1] = from1(L[L_H1]); H[H_H2] = from1(L[L_H2]); H[H_H3] = from1(L[L_H3]);
     H[H_H4] = from2(L[L_H4B], L[L_H4A]); H[H_H5] = from1(L[L_H5]); H[H_HF] = from1(L[L_HF]);
+#endif
     H[H_T0] = from1(L[L_T0]); H[H_T1] = from1(L[L_T1]); H[H_T2] = from1(L[L_T2]);
     H[H_T3] = from2(L[L_T3B], L[L_T3A]);
 #if SAHS_MODEL == 0

@@ -52,12 +52,15 @@ class _AudioNet(nn.Module):
         self.encoder_fc1 = nn.Sequential(nn.Linear(64, 64), act(), nn.Linear(64, W.D_DRV))
 
 
+def _radiance_cfg(m):
+    return [(m.coarse.hidden_size, 256), (m.coarse.include_input_xyz, True), (m.coarse.num_encoding_fn_dir, 4),
+            (m.coarse.include_input_dir, True), (m.coarse.use_viewdirs, True), (m.coarse.use_spatial_embeddings, True)]
+
+
 def _common_cfg(m):
     return [(m.warp.use_warp, True), (m.warp.num_layers, 6), (m.warp.hidden_size, 128), (m.warp.skip_connect_every, 4),
             (m.hyper.use_ambient, True), (m.hyper.slice_method, "bendy_sheet"), (m.hyper.num_layers, 6), (m.hyper.hidden_size, 64),
-            (m.hyper.skip_connect_every, 4), (m.hyper.include_driving, True), (m.coarse.hidden_size, 256),
-            (m.coarse.include_input_xyz, True), (m.coarse.num_encoding_fn_dir, 4), (m.coarse.include_input_dir, True),
-            (m.coarse.use_viewdirs, True), (m.coarse.use_spatial_embeddings, True)]
+            (m.hyper.skip_connect_every, 4), (m.hyper.include_driving, True)] + _radiance_cfg(m)
 
 
 def _check_cfg(cfg, arch):
@@ -68,15 +71,18 @@ def _check_cfg(cfg, arch):
         want = _common_cfg(m) + [(m.warp.num_encoding_fn_xyz, 10), (m.hyper.ambient_coord_dim, 2), (m.hyper.num_encoding_fn_ambient, 4),
                                  (m.hyper.include_input_ambient, True), (m.coarse.num_layers, 8), (m.coarse.num_encoding_fn_xyz, 10),
                                  (m.coarse.use_pose, True), (m.coarse.include_driving, False)]
-    else:
+    elif arch == "nerface":
         want = _common_cfg(m) + [(m.warp.num_encoding_fn_xyz, 15), (m.hyper.num_encoding_fn_xyz, 15), (m.hyper.ambient_coord_dim, 1),
                                  (m.hyper.num_encoding_fn_ambient, 15), (m.hyper.include_input_ambient, False), (m.coarse.num_layers, 4),
                                  (m.coarse.num_encoding_fn_xyz, 15), (m.coarse.use_pose, False), (m.coarse.include_driving, True)]
+    else:   # nerface_static: config/expression/person_1.yml
+        want = _radiance_cfg(m) + [(m.warp.use_warp, False), (m.hyper.use_ambient, False), (m.coarse.num_layers, 4),
+                                   (m.coarse.num_encoding_fn_xyz, 10), (m.coarse.use_pose, False), (m.coarse.include_driving, True)]
     bad = [(a, b) for a, b in want if a != b]
     if bad or not hasattr(m, "fine"):
-        raise NotImplementedError("this build covers AudioFaceModel (config/audio/*.yml) and NeRFaceModel with warp + hyper sheet "
-                                  "(config/expression/person_2.yml, person_3.yml); the no-warp/no-hyper ablation (person_1.yml) is "
-                                  "not built. Mismatches (got, want): %r" % (bad,))
+        raise NotImplementedError("this build covers AudioFaceModel (config/audio/*.yml) and NeRFaceModel as configured by "
+                                  "config/expression/person_1.yml (no warp, no hyper sheet) or person_2.yml / person_3.yml (both on). "
+                                  "Mismatches (got, want): %r" % (bad,))
 
 
 class _FieldModel(nn.Module):
@@ -88,12 +94,13 @@ class _FieldModel(nn.Module):
         self.num_coarse = cfg.nerf.train.num_coarse
         self.num_fine = cfg.nerf.train.num_fine
         self.precision = ops.PRECISIONS[precision]
-        nf = W.NERFACE
+        nf = {"nerface": W.NERFACE, "nerface_static": W.NERFACE_STATIC}.get(self.arch)
         d_def, d_tr, amb, trl = ((W.D_DEF_IN, W.D_TR_IN, 2, W.TR_LAYERS) if self.arch == "audio"
                                  else (nf["D_DEF_IN"], nf["D_TR_IN"], nf["AMB_DIM"], nf["TR_LAYERS"]))
         self.spatial_embeddings = nn.Parameter(torch.randn(1, W.D_GRID, W.G_RES, W.G_RES, W.G_RES) * 0.01)   # models.py:199-201
-        self.warp_field_mlp = _DeformMLP("layers_xyz", "fc_final", W.WARP_H, 3, W.DEF_LAYERS, W.DEF_SKIP, d_def)
-        self.hyper_sheep_mlp = _DeformMLP("layers_ambient", "fc_ambient", W.HYP_H, amb, W.DEF_LAYERS, W.DEF_SKIP, d_def)
+        if self.arch != "nerface_static":       # models.py:231-254: the modules exist only when use_warp / use_ambient
+            self.warp_field_mlp = _DeformMLP("layers_xyz", "fc_final", W.WARP_H, 3, W.DEF_LAYERS, W.DEF_SKIP, d_def)
+            self.hyper_sheep_mlp = _DeformMLP("layers_ambient", "fc_ambient", W.HYP_H, amb, W.DEF_LAYERS, W.DEF_SKIP, d_def)
         self.nerf_mlps = nn.ModuleDict({"coarse": _RadianceMLP(trl, d_tr), "fine": _RadianceMLP(trl, d_tr)})
         if self.arch == "audio":
             self.audNet_head = _AudioNet()
@@ -164,12 +171,16 @@ class AudioFaceModel(_FieldModel):
 
 
 class NeRFaceModel(_FieldModel):
-    """models.py:189-378: expression-driven (driving = the 76-d expression vector); config/expression/person_2|3.yml.
-    fp32 forward (rendering) in this round; training and bf16 stay with the AudioFaceModel."""
-    arch = "nerface"
+    """models.py:189-378: expression-driven (driving = the 76-d expression vector).  Two architectures, chosen by the config as
+    the reference does (models.py:231,244): warp + hyper sheet on (config/expression/person_2.yml, person_3.yml) or both off
+    (person_1.yml).  fp32 forward (rendering) in this round; training and bf16 stay with the AudioFaceModel."""
 
     def __init__(self, cfg, precision="fp32"):
         super().__init__()
         if precision != "fp32":
             raise NotImplementedError("NeRFaceModel: only the fp32 kernel is built in this round")
+        deform = (bool(cfg.models.warp.use_warp), bool(cfg.models.hyper.use_ambient))
+        if deform[0] != deform[1]:
+            raise NotImplementedError("NeRFaceModel: warp and hyper sheet are built both on or both off (as in the shipped configs)")
+        self.arch = "nerface" if deform[0] else "nerface_static"
         self._build(cfg, precision)

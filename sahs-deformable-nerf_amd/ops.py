@@ -42,15 +42,18 @@ def _no_grad_needed(*tensors):
                                   "(wrap the call in torch.no_grad())")
 
 
-ARCHS = ("audio", "nerface")   # AudioFaceModel (config/audio) | NeRFaceModel (config/expression person_2/3)
+ARCHS = ("audio", "nerface", "nerface_static")   # = SAHS_MODEL_AUDIO / _NERFACE / _NERFACE_STATIC of include/sahs_nerf.h
 
 
 def _fn(name, arch="audio"):
-    """C-ABI entry point `name` of the architecture's family (sahs_<name> | sahs_nerface_<name>)."""
+    """sahs_model_<name> bound to the architecture: AudioFaceModel (config/audio) | NeRFaceModel (config/expression person_2/3)
+    | NeRFaceModel without deformation (config/expression/person_1)."""
     if arch not in ARCHS:
         raise _lib.SahsError("unknown architecture %r" % (arch,))
-    full = "sahs_" + ("nerface_" if arch == "nerface" else "") + name
-    return getattr(_lib.lib(), full), full
+    full = "sahs_model_" + name
+    f = getattr(_lib.lib(), full)
+    m = ARCHS.index(arch)
+    return (lambda *a: f(m, *a)), full + "(%s)" % arch
 
 
 def param_count(arch="audio"):
@@ -74,7 +77,7 @@ def fold_conditioning(flat, audio, pose, arch="audio"):
     """audio: the (16, 29) DeepSpeech window (AudioFaceModel) or the 76-d expression vector (NeRFaceModel)."""
     flat, audio = _req(flat, "flat_params"), _req(audio, "audio")
     pose = _req(pose, "pose")
-    want = (16, 29) if arch == "audio" else (76,)
+    want = (16, 29) if arch == "audio" else (76,)   # NeRFaceModels: the expression vector
     if tuple(audio.shape) != want:
         raise _lib.SahsError("driving input must be %s for %r, got %s" % (want, arch, tuple(audio.shape)))
     if pose.dim() != 2 or pose.shape[0] < 3 or pose.shape[1] != 4:

@@ -41,29 +41,41 @@ NERFACE_MAC_PER_SAMPLE = (128 * 205 + 4 * 128 * 128 + 128 * (128 + 205) + 3 * 12
     + (128 * 256 + 3 * 128 * 128 + 12 * 128)
 
 
+# NeRFaceModel built from config/expression/person_1.yml (warp.use_warp False, hyper.use_ambient False): no deformation
+# nets, 10-octave encoding, trunk fed [PE63 | expression76].
+NERFACE_STATIC = dict(D_XYZ=63, D_AMB=0, AMB_DIM=0, TR_LAYERS=4, D_DEF_IN=0, D_TR_IN=63 + 76)
+NERFACE_STATIC_MAC_PER_SAMPLE = (256 * 139 + 2 * 256 * 256 + 256 * (256 + 139) + 256 * 256 + 256) + (128 * 315 + 3 * 128 * 128 + 3 * 128) \
+    + (128 * 256 + 3 * 128 * 128 + 12 * 128)
+MODELS = ("audio", "nerface", "nerface_static")
+
+
 def canonical_spec(model="audio"):
     """[(state_dict key, shape)] in ``state_dict`` order."""
     if model == "nerface":
         return _spec(NERFACE["D_DEF_IN"], NERFACE["D_TR_IN"], NERFACE["AMB_DIM"], NERFACE["TR_LAYERS"], audionet=False)
+    if model == "nerface_static":
+        return _spec(0, NERFACE_STATIC["D_TR_IN"], 0, NERFACE_STATIC["TR_LAYERS"], audionet=False, deform=False)
     assert model == "audio", model
     return _spec(D_DEF_IN, D_TR_IN, 2, TR_LAYERS, audionet=True)
 
 
-def _spec(D_DEF_IN, D_TR_IN, AMB_DIM, TR_LAYERS, audionet):
+def _spec(D_DEF_IN, D_TR_IN, AMB_DIM, TR_LAYERS, audionet, deform=True):
     spec = [("spatial_embeddings", (1, D_GRID, G_RES, G_RES, G_RES))]
 
     def lin(name, out, inp):
         spec.append((name + ".weight", (out, inp)))
         spec.append((name + ".bias", (out,)))
 
-    for i in range(DEF_LAYERS):
+    for i in range(DEF_LAYERS if deform else 0):
         inp = D_DEF_IN if i == 0 else (WARP_H + D_DEF_IN if i == DEF_SKIP else WARP_H)
         lin(f"warp_field_mlp.layers_xyz.{i}", WARP_H, inp)
-    lin("warp_field_mlp.fc_final", 3, WARP_H)
-    for i in range(DEF_LAYERS):
+    if deform:
+        lin("warp_field_mlp.fc_final", 3, WARP_H)
+    for i in range(DEF_LAYERS if deform else 0):
         inp = D_DEF_IN if i == 0 else (HYP_H + D_DEF_IN if i == DEF_SKIP else HYP_H)
         lin(f"hyper_sheep_mlp.layers_ambient.{i}", HYP_H, inp)
-    lin("hyper_sheep_mlp.fc_ambient", AMB_DIM, HYP_H)
+    if deform:
+        lin("hyper_sheep_mlp.fc_ambient", AMB_DIM, HYP_H)
     for lvl in ("coarse", "fine"):
         p = f"nerf_mlps.{lvl}."
         for i in range(TR_LAYERS):

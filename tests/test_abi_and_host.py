@@ -184,8 +184,12 @@ def test_nerface_model_state_dict_and_config_guard():
     assert m.state_dict()["hyper_sheep_mlp.fc_ambient.weight"].shape == (1, 64)
     fw = W.flatten_state_dict(W.hash_state_dict(model="nerface"), model="nerface")
     assert torch.equal(m.load_flat(fw).flat_params(), torch.from_numpy(fw))
+    st = sahs.NeRFaceModel(sahs.default_config("expression_static"))     # config/expression/person_1.yml: no deformation nets
+    assert st.arch == "nerface_static" and [k for k, _ in W.canonical_spec("nerface_static")] == list(st.state_dict().keys())
+    assert not any(k.startswith(("warp_field_mlp", "hyper_sheep_mlp")) for k in st.state_dict())
+    assert st.state_dict()["nerf_mlps.fine.layers_xyz.3.weight"].shape == (256, 256 + 63 + 76)
     bad = sahs.default_config("expression")
-    bad.models.warp.use_warp = False               # config/expression/person_1.yml (no deformation): not built
+    bad.models.warp.use_warp = False               # warp off but hyper sheet on: not a shipped combination
     with pytest.raises(NotImplementedError):
         sahs.NeRFaceModel(bad)
     with pytest.raises(NotImplementedError):

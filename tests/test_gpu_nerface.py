@@ -28,19 +28,19 @@ def nf():
     ops = pkg("ops")
     cache = {}
 
-    def get(seed=0, density_bias=0.0, density_gain=1.0):
-        key = (int(seed), float(density_bias), float(density_gain))
+    def get(seed=0, density_bias=0.0, density_gain=1.0, arch="nerface"):
+        key = (int(seed), float(density_bias), float(density_gain), arch)
         if key not in cache:
-            fw = W.flatten_state_dict(W.hash_state_dict(*key, model="nerface"), model="nerface")
+            fw = W.flatten_state_dict(W.hash_state_dict(*key[:3], model=arch), model=arch)
             flat = T(fw)
-            cache[key] = (fw, flat, ops.pack_weights(flat, arch="nerface"))
+            cache[key] = (fw, flat, ops.pack_weights(flat, arch=arch))
         return cache[key]
 
     return get
 
 
 def test_sizes_and_errors(ops):
-    assert ops.param_count("nerface") == 2_311_140 and ops.param_count() == 2_775_633
+    assert ops.param_count("nerface") == 2_311_140 and ops.param_count() == 2_775_633 and ops.param_count("nerface_static") == 2_066_976
     with pytest.raises(Exception):
         ops.pack_weights(torch.zeros(2_775_633, device=dev()), arch="nerface")        # the audio model's buffer
     with pytest.raises(Exception):
@@ -152,3 +152,65 @@ def test_model_seam_and_training_guard(nf):
                                   pose=T(g["pose"]))
     with pytest.raises(NotImplementedError):
         sahs.NeRFaceModel(sahs.default_config("audio"))
+
+
+# ---- config/expression/person_1.yml: NeRFaceModel without deformation nets (use_warp False, use_ambient False) ----
+@pytest.mark.parametrize("variant", ["default", "boosted"])
+def test_static_field_vs_golden(ops, nf, variant):
+    g = load_golden("nerface_static_field")
+    kw = dict(default=dict(), boosted=dict(density_bias=8.0, density_gain=30.0))[variant]
+    fw, flat, packed = nf(arch="nerface_static", **kw)
+    frame = ops.fold_conditioning(flat, T(g["expression"]), T(g["pose"]), arch="nerface_static")
+    x = g["x"]
+    P = x.shape[0]
+    rays = np.zeros((P, 8), np.float32)
+    rays[:, :6] = x
+    z = torch.zeros(P, 1, device=dev())
+    raw_c, dx, w, grid = ops.field_forward(packed, frame, 0, T(rays), z, debug=True, arch="nerface_static")
+    raw_f = ops.field_forward(packed, frame, 1, T(rays), z, arch="nerface_static")
+    assert not bool(dx.any())
+    close(grid.view(P, 32), g[variant + "_grid_coarse"], 1e-5, 1e-7, "grid")
+    scale = 30.0 if variant == "boosted" else 1.0
+    for lvl, raw in (("coarse", raw_c), ("fine", raw_f)):
+        raw = raw.view(P, 16)
+        close(raw[:, :15], g[variant + "_raw_" + lvl][:, :15], 1e-3, 1e-4, "raw rgb/seg " + lvl)
+        close(raw[:, 15], g[variant + "_raw_" + lvl][:, 15], 1e-3, 1e-4 * scale, "raw sigma " + lvl)
+
+
+@pytest.mark.parametrize("N,S", [(37, 64), (3, 192), (5, 1)])
+def test_static_field_vs_oracle(ops, nf, N, S):
+    rng = np.random.default_rng(N * 1000 + S + 7)
+    g = load_golden("nerface_static_field")
+    fw, flat, packed = nf(density_bias=8.0, density_gain=30.0, arch="nerface_static")
+    frame = ops.fold_conditioning(flat, T(g["expression"]), T(g["pose"]), arch="nerface_static")
+    rays = np.zeros((N, 8), np.float32)
+    rays[:, 0:3] = rng.normal(0, 0.05, (N, 3)) + np.array([0, 0, 0.5])
+    rays[:, 3:6] = rng.normal(0, 0.15, (N, 3)) + np.array([0, 0, -1.0])
+    z = np.sort(rng.uniform(0.2, 0.8, (N, S)).astype(np.float32), axis=1)
+    x6 = np.concatenate([rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None], np.broadcast_to(rays[:, None, 3:6], (N, S, 3))], axis=-1)
+    x6 = x6.reshape(-1, 6).astype(np.float32)
+    with oracle.model("nerface_static"):
+        refs = [oracle.field_forward(fw, level, x6, g["expression"], oracle.pose_encoding(g["pose"])) for level in (0, 1)]
+    for level in (0, 1):
+        raw = ops.field_forward(packed, frame, level, T(rays), T(z), arch="nerface_static").reshape(-1, 16)
+        close(raw[:, :15], refs[level][:, :15], 1e-3, 1e-4, "raw rgb/seg level %d" % level)
+        close(raw[:, 15], refs[level][:, 15], 1e-3, 3e-3, "raw sigma level %d" % level)
+
+
+def test_static_end_to_end_vs_golden(nf):
+    sahs = pkg()
+    g = load_golden("nerface_static_e2e_val")
+    cfg = sahs.default_config("expression_static")
+    fw, flat, packed = nf(int(g["weights_seed"]), float(g["weights_density_bias"]), float(g["weights_density_gain"]), arch="nerface_static")
+    model = sahs.NeRFaceModel(cfg).to(dev()).load_flat(fw)
+    assert model.arch == "nerface_static"
+    pose = T(g["pose"])
+    H, Wd = int(g["H"]), int(g["W"])
+    ro, rd = sahs.get_ray_bundle(H, Wd, g["intrinsics"], pose)
+    with torch.no_grad(), FeedRand(golden_rand(g)) as feed:
+        outs = sahs.run_one_iter_of_nerf(H, Wd, g["intrinsics"], model, ro, rd, cfg, mode="validation", driving=T(g["expression"]),
+                                         pose=pose, background_prior=T(g["bg"]), inHead=torch.zeros(H, Wd, 12, device=dev()))
+        assert not feed.log
+    names = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"]
+    for nm, o in zip(names, outs):   # 10 octaves, no warp: the audio model's end-to-end tolerance
+        close(o, g["out_" + nm], 2e-3, 2e-4, "static e2e:" + nm)

@@ -19,10 +19,10 @@ def nf_flat():
     W = pkg("weights")
     cache = {}
 
-    def get(seed=0, density_bias=0.0, density_gain=1.0):
-        key = (int(seed), float(density_bias), float(density_gain))
+    def get(seed=0, density_bias=0.0, density_gain=1.0, arch="nerface"):
+        key = (int(seed), float(density_bias), float(density_gain), arch)
         if key not in cache:
-            cache[key] = W.flatten_state_dict(W.hash_state_dict(*key, model="nerface"), model="nerface")
+            cache[key] = W.flatten_state_dict(W.hash_state_dict(*key[:3], model=arch), model=arch)
         return cache[key]
 
     return get
@@ -31,6 +31,8 @@ def nf_flat():
 def test_param_count():
     with oracle.model("nerface"):
         assert oracle.param_count() == pkg("weights").param_count("nerface") == 2_311_140
+    with oracle.model("nerface_static"):
+        assert oracle.param_count() == pkg("weights").param_count("nerface_static") == 2_066_976
     assert oracle.param_count() == 2_775_633
 
 
@@ -39,6 +41,24 @@ def test_positional_encodings():
     # fl(2^k x) is exact, so both sides evaluate sin/cos at the same argument (up to 2^14 * 0.9 rad): 1-ulp libm vs SLEEF
     close(oracle.positional_encoding(g["x"], 15), g["pe_xyz"], 1e-6, 1e-6, "pe_xyz")
     close(oracle.positional_encoding(g["w"], 15, include_input=False), g["pe_amb"], 1e-6, 1e-6, "pe_amb")
+
+
+@pytest.mark.parametrize("variant", ["default", "boosted"])
+def test_field_static(nf_flat, variant):
+    """config/expression/person_1.yml: no deformation nets, 10 octaves -> the audio model's tolerances."""
+    g = load_golden("nerface_static_field")
+    kw = dict(default=dict(), boosted=dict(density_bias=8.0, density_gain=30.0))[variant]
+    flat = nf_flat(arch="nerface_static", **kw)
+    with oracle.model("nerface_static"):
+        p36 = oracle.pose_encoding(g["pose"])
+        raw_c, dx, w, grid = oracle.field_forward(flat, 0, g["x"], g["expression"], p36, debug=True)
+        raw_f = oracle.field_forward(flat, 1, g["x"], g["expression"], p36)
+    assert not dx.any() and not g[variant + "_dx"].any() and g[variant + "_w"].shape == (256, 0)
+    close(grid, g[variant + "_grid_coarse"], 1e-5, 1e-7, "grid features")
+    scale = 30.0 if variant == "boosted" else 1.0
+    for lvl, raw in (("coarse", raw_c), ("fine", raw_f)):
+        close(raw[:, :15], g[variant + "_raw_" + lvl][:, :15], 1e-3, 1e-4, "raw rgb/seg " + lvl)
+        close(raw[:, 15], g[variant + "_raw_" + lvl][:, 15], 1e-3, 1e-4 * scale, "raw sigma " + lvl)
 
 
 @pytest.mark.parametrize("variant", ["default", "boosted"])
@@ -62,18 +82,19 @@ def test_field(nf_flat, variant):
         close(raw[:, 15], g[variant + "_raw_" + lvl][:, 15], 2e-3, 2e-3 * scale, "raw sigma " + lvl)
 
 
-@pytest.mark.parametrize("name", ["nerface_e2e_val", "nerface_e2e_det"])
+@pytest.mark.parametrize("name", ["nerface_e2e_val", "nerface_e2e_det", "nerface_static_e2e_val"])
 def test_end_to_end(nf_flat, name):
     """The fine pass of this model is ill-conditioned in the resampled depths: sigma contains sin/cos(2^14 x'), so a 1e-5
     difference in a depth (round-off level of the inverse cdf, cf. test_sample_pdf) turns the top octaves by 0.16 rad.  The
     stages are therefore pinned separately -- coarse pass tight, resampled depths to the inverse-cdf bound, fine pass tight
     on the REFERENCE's own depths -- and the chained result to the looser bound that follows."""
     g = load_golden(name)
-    flat = nf_flat(int(g["weights_seed"]), float(g["weights_density_bias"]), float(g["weights_density_gain"]))
+    arch = "nerface_static" if "static" in name else "nerface"
+    flat = nf_flat(int(g["weights_seed"]), float(g["weights_density_bias"]), float(g["weights_density_gain"]), arch=arch)
     log = golden_rand(g)
     rand = dict(zip(["t_rand", "u"], [a for _, a in log])) if log else {}
     N = int(g["H"]) * int(g["W"])
-    with oracle.model("nerface"):
+    with oracle.model(arch):
         ro, rd = oracle.get_ray_bundle(int(g["H"]), int(g["W"]), g["intrinsics"], g["pose"])
         ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
         rays = np.concatenate([ro, rd, np.full((N, 1), g["near"], np.float32), np.full((N, 1), g["far"], np.float32)], 1).astype(np.float32)
