@@ -130,7 +130,7 @@ int sahs_conditioning_backward(const float *flat_params, const float *audio, con
  * window for the AudioFaceModel and the 76-d expression vector (models.py:368 `driving.repeat`) for the NeRFaceModels;
  * rays, depths and outputs are the same, and sahs_get_ray_bundle, sahs_ray_uniforms, sahs_stratified_depths,
  * sahs_composite_forward, sahs_resample, sahs_sample_pdf are model-independent.  The NeRFaceModels are built for SAHS_F32
- * forward (rendering) in this round. */
+ * (rendering and training). */
 #define SAHS_MODEL_AUDIO 0
 #define SAHS_MODEL_NERFACE 1
 #define SAHS_MODEL_NERFACE_STATIC 2
@@ -147,6 +147,16 @@ int sahs_model_render_rays(int model, const void *packed, const float *frame, in
                            const float *u, const float *noise_f, float *z_c, float *z_f, float *raw, float *weights, float *rgb_c,
                            float *disp_c, float *acc_c, float *rgb_f, float *disp_f, float *acc_f, float *w_bg, float *depth_f,
                            void *stream);
+
+/* training path of any built model (fp32): the sahs_field_forward_save / sahs_field_backward pair above with a model id.
+ * grad_cond: [0:76] d driving (for the NeRFaceModels this IS the gradient of the expression vector; for the AudioFaceModel
+ * sahs_conditioning_backward carries it on through AudioNet), [80:116] d pose encoding. */
+long sahs_model_act_words_per_sample(int model);
+long sahs_model_field_backward_workspace_words(int model, long P);
+int sahs_model_field_forward_save(int model, const void *packed, const float *frame, int level, long N, int S, const float *rays,
+                                  int ray_stride, const float *z, float *raw, float *act_out, void *stream);
+int sahs_model_field_backward(int model, const float *flat_params, const float *frame, int level, long P, const float *act_in,
+                              const float *d_raw, float *grad_flat, float *grad_cond, float *workspace, void *stream);
 
 #ifdef __cplusplus
 }

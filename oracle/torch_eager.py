@@ -33,11 +33,27 @@ def get_ray_bundle(H, W, intr, c2w):
 
 
 class EagerField:
-    """AudioFaceModel.forward (models.py:514-528) over a state_dict of tensors."""
+    """AudioFaceModel.forward (models.py:514-528) / NeRFaceModel.forward (models.py:366-378) over a state_dict of tensors.
+    arch: "audio" (config/audio), "nerface" (config/expression/person_2|3.yml), "nerface_static" (person_1.yml)."""
 
-    def __init__(self, sd, num_coarse=64, num_fine=64):
+    ARCH = {"audio": dict(L=10, L_amb=4, amb_inc=True, layers=8, deform=True, audionet=True, trunk_pose=True),
+            "nerface": dict(L=15, L_amb=15, amb_inc=False, layers=4, deform=True, audionet=False, trunk_pose=False),
+            "nerface_static": dict(L=10, L_amb=0, amb_inc=False, layers=4, deform=False, audionet=False, trunk_pose=False)}
+
+    def __init__(self, sd, num_coarse=64, num_fine=64, arch="audio", masks=None):
         self.sd = sd
         self.num_coarse, self.num_fine = num_coarse, num_fine
+        self.a = self.ARCH[arch]
+        # masks: optional {"warp.i" | "hyper.i" | "trunk.i" | "dir.i" | "seg.i": bool (P, width)} -- the branch every (leaky) ReLU
+        # takes, imposed from outside.  Used by the gradient tests to compare derivatives on the SAME side of every kink: two
+        # correct fp32 forwards that differ by 1e-5 put a few pre-activations on different sides of zero, and one such sample
+        # moves a bias-gradient entry by percents.
+        self.masks = masks
+
+    def act(self, name, x, slope):
+        if self.masks is None:
+            return F.leaky_relu(x, slope) if slope > 0 else torch.relu(x)
+        return x * torch.where(self.masks[name], torch.ones((), dtype=x.dtype, device=x.device), torch.full((), slope, dtype=x.dtype, device=x.device))
 
     def lin(self, name, x):
         return F.linear(x, self.sd[name + ".weight"], self.sd[name + ".bias"])
@@ -61,44 +77,52 @@ class EagerField:
 
     def deform(self, prefix, list_name, final, n_layers, skip, initial):
         x = initial
+        tag = "warp" if prefix.startswith("warp") else "hyper"
         for i in range(n_layers):
-            x = torch.relu(self.lin("%s.%s.%d" % (prefix, list_name, i), torch.cat((x, initial), -1) if i == skip else x))
+            x = self.act("%s.%d" % (tag, i), self.lin("%s.%s.%d" % (prefix, list_name, i), torch.cat((x, initial), -1) if i == skip else x), 0.0)
         return self.lin("%s.%s" % (prefix, final), x)
 
     def grid(self, level, xyz):
         """models.py:346-365."""
         n = self.num_coarse + (self.num_fine if level == "fine" else 0)
-        c = xyz.float().reshape((-1, n, 3))
-        B = c.shape[0]
         g = self.sd["spatial_embeddings"]
+        c = xyz.to(g.dtype).reshape((-1, n, 3))      # models.py:355 `.float()`; float64 when the whole field is evaluated in double
+        B = c.shape[0]
         s = F.grid_sample(g.expand(B, -1, -1, -1, -1), c.reshape(B, 1, 1, -1, 3), mode="bilinear", padding_mode="zeros", align_corners=True)
         N, C, H, W, D = s.shape
         return s.permute(0, 4, 3, 2, 1).reshape(N * H * W * D, C)
 
     def forward(self, level, x, audio, pose):
+        a = self.a
         P = x.shape[0]
         xyz, dirs = x[..., :3], x[..., 3:6]
-        driving = self.audionet(audio).repeat(P, 1)                    # models.py:517-518
-        pose36 = self.pose_encoding(pose).repeat(P, 1)                 # :519-521
-        initial = torch.cat((positional_encoding(xyz, 10), driving, pose36), dim=1)
-        warped = xyz + torch.tanh(self.deform("warp_field_mlp", "layers_xyz", "fc_final", 6, 4, initial))     # :304-305
-        initial = torch.cat((positional_encoding(xyz, 10), driving, pose36), dim=1)                           # PE recomputed, :310
-        amb = self.deform("hyper_sheep_mlp", "layers_ambient", "fc_ambient", 6, 4, initial)
+        driving = (self.audionet(audio) if a["audionet"] else audio).repeat(P, 1)      # models.py:517-518 / :368
+        pose36 = self.pose_encoding(pose).repeat(P, 1)                                 # :519-521 / :369-370
+        L = a["L"]
+        if a["deform"]:
+            initial = torch.cat((positional_encoding(xyz, L), driving, pose36), dim=1)
+            warped = xyz + torch.tanh(self.deform("warp_field_mlp", "layers_xyz", "fc_final", 6, 4, initial))     # :304-305
+            initial = torch.cat((positional_encoding(xyz, L), driving, pose36), dim=1)                           # PE recomputed, :310
+            amb = self.deform("hyper_sheep_mlp", "layers_ambient", "fc_ambient", 6, 4, initial)
+            enc = torch.cat((positional_encoding(warped, L), positional_encoding(amb, a["L_amb"], a["amb_inc"])), dim=1)
+        else:
+            warped = xyz                                                                                          # :316-327
+            enc = positional_encoding(warped, L)
         feats = self.grid(level, warped)
         p = "nerf_mlps.%s." % level
-        init = torch.cat((positional_encoding(warped, 10), positional_encoding(amb, 4), pose36), dim=1)        # modules.py:255-266
+        init = torch.cat((enc, pose36 if a["trunk_pose"] else driving), dim=1)                                    # modules.py:255-267
         h = init
-        for i in range(8):
-            h = F.leaky_relu(self.lin(p + "layers_xyz.%d" % i, torch.cat((h, init), -1) if i == 3 else h), 0.01)
+        for i in range(a["layers"]):
+            h = self.act("trunk.%d" % i, self.lin(p + "layers_xyz.%d" % i, torch.cat((h, init), -1) if i == 3 else h), 0.01)
         feat = self.lin(p + "fc_feat", h)
         alpha = self.lin(p + "fc_alpha", feat)
         c = torch.cat((feat, positional_encoding(dirs, 4), feats), -1)
         for i in range(4):
-            c = F.leaky_relu(self.lin(p + "layers_dir.%d" % i, c), 0.01)
+            c = self.act("dir.%d" % i, self.lin(p + "layers_dir.%d" % i, c), 0.01)
         rgb = self.lin(p + "fc_rgb", c)
         s = feat
         for i in range(4):
-            s = F.leaky_relu(self.lin(p + "layers_seg.%d" % i, s), 0.01)
+            s = self.act("seg.%d" % i, self.lin(p + "layers_seg.%d" % i, s), 0.01)
         return torch.cat((rgb, self.lin(p + "fc_seg", s), alpha), dim=-1)
 
 

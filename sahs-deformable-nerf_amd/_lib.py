@@ -46,6 +46,10 @@ SIGNATURES = {
     "sahs_model_fold_conditioning": (_I, [_I, _P, _P, _P, _I, _P, _P]),
     "sahs_model_field_forward": (_I, [_I, _P, _P, _I, _L, _I, _P, _I, _P, _P, _P, _I, _P]),
     "sahs_model_render_rays": (_I, [_I, _P, _P, _I, _L, _P, _I, _I, _I, _I, _I] + [_P] * 18),
+    "sahs_model_act_words_per_sample": (_L, [_I]),
+    "sahs_model_field_backward_workspace_words": (_L, [_I, _L]),
+    "sahs_model_field_forward_save": (_I, [_I, _P, _P, _I, _L, _I, _P, _I, _P, _P, _P, _P]),
+    "sahs_model_field_backward": (_I, [_I, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

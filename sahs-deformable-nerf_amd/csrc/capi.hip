@@ -39,6 +39,10 @@ int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, 
     long sahs_layout_param_count##sfx(void);                                                                                        \
     long sahs_layout_packed_words_f32##sfx(void);                                                                                   \
     long sahs_layout_frame_words##sfx(void);                                                                                        \
+    long sahs_layout_act_words##sfx(void);                                                                                          \
+    long sahs_field_backward_ws_words##sfx(long P);                                                                                 \
+    int sahs_field_backward_launch##sfx(const float *flat, const float *frame, int level, long P, const float *actbuf,              \
+                                        const float *d_raw, float *grad_flat, float *grad_cond, float *ws, hipStream_t stream);     \
     int sahs_pack_weights_f32_launch##sfx(const float *flat, float *packed, hipStream_t stream);                                   \
     int sahs_fold_conditioning_launch##sfx(const float *flat, const float *driving, const float *pose, int pose_ld, float *frame,  \
                                            hipStream_t stream);                                                                     \
@@ -264,14 +268,20 @@ struct ModelFns {
     int (*pack_f32)(const float *, float *, hipStream_t);
     int (*fold)(const float *, const float *, const float *, int, float *, hipStream_t);
     int (*field_f32)(const float *, const float *, int, long, int, const float *, int, const float *, float *, float *, float *, int, hipStream_t);
+    long (*act_words)(void);
+    long (*bwd_ws_words)(long);
+    int (*bwd)(const float *, const float *, int, long, const float *, const float *, float *, float *, float *, hipStream_t);
 };
 static const ModelFns kModels[3] = {
     {sahs_layout_param_count, sahs_layout_packed_words_f32, sahs_layout_frame_words, sahs_pack_weights_f32_launch,
-     sahs_fold_conditioning_launch, sahs_field_forward_f32_launch},
+     sahs_fold_conditioning_launch, sahs_field_forward_f32_launch, sahs_layout_act_words, sahs_field_backward_ws_words,
+     sahs_field_backward_launch},
     {sahs_layout_param_count_nf, sahs_layout_packed_words_f32_nf, sahs_layout_frame_words_nf, sahs_pack_weights_f32_launch_nf,
-     sahs_fold_conditioning_launch_nf, sahs_field_forward_f32_launch_nf},
+     sahs_fold_conditioning_launch_nf, sahs_field_forward_f32_launch_nf, sahs_layout_act_words_nf, sahs_field_backward_ws_words_nf,
+     sahs_field_backward_launch_nf},
     {sahs_layout_param_count_ns, sahs_layout_packed_words_f32_ns, sahs_layout_frame_words_ns, sahs_pack_weights_f32_launch_ns,
-     sahs_fold_conditioning_launch_ns, sahs_field_forward_f32_launch_ns},
+     sahs_fold_conditioning_launch_ns, sahs_field_forward_f32_launch_ns, sahs_layout_act_words_ns, sahs_field_backward_ws_words_ns,
+     sahs_field_backward_launch_ns},
 };
 #define REQUIRE_MODEL(m, name) do { if ((m) < 0 || (m) > 2) return fail(3, "%s: unknown model %ld", name, (long)(m)); } while (0)
 
@@ -321,6 +331,31 @@ int sahs_model_field_forward(int model, const void *packed, const float *frame, 
 {
     REQUIRE_MODEL(model, "sahs_model_field_forward");
     return field_forward_model(model, packed, frame, level, N, S, rays, ray_stride, z, raw, dbg, precision, stream);
+}
+
+long sahs_model_act_words_per_sample(int model) { return (model < 0 || model > 2) ? -1 : kModels[model].act_words(); }
+long sahs_model_field_backward_workspace_words(int model, long P) { return (model < 0 || model > 2) ? -1 : kModels[model].bwd_ws_words(P); }
+
+int sahs_model_field_forward_save(int model, const void *packed, const float *frame, int level, long N, int S, const float *rays,
+                                  int ray_stride, const float *z, float *raw, float *act_out, void *stream)
+{
+    REQUIRE_MODEL(model, "sahs_model_field_forward_save");
+    REQUIRE(packed && frame && rays && z && raw && act_out, "sahs_model_field_forward_save");
+    REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_model_field_forward_save(shape)");
+    REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && ALIGNED16(act_out), "sahs_model_field_forward_save(alignment)");
+    int e = kModels[model].field_f32((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, nullptr, act_out, num_cus(),
+                                     (hipStream_t)stream);
+    return e ? hip_fail("sahs_model_field_forward_save", e) : 0;
+}
+
+int sahs_model_field_backward(int model, const float *flat_params, const float *frame, int level, long P, const float *act_in,
+                              const float *d_raw, float *grad_flat, float *grad_cond, float *workspace, void *stream)
+{
+    REQUIRE_MODEL(model, "sahs_model_field_backward");
+    REQUIRE(flat_params && frame && act_in && d_raw && grad_flat && grad_cond && workspace, "sahs_model_field_backward");
+    REQUIRE((level == 0 || level == 1) && P >= 0 && P <= 4000000L, "sahs_model_field_backward(0 <= P <= 4e6 samples per call)");
+    int e = kModels[model].bwd(flat_params, frame, level, P, act_in, d_raw, grad_flat, grad_cond, workspace, (hipStream_t)stream);
+    return e ? hip_fail("sahs_model_field_backward", e) : 0;
 }
 
 static int field_nf(const void *pk, const float *fr, int lv, long N, int S, const float *r, int rs, const float *z, float *raw, float *dbg, int pr, void *st)

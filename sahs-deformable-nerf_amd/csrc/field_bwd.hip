@@ -10,10 +10,11 @@
 // encoding) get their weight-column gradients from the bias gradient (their value is the same for every sample:
 // dW[:, const] = db (x) c) and their own gradient from W[:, const]^T db.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "sahs_common.hpp"
 #include "sahs_layout.hpp"
 
-namespace sahs {
+namespace SAHS_NS {
 
 // ------------------------------------------------------------------------------------------------
 // C[M x N] (op)= A'[M x K] B[K x N], fp32, v_mfma_f32_16x16x4_f32.  TA: A'(m,k) = A[k*lda + m], else A[m*lda + k];
@@ -358,22 +359,26 @@ __global__ void rank1_add_kernel(long M, int N, const float *__restrict__ dcol, 
 
 // ---- positional-encoding backward: d(enc)/d(coord) from the saved sin/cos rows -----------------------------
 // enc = [v | sin(2^k v) | cos(2^k v)]_k (nerf_helpers.py:322-349): d sin = 2^k cos, d cos = -2^k sin.
-template <int D, int L>
+template <int D, int L, int INC>
 __device__ __forceinline__ void pe_grad(const float *enc, const float *denc, float *dv)
 {
+    constexpr int D0 = INC ? D : 0;    // include_input: the raw coordinates come first
 #pragma unroll
     for (int a = 0; a < D; ++a) {
-        float g = denc[a];
+        float g = INC ? denc[a] : 0.0f;
 #pragma unroll
         for (int k = 0; k < L; ++k) {
-            const int si = D + 2 * D * k + a, ci = si + D;
+            const int si = D0 + 2 * D * k + a, ci = si + D;
             g += (float)(1 << k) * (denc[si] * enc[ci] - denc[ci] * enc[si]);
         }
         dv[a] = g;
     }
 }
 
-// Per sample: d_in [P x 96] = gradient wrt [PE63(x') pad 64 | PE18(w) pad 32].  d_xw [P x 4] += dL/dx' through PE63 (the trilinear
+constexpr int DIN_LD = 16 * (KB_XYZ + KB_AMB);   // row of the gradient wrt [PE(x') blocks | PE(w) blocks]: 96 | 128 | 64
+constexpr int DIN_AMB = 16 * KB_XYZ;             // where the PE(w) part starts
+
+// Per sample: d_in [P x DIN_LD] = gradient wrt [PE(x') blocks | PE(w) blocks].  d_xw [P x 4] += dL/dx' through PE63 (the trilinear
 // part was written by grid_backward_kernel), d_w [P x 4] = dL/dw.
 __global__ void __launch_bounds__(256) encode_backward_kernel(long P, const float *__restrict__ actbuf, const float *__restrict__ d_in,
                                                               float *__restrict__ d_xw, float *__restrict__ d_w)
@@ -381,8 +386,11 @@ __global__ void __launch_bounds__(256) encode_backward_kernel(long P, const floa
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
         const float *a = actbuf + p * (long)act::STRIDE;
         float gx[3], gw[2];
-        pe_grad<3, 10>(a + act::PEX, d_in + p * 96, gx);
-        pe_grad<2, 4>(a + act::PEW, d_in + p * 96 + 64, gw);
+        pe_grad<3, L_XYZ, 1>(a + act::PEX, d_in + p * DIN_LD, gx);
+        gw[0] = 0.0f; gw[1] = 0.0f;
+#if SAHS_MODEL != 2
+        pe_grad<AMB_DIM, L_AMB, AMB_INC>(a + act::PEW, d_in + p * DIN_LD + DIN_AMB, gw);
+#endif
         f32x4 t = *reinterpret_cast<const f32x4 *>(d_xw + p * 4);
         t[0] += gx[0]; t[1] += gx[1]; t[2] += gx[2];
         *reinterpret_cast<f32x4 *>(d_xw + p * 4) = t;
@@ -503,9 +511,9 @@ __global__ void axpy_kernel(int n, const float *__restrict__ x, float *__restric
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[i] += x[i];
 }
 
-}  // namespace sahs
+}  // namespace SAHS_NS
 
-using namespace sahs;
+using namespace SAHS_NS;
 
 namespace {
 
@@ -517,7 +525,11 @@ struct Bwd {
     long walo = 0;
     int err = 0;
     void check() { if (!err) err = (int)hipGetLastError(); }
-    static bool al(const void *p, long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0; }
+    static bool al(const void *p, long ld)
+    {
+        static const bool nodma = getenv("SAHS_BWD_NODMA") != nullptr;     // diagnostic: route every GEMM to the register-staged kernel
+        return !nodma && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ld % 4 == 0;
+    }
     // dX[P x N] (mode) = dY[P x K] * W[K x N] (* mask)
     void nn(const float *dY, long ldy, int K, const float *W, long ldw, int N, float *dX, long ldx, int mode, const float *mask = nullptr,
             long ldm = 0, float slope = 0.0f)
@@ -568,26 +580,28 @@ struct Bwd {
 // channel-last copies of the feature grid and of its gradient accumulator
 constexpr int DB_SCRATCH = 8192;   // per-call bias-gradient scratch (all layers of one level: ~5.3 K floats)
 constexpr long WAL_FLOATS = 2L << 20;   // aligned weight sub-matrix copies of one level (< 1.8 M floats)
-extern "C" long sahs_field_backward_ws_words(long P) { return P * (256L * 3 + 96 + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS + WAL_FLOATS; }
+extern "C" long SAHS_SYM(sahs_field_backward_ws_words)(long P) { return P * (256L * 3 + DIN_LD + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS + WAL_FLOATS; }
 
 // grad_cond: [0:76] d_driving, [80:116] d_pose36 (accumulated).  grad_flat: accumulated.  d_raw: (P,16).
-extern "C" int sahs_field_backward_launch(const float *flat, const float *frame, int level, long P, const float *actbuf, const float *d_raw,
+extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const float *frame, int level, long P, const float *actbuf, const float *d_raw,
                                           float *grad_flat, float *grad_cond, float *ws, hipStream_t stream)
 {
     if (P <= 0) return 0;
     if (P > 4000000L) return -3;   // gridDim.y of the P x N GEMMs; callers chunk larger batches
     Bwd b{stream, P};
-    b.zero = ws + P * (256L * 3 + 96 + 32 + 12) + DB_SCRATCH - 64;   // tail of the (zeroed) bias-gradient scratch, never written
-    b.wal = ws + P * (256L * 3 + 96 + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS;
+    b.zero = ws + P * (256L * 3 + DIN_LD + 32 + 12) + DB_SCRATCH - 64;   // tail of the (zeroed) bias-gradient scratch, never written
+    b.wal = ws + P * (256L * 3 + DIN_LD + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS;
     const FlatOffsets &F = kFlat;
     const FlatOffsets::Lvl &Lv = F.lvl[level];
-    float *gA = ws, *gB = gA + P * 256, *dfeat = gB + P * 256, *din = dfeat + P * 256, *dgridf = din + P * 96, *dxw = dgridf + P * 32,
+    float *gA = ws, *gB = gA + P * 256, *dfeat = gB + P * 256, *din = dfeat + P * 256, *dgridf = din + P * DIN_LD, *dxw = dgridf + P * 32,
           *dw = dxw + P * 4, *g3 = dw + P * 4, *db = g3 + P * 4, *grid_cl = db + DB_SCRATCH, *dgrid_cl = grid_cl + GRID_FLOATS;
     const long AS = act::STRIDE;
     if (hipMemsetAsync(db, 0, sizeof(float) * DB_SCRATCH, stream) != hipSuccess) return (int)hipGetLastError();
     if (hipMemsetAsync(dgrid_cl, 0, sizeof(float) * GRID_FLOATS, stream) != hipSuccess) return (int)hipGetLastError();
     const float *drv = frame + FRAME_DRV_OFF, *p36 = frame + FRAME_POSE_OFF;
     float *d_drv = grad_cond + 0, *d_p36 = grad_cond + 80;
+    const float *trc = TRUNK_SEES_POSE ? p36 : drv;          // the per-frame constant the trunk sees, and its gradient slot
+    float *d_trc = TRUNK_SEES_POSE ? d_p36 : d_drv;
     auto W = [&](long off) { return flat + off; };
     auto G = [&](long off) { return grad_flat + off; };
     int dbo = 0;   // running offset into db scratch
@@ -662,21 +676,21 @@ extern "C" int sahs_field_backward_launch(const float *flat, const float *frame,
     {
         // feat = fc_feat(t7)
         float *d = newdb(TR_H);
-        b.tn(dfeat, 256, TR_H, A + act::T + 7 * 256, AS, TR_H, G(Lv.feat_w), TR_H, d);
+        b.tn(dfeat, 256, TR_H, A + act::T + (TR_LAYERS - 1) * 256, AS, TR_H, G(Lv.feat_w), TR_H, d);
         add_bias(d, Lv.feat_b, TR_H);
-        b.nn(dfeat, 256, TR_H, W(Lv.feat_w), TR_H, TR_H, gA, 256, 0, A + act::T + 7 * 256, AS, 0.01f);
+        b.nn(dfeat, 256, TR_H, W(Lv.feat_w), TR_H, TR_H, gA, 256, 0, A + act::T + (TR_LAYERS - 1) * 256, AS, 0.01f);
         float *cur = gA, *nxt = gB;
-        for (int i = 7; i >= 1; --i) {   // layers_xyz[i]: input t_{i-1} (and, for i == 3, [PE(x') | PE(w) | pose36])
+        for (int i = TR_LAYERS - 1; i >= 1; --i) {   // layers_xyz[i]: input t_{i-1} (and, for i == 3, [PE(x') | PE(w) | pose36])
             float *dl = newdb(TR_H);
             const long ldw = (i == 3) ? TR_H + D_TR_IN : TR_H;
             b.tn(cur, 256, TR_H, A + act::T + (i - 1) * 256, AS, TR_H, G(Lv.xyz_w[i]), ldw, dl);
             add_bias(dl, Lv.xyz_b[i], TR_H);
             if (i == 3) {
                 b.tn(cur, 256, TR_H, A + act::PEX, AS, D_XYZ, G(Lv.xyz_w[3]) + TR_H, ldw);
-                b.tn(cur, 256, TR_H, A + act::PEW, AS, D_AMB, G(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw);
-                consts(Lv.xyz_w[3], ldw, TR_H, TR_H + D_XYZ + D_AMB, D_POSE, dl, p36, d_p36);
-                b.nn(cur, 256, TR_H, W(Lv.xyz_w[3]) + TR_H, ldw, D_XYZ, din, 96, 0);        // first writer of din stores,
-                b.nn(cur, 256, TR_H, W(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw, D_AMB, din + 64, 96, 0);   // layers_xyz[0] below accumulates
+                if (D_AMB > 0) b.tn(cur, 256, TR_H, A + act::PEW, AS, D_AMB, G(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw);
+                consts(Lv.xyz_w[3], ldw, TR_H, TR_H + D_XYZ + D_AMB, D_TR_CONST, dl, trc, d_trc);
+                b.nn(cur, 256, TR_H, W(Lv.xyz_w[3]) + TR_H, ldw, D_XYZ, din, DIN_LD, 0);        // first writer of din stores,
+                if (D_AMB > 0) b.nn(cur, 256, TR_H, W(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw, D_AMB, din + DIN_AMB, DIN_LD, 0);   // layers_xyz[0] below accumulates
             }
             b.nn(cur, 256, TR_H, W(Lv.xyz_w[i]), ldw, TR_H, nxt, 256, 0, A + act::T + (i - 1) * 256, AS, 0.01f);
             float *t = cur; cur = nxt; nxt = t;
@@ -684,11 +698,11 @@ extern "C" int sahs_field_backward_launch(const float *flat, const float *frame,
         // layers_xyz[0]: [PE63(x') | PE18(w) | pose36] -> t0
         float *dl = newdb(TR_H);
         b.tn(cur, 256, TR_H, A + act::PEX, AS, D_XYZ, G(Lv.xyz_w[0]), D_TR_IN, dl);
-        b.tn(cur, 256, TR_H, A + act::PEW, AS, D_AMB, G(Lv.xyz_w[0]) + D_XYZ, D_TR_IN);
+        if (D_AMB > 0) b.tn(cur, 256, TR_H, A + act::PEW, AS, D_AMB, G(Lv.xyz_w[0]) + D_XYZ, D_TR_IN);
         add_bias(dl, Lv.xyz_b[0], TR_H);
-        consts(Lv.xyz_w[0], D_TR_IN, TR_H, D_XYZ + D_AMB, D_POSE, dl, p36, d_p36);
-        b.nn(cur, 256, TR_H, W(Lv.xyz_w[0]), D_TR_IN, D_XYZ, din, 96, 1);
-        b.nn(cur, 256, TR_H, W(Lv.xyz_w[0]) + D_XYZ, D_TR_IN, D_AMB, din + 64, 96, 1);
+        consts(Lv.xyz_w[0], D_TR_IN, TR_H, D_XYZ + D_AMB, D_TR_CONST, dl, trc, d_trc);
+        b.nn(cur, 256, TR_H, W(Lv.xyz_w[0]), D_TR_IN, D_XYZ, din, DIN_LD, 1);
+        if (D_AMB > 0) b.nn(cur, 256, TR_H, W(Lv.xyz_w[0]) + D_XYZ, D_TR_IN, D_AMB, din + DIN_AMB, DIN_LD, 1);
     }
     // ================= encodings + feature grid -> d x', d w =================
     {
@@ -699,12 +713,13 @@ extern "C" int sahs_field_backward_launch(const float *flat, const float *frame,
         grid_transpose_kernel<<<tb, 256, 0, stream>>>(dgrid_cl, G(F.grid), 1); b.check();
         encode_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, din, dxw, dw); b.check();
     }
+#if SAHS_MODEL != 2
     // ================= hyper sheet (modules.py:444-462): w = fc_ambient(g5) =================
     {
         float *dbl = newdb(4);
-        b.tn(dw, 4, 2, A + act::HH + 5 * 64, AS, HYP_H, G(F.hyp_fw), HYP_H, dbl);
-        add_bias(dbl, F.hyp_fb, 2);
-        b.nn(dw, 4, 2, W(F.hyp_fw), HYP_H, HYP_H, gA, 256, 0, A + act::HH + 5 * 64, AS, 0.0f);
+        b.tn(dw, 4, AMB_DIM, A + act::HH + 5 * 64, AS, HYP_H, G(F.hyp_fw), HYP_H, dbl);
+        add_bias(dbl, F.hyp_fb, AMB_DIM);
+        b.nn(dw, 4, AMB_DIM, W(F.hyp_fw), HYP_H, HYP_H, gA, 256, 0, A + act::HH + 5 * 64, AS, 0.0f);
         float *cur = gA, *nxt = gB;
         for (int i = 5; i >= 1; --i) {
             float *dl = newdb(HYP_H);
@@ -752,6 +767,9 @@ extern "C" int sahs_field_backward_launch(const float *flat, const float *frame,
         consts(F.warp_w[0], D_DEF_IN, WARP_H, D_XYZ, D_DRV, dl, drv, d_drv);
         consts(F.warp_w[0], D_DEF_IN, WARP_H, D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);
     }
+#else
+    (void)drv; (void)d_p36; (void)p36; (void)g3;   // no deformation nets: the gradient stops at the (input) point
+#endif
     (void)layer_params;
     return b.err;
 }

@@ -302,7 +302,10 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         }
 #if SAHS_MODEL == 2
         // no deformation nets (use_warp False, use_ambient False): the template is queried at the raw point (models.py:316-327)
-        if (q == 0) { stash[0] = x[0]; stash[1] = x[1]; stash[2] = x[2]; stash[3] = 0.0f; stash[4] = 0.0f; }
+        if (q == 0) {
+            stash[0] = x[0]; stash[1] = x[1]; stash[2] = x[2]; stash[3] = 0.0f; stash[4] = 0.0f;
+            if (SAVE && sv != nullptr) { sv[act::XW] = x[0]; sv[act::XW + 1] = x[1]; sv[act::XW + 2] = x[2]; }   // the grid backward reads it
+        }
 #else
         f32x4 pe_x[KB_XYZ];
         {

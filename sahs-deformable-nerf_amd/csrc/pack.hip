@@ -253,3 +253,4 @@ extern "C" int SAHS_SYM(sahs_fold_conditioning_launch)(const float *flat, const 
 extern "C" long SAHS_SYM(sahs_layout_param_count)(void) { return kFlat.total; }
 extern "C" long SAHS_SYM(sahs_layout_packed_words_f32)(void) { return PACK_FLOATS; }
 extern "C" long SAHS_SYM(sahs_layout_frame_words)(void) { return FRAME_FLOATS; }
+extern "C" long SAHS_SYM(sahs_layout_act_words)(void) { return act::STRIDE; }

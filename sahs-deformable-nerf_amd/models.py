@@ -173,7 +173,7 @@ class AudioFaceModel(_FieldModel):
 class NeRFaceModel(_FieldModel):
     """models.py:189-378: expression-driven (driving = the 76-d expression vector).  Two architectures, chosen by the config as
     the reference does (models.py:231,244): warp + hyper sheet on (config/expression/person_2.yml, person_3.yml) or both off
-    (person_1.yml).  fp32 forward (rendering) in this round; training and bf16 stay with the AudioFaceModel."""
+    (person_1.yml).  fp32 rendering and training; the bf16 kernel stays with the AudioFaceModel."""
 
     def __init__(self, cfg, precision="fp32"):
         super().__init__()

@@ -202,23 +202,23 @@ def render_rays(packed, frame, rays, num_coarse, num_fine, precision=SAHS_F32, l
 # ---------------------------------------------------------------------------------------------------------
 # training path
 # ---------------------------------------------------------------------------------------------------------
-def field_forward_save(packed, frame, level, rays, z):
+def field_forward_save(packed, frame, level, rays, z, arch="audio"):
     """fp32 field forward that also returns the saved activations (N*S, act_words) for field_backward."""
     packed, frame, rays, z = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays"), _req(z, "z")
     N, S = z.shape
     raw = torch.empty(N, S, 16, dtype=torch.float32, device=z.device)
-    act = torch.empty(N * S, _lib.lib().sahs_act_words_per_sample(), dtype=torch.float32, device=z.device)
-    check(_lib.lib().sahs_field_forward_save(_p(packed), _p(frame), int(level), N, S, _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(act),
-                                              _stream()), "sahs_field_forward_save")
+    act = torch.empty(N * S, _fn("act_words_per_sample", arch)[0](), dtype=torch.float32, device=z.device)
+    f, name = _fn("field_forward_save", arch)
+    check(f(_p(packed), _p(frame), int(level), N, S, _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(act), _stream()), name)
     return raw, act
 
 
-def field_backward(flat, frame, level, act, d_raw, grad_flat, grad_cond):
+def field_backward(flat, frame, level, act, d_raw, grad_flat, grad_cond, arch="audio"):
     flat, frame, act, d_raw = _req(flat, "flat_params"), _req(frame, "frame"), _req(act, "act"), _req(d_raw, "d_raw")
     P = act.shape[0]
-    ws = torch.empty(_lib.lib().sahs_field_backward_workspace_words(P), dtype=torch.float32, device=act.device)
-    check(_lib.lib().sahs_field_backward(_p(flat), _p(frame), int(level), P, _p(act), _p(d_raw), _p(grad_flat), _p(grad_cond), _p(ws), _stream()),
-          "sahs_field_backward")
+    ws = torch.empty(_fn("field_backward_workspace_words", arch)[0](P), dtype=torch.float32, device=act.device)
+    f, name = _fn("field_backward", arch)
+    check(f(_p(flat), _p(frame), int(level), P, _p(act), _p(d_raw), _p(grad_flat), _p(grad_cond), _p(ws), _stream()), name)
 
 
 def composite_backward(raw, z, rays, noise, bg, white_background, d_rgb, d_disp, d_acc, d_depth, d_wlast):
@@ -242,17 +242,19 @@ class RenderRaysFn(torch.autograd.Function):
     BLOCK_RAYS = 4096
 
     @staticmethod
-    def forward(ctx, flat, audio, pose, rays, bg, t_rand, noise_c, u, noise_f, packed, num_coarse, num_fine, lindisp, white_background):
-        frame = fold_conditioning(flat.detach(), audio.detach(), pose)
+    def forward(ctx, flat, audio, pose, rays, bg, t_rand, noise_c, u, noise_f, packed, num_coarse, num_fine, lindisp, white_background,
+                arch="audio"):
+        frame = fold_conditioning(flat.detach(), audio.detach(), pose, arch=arch)
+        ctx.arch = arch
         none = torch.empty(0, device=rays.device)
         ctx.cfg = (num_coarse, num_fine, bool(white_background), bg is not None, noise_c is not None, noise_f is not None)
         ctx.kept = rays.shape[0] <= RenderRaysFn.BLOCK_RAYS and num_fine > 0
         if ctx.kept:     # the same launch chain as sahs_render_rays, with the field activations kept
             z_c = stratified_depths(rays, num_coarse, lindisp, t_rand)
-            raw_c, act_c = field_forward_save(packed, frame, 0, rays, z_c)
+            raw_c, act_c = field_forward_save(packed, frame, 0, rays, z_c, arch)
             rgb_c, disp_c, acc_c, w_c, _ = composite_forward(raw_c, z_c, rays, noise_c, bg, white_background)
             z_f = resample(z_c, w_c, num_fine, u)
-            raw_f, act_f = field_forward_save(packed, frame, 1, rays, z_f)
+            raw_f, act_f = field_forward_save(packed, frame, 1, rays, z_f, arch)
             rgb_f, disp_f, acc_f, w_f, depth_f = composite_forward(raw_f, z_f, rays, noise_f, bg, white_background)
             outs = (rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_f[:, -1].contiguous(), depth_f)
             ctx.save_for_backward(flat.detach(), audio.detach(), rays, z_c, z_f, frame, packed,
@@ -260,7 +262,7 @@ class RenderRaysFn(torch.autograd.Function):
             return outs
         ws = {}
         outs = render_rays(packed, frame, rays, num_coarse, num_fine, precision=SAHS_F32, lindisp=lindisp, white_background=white_background,
-                           bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f, workspace=ws)
+                           bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f, workspace=ws, arch=arch)
         ctx.save_for_backward(flat.detach(), audio.detach(), rays, ws["z_c"].clone(), ws["z_f"].clone() if num_fine > 0 else none, frame, packed,
                               *[t if t is not None else none for t in (bg, noise_c, noise_f)])
         return outs
@@ -289,12 +291,15 @@ class RenderRaysFn(torch.autograd.Function):
                 if all(g is None for g in grads):
                     continue
                 zb = z[sl].contiguous()
-                raw, act = kept[level] if kept is not None else field_forward_save(packed, frame, level, rb, zb)
+                raw, act = kept[level] if kept is not None else field_forward_save(packed, frame, level, rb, zb, ctx.arch)
                 nb = None if noise is None else noise[sl].contiguous()
                 gb = [None if g is None else c(g[sl]) for g in grads]
                 d_raw = composite_backward(raw, zb, rb, nb, bgb, white, *gb)
-                field_backward(flat, frame, level, act, d_raw.view(-1, 16), grad_flat, grad_cond)
+                field_backward(flat, frame, level, act, d_raw.view(-1, 16), grad_flat, grad_cond, ctx.arch)
                 del raw, act, d_raw
-        check(_lib.lib().sahs_conditioning_backward(_p(flat), _p(audio), _p(grad_cond), _p(grad_flat), _p(grad_audio), _stream()),
-              "sahs_conditioning_backward")
-        return (grad_flat, grad_audio) + (None,) * 12
+        if ctx.arch == "audio":
+            check(_lib.lib().sahs_conditioning_backward(_p(flat), _p(audio), _p(grad_cond), _p(grad_flat), _p(grad_audio), _stream()),
+                  "sahs_conditioning_backward")
+        else:       # NeRFaceModel: the driving vector is the expression itself
+            grad_audio = grad_cond[:76].clone()
+        return (grad_flat, grad_audio) + (None,) * 13

@@ -76,15 +76,13 @@ def predict_and_render_radiance(ray_batch, model, options, mode="train", driving
             raise NotImplementedError("background_prior must have 15 channels (rgb3 + seg12)")
         bg = background_prior.to(torch.float32)
     arch = getattr(model, "arch", "audio")
-    if needs_grad and arch != "audio":
-        raise NotImplementedError("the HIP backward covers the AudioFaceModel; render the NeRFaceModel under torch.no_grad()")
     if needs_grad:
         # training step (train_stage_rays_auto.py:437-499): differentiable op, fp32; its backward runs the HIP backward kernels
         if model.precision != ops.SAHS_F32:
             raise NotImplementedError("training runs the fp32 path; build the model with precision='fp32'")
         flat = model.flat_params(differentiable=True)
         return ops.RenderRaysFn.apply(flat, driving.to(torch.float32), pose.to(torch.float32), rays.detach(), bg, t_rand, noise_c, u, noise_f,
-                                      packed, nc, nf, bool(opt.lindisp), bool(opt.white_background))
+                                      packed, nc, nf, bool(opt.lindisp), bool(opt.white_background), arch)
     return ops.render_rays(packed, frame, rays, nc, nf, precision=model.precision, lindisp=bool(opt.lindisp),
                            white_background=bool(opt.white_background), bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f,
                            workspace=_workspace, arch=arch)

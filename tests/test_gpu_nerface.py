@@ -137,7 +137,7 @@ def test_end_to_end_vs_golden(ops, nf, name):
         close(v.reshape(g["out_" + nm].shape), g["out_" + nm], 5e-4, 1e-4, name + ": fine pass on reference depths: " + nm)
 
 
-def test_model_seam_and_training_guard(nf):
+def test_model_seam_and_config_guard(nf):
     sahs = pkg()
     cfg = sahs.default_config("expression")
     fw, flat, packed = nf(density_bias=8.0, density_gain=30.0)
@@ -148,10 +148,9 @@ def test_model_seam_and_training_guard(nf):
         raw = model("coarse", x, T(g["expression"]), T(g["pose"]), None)
     close(raw[:, :15], g["boosted_raw_coarse"][:, :15], 2e-3, 2e-3, "model(...) seam")
     with pytest.raises(NotImplementedError):
-        sahs.run_one_iter_of_nerf(0, 0, None, model.train(), x[:8, :3], x[:8, 3:6], cfg, mode="train", driving=T(g["expression"]),
-                                  pose=T(g["pose"]))
-    with pytest.raises(NotImplementedError):
         sahs.NeRFaceModel(sahs.default_config("audio"))
+    with pytest.raises(NotImplementedError):
+        sahs.NeRFaceModel(cfg, precision="bf16")
 
 
 # ---- config/expression/person_1.yml: NeRFaceModel without deformation nets (use_warp False, use_ambient False) ----
@@ -214,3 +213,176 @@ def test_static_end_to_end_vs_golden(nf):
     names = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"]
     for nm, o in zip(names, outs):   # 10 octaves, no warp: the audio model's end-to-end tolerance
         close(o, g["out_" + nm], 2e-3, 2e-4, "static e2e:" + nm)
+
+
+# ---- training path of the NeRFaceModels: HIP backward vs the reference's own autograd (golden) and vs eager autograd ----
+@pytest.mark.parametrize("arch", ["nerface", "nerface_static"])
+def test_gradients_vs_golden(nf, arch):
+    """Train mode, noise 0.1, loss = <rgb_c,A> + <rgb_f,B> + 0.1*sum(depth_f) through ops.RenderRaysFn, on the reference's rays and
+    random draws; gradients against the reference's (tests/golden/make_golden_nerface.py).  The 15-octave model's fine pass (and
+    with it the gradients) is ill-conditioned in the resampled depths -- see test_oracle_nerface_vs_golden.py -- hence its looser
+    bound; the 10-octave one is held to the audio model's."""
+    sahs = pkg()
+    g = load_golden(arch + "_train_grads")
+    cfg = sahs.default_config("expression" if arch == "nerface" else "expression_static")
+    fw, flat, packed = nf(0, 8.0, 30.0, arch=arch)
+    model = sahs.NeRFaceModel(cfg).to(dev()).load_flat(fw).train()
+    expr = T(g["expression"]).requires_grad_(True)
+    with FeedRand(golden_rand(g)) as feed:
+        outs = sahs.run_one_iter_of_nerf(10, 10, None, model, T(g["ro"]), T(g["rd"]), cfg, mode="train", driving=expr, pose=T(g["pose"]),
+                                         background_prior=T(g["bg"]), inHead=torch.zeros(32, 12, device=dev()))
+        assert not feed.log
+    # entries: the chained 15-octave gradients differ by tens of percents on single entries (resampled depths + kink flips, for
+    # the reference's own CPU-vs-GPU runs alike); their exactness is established by test_field_backward_seam_vs_autograd
+    rn, ra = (1e-1, 0.5) if arch == "nerface" else (5e-3, 1e-2)
+    loss = (outs[0] * T(g["A"])).sum() + (outs[3] * T(g["B"])).sum() + outs[7].sum() * 0.1
+    assert abs(float(loss) - float(g["loss"])) <= rn * abs(float(g["loss"])) + 1e-3
+    loss.backward()
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for k, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        gr = params[k].grad
+        assert gr is not None, k
+        n = float(gr.double().norm())
+        assert abs(n - ref_norm) <= rn * ref_norm + 1e-7, (k, n, ref_norm)
+        if "grad_" + k in g:
+            ref = g["grad_" + k]
+            err = float(np.abs(gr.cpu().numpy() - ref).max()) / (float(np.abs(ref).max()) + 1e-12)
+            worst = max(worst, err)
+            assert err <= ra, (k, err)
+    ge = expr.grad.cpu().numpy()
+    assert float(np.abs(ge - g["grad_expression"]).max()) <= ra * float(np.abs(g["grad_expression"]).max()), "d expression"
+    print("worst entry error / tensor scale: %.2e" % worst)
+
+
+@pytest.mark.parametrize("arch", ["nerface", "nerface_static"])
+def test_train_step_vs_eager_autograd(nf, arch):
+    """256 rays, identical inputs and draws: the HIP backward against plain torch autograd of the eager restatement (itself pinned
+    to the reference's gradients on CPU).  Same depths on both sides, so this comparison is tight for both architectures."""
+    from oracle import torch_eager as TE
+    sahs = pkg()
+    W = pkg("weights")
+    cfg = sahs.default_config("expression" if arch == "nerface" else "expression_static")
+    sd_np = W.hash_state_dict(0, 8.0, 30.0, model=arch)
+    fw, flat, packed = nf(0, 8.0, 30.0, arch=arch)
+    model = sahs.NeRFaceModel(cfg).to(dev()).load_flat(fw).train()
+    sd_t = {k: torch.from_numpy(v).to(dev()).requires_grad_(True) for k, v in sd_np.items()}
+    field = TE.EagerField(sd_t, arch=arch)
+    R = 256
+    gen = torch.Generator(device=dev()).manual_seed(5)
+    expr = (torch.randn(76, device=dev(), generator=gen) * 0.5)
+    pose = T(np.concatenate([np.eye(3), [[0.0], [0.0], [0.5]]], 1).astype(np.float32))
+    ro = torch.zeros(R, 3, device=dev())
+    ro[:, 2] = 0.5
+    rd = torch.randn(R, 3, device=dev(), generator=gen) * 0.15 + torch.tensor([0, 0, -1.0], device=dev())
+    bg = torch.cat([torch.rand(R, 3, device=dev(), generator=gen), torch.ones(R, 1, device=dev()), torch.zeros(R, 11, device=dev())], 1)
+    A, B = torch.randn(R, 15, device=dev(), generator=gen), torch.randn(R, 15, device=dev(), generator=gen)
+    rand = dict(t_rand=torch.rand(R, 64, device=dev(), generator=gen), noise_c=torch.randn(R, 64, device=dev(), generator=gen) * 0.1,
+                u=torch.rand(R, 64, device=dev(), generator=gen), noise_f=torch.randn(R, 128, device=dev(), generator=gen) * 0.1)
+    feed = [("rand", rand["t_rand"].cpu().numpy()), ("randn", (rand["noise_c"] / 0.1).cpu().numpy()), ("rand", rand["u"].cpu().numpy()),
+            ("randn", (rand["noise_f"] / 0.1).cpu().numpy())]
+    e1 = expr.clone().requires_grad_(True)
+    with FeedRand(feed):
+        outs = sahs.run_one_iter_of_nerf(0, 0, None, model, ro, rd, cfg, mode="train", driving=e1, pose=pose, background_prior=bg)
+    loss = (outs[0] * A).sum() + (outs[3] * B).sum() + outs[7].sum() * 0.1
+    loss.backward()
+    e2 = expr.clone().requires_grad_(True)
+    o2 = TE.run_one_iter(field, ro, rd, cfg.dataset.near, cfg.dataset.far, e2, pose, bg=bg, rand=[rand], perturb=True, noise_std=0.1)
+    l2 = (o2[0] * A).sum() + (o2[3] * B).sum() + o2[7].sum() * 0.1
+    l2.backward()
+    assert abs(float(loss) - float(l2)) <= 2e-2 * abs(float(l2)) + 1e-2
+    tol = 0.5 if arch == "nerface" else 2e-2     # see test_gradients_vs_golden
+    for k, p in model.named_parameters():
+        ref = sd_t[k].grad
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((p.grad - ref).abs().max()) / scale
+        assert err <= tol, "%s: %.3e of scale" % (k, err)
+    assert float((e1.grad - e2.grad).abs().max()) <= tol * float(e2.grad.abs().max())
+
+
+@pytest.mark.parametrize("arch,level", [("nerface", 0), ("nerface", 1), ("nerface_static", 1), ("audio", 1)])
+def test_field_backward_seam_vs_autograd(ops, nf, arch, level):
+    """sahs_model_field_forward_save + sahs_model_field_backward on explicit rays/depths against torch autograd of the eager field on
+    the same points with the same upstream gradient: no resampling in the loop, so this is well conditioned for every architecture
+    (what is left of the 15-octave amplification is the 1e-7 round-off of x' times 2^14).  The yardstick is float64 autograd evaluated on the
+    SAME side of every (leaky-)ReLU kink as the HIP forward (its saved activations): two correct fp32 forwards that differ by 1e-5
+    put a handful of pre-activations on different sides of zero, and with density-boosted weights one such sample moves a
+    bias-gradient entry by percents -- that, not the backward arithmetic, is what separates the HIP gradients from PyTorch's in
+    the end-to-end gradient tests (observed there: up to 1.7e-2 of scale).  With the branches pinned the bound is 2e-3 (observed: audio 1.5e-5,
+    static 5e-6, 15-octave model 5e-4)."""
+    from oracle import torch_eager as TE
+    W = pkg("weights")
+    S = 64 if level == 0 else 128
+    N = 24
+    gen = torch.Generator(device=dev()).manual_seed(11 + level)
+    if arch == "audio":
+        fw = W.flatten_state_dict(W.hash_state_dict(0, 8.0, 30.0))
+        flat = T(fw)
+        packed = ops.pack_weights(flat)
+        driving = torch.randn(16, 29, device=dev(), generator=gen)
+        near, far, cam = 0.48, 1.08, 0.8
+        sd_np = W.hash_state_dict(0, 8.0, 30.0)
+    else:
+        fw, flat, packed = nf(0, 8.0, 30.0, arch=arch)
+        driving = torch.randn(76, device=dev(), generator=gen) * 0.5
+        near, far, cam = 0.2, 0.8, 0.5
+        sd_np = W.hash_state_dict(0, 8.0, 30.0, model=arch)
+    pose = T(np.concatenate([np.eye(3), [[0.0], [0.0], [cam]]], 1).astype(np.float32))
+    rays = torch.zeros(N, 8, device=dev())
+    rays[:, 2] = cam
+    rays[:, 3:6] = torch.randn(N, 3, device=dev(), generator=gen) * 0.15 + torch.tensor([0, 0, -1.0], device=dev())
+    z = torch.sort(torch.rand(N, S, device=dev(), generator=gen) * (far - near) + near, dim=1).values
+    d_raw = torch.randn(N * S, 16, device=dev(), generator=gen)
+    frame = ops.fold_conditioning(flat, driving, pose, arch=arch)
+    raw, act = ops.field_forward_save(packed, frame, level, rays, z, arch)
+    grad_flat = torch.zeros_like(flat)
+    grad_cond = torch.zeros(128, device=dev())
+    ops.field_backward(flat, frame, level, act, d_raw, grad_flat, grad_cond, arch)
+    x6 = torch.cat([rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None], rays[:, None, 3:6].expand(N, S, 3)], -1).reshape(-1, 6)
+    lvl = "coarse" if level == 0 else "fine"
+
+    # which side of zero every hidden unit is on, as the HIP forward saw it (saved post-activations; sahs::act layout)
+    kbx, kba, trl = {"audio": (4, 2, 8), "nerface": (6, 2, 4), "nerface_static": (4, 0, 4)}[arch]
+    WH = 16 * kbx; HH = WH + 6 * 128 + 16; Tt = HH + 6 * 64 + 32 + 16 * kbx + 16 * kba; C = Tt + trl * 256 + 256 + 64; Ss = C + 512
+    assert act.shape[1] == Ss + 512
+    masks = {}
+    for i in range(6):
+        masks["warp.%d" % i] = act[:, WH + 128 * i: WH + 128 * (i + 1)] > 0
+        masks["hyper.%d" % i] = act[:, HH + 64 * i: HH + 64 * (i + 1)] > 0
+    for i in range(trl):
+        masks["trunk.%d" % i] = act[:, Tt + 256 * i: Tt + 256 * (i + 1)] > 0
+    for i in range(4):
+        masks["dir.%d" % i] = act[:, C + 128 * i: C + 128 * (i + 1)] > 0
+        masks["seg.%d" % i] = act[:, Ss + 128 * i: Ss + 128 * (i + 1)] > 0
+
+    def autograd(dtype, use_masks):
+        sd_t = {k: torch.from_numpy(v).to(dev()).to(dtype).requires_grad_(True) for k, v in sd_np.items()}
+        drv = driving.to(dtype).clone().requires_grad_(True)
+        raw_e = TE.EagerField(sd_t, arch=arch, masks=masks if use_masks else None).forward(lvl, x6.to(dtype), drv, pose.to(dtype))
+        (raw_e * d_raw.to(dtype)).sum().backward()
+        return raw_e.detach(), sd_t, drv.grad
+
+    raw32, g32, dd32 = autograd(torch.float32, False)     # plain fp32 PyTorch: its own branch decisions
+    raw64, g64, dd64 = autograd(torch.float64, True)      # the yardstick: exact arithmetic on the HIP forward's side of every kink
+    close(raw.reshape(-1, 16)[:, :15], raw64[:, :15].cpu().numpy(), 2e-3, 2e-3, "raw")
+    off = W.canonical_offsets(arch)
+    worst = ("", 0.0, 0.0)
+    for k, (o, shape) in off.items():
+        if ("nerf_mlps." in k and lvl not in k) or k.startswith("audNet_head"):
+            continue                      # the other level's net gets no gradient; AudioNet is sahs_conditioning_backward's
+        ref = g64[k].grad
+        got = grad_flat[o:o + ref.numel()].view_as(ref).double()
+        scale = float(ref.abs().max()) + 1e-30
+        err = float((got - ref).abs().max()) / scale
+        err32 = float((g32[k].grad.double() - ref).abs().max()) / scale
+        if err > worst[1]:
+            worst = (k, err, err32)
+        # 2e-3, except for sums that cancel (the single fc_ambient bias under 15 octaves: plain fp32 autograd is off by 31 % there,
+        # the HIP value by 1 %): never worse than half of what fp32 PyTorch makes of the same tensor
+        assert err <= max(2e-3, 0.5 * err32), "%s: %.3e of scale (plain fp32 autograd, own branches: %.3e)" % (k, err, err32)
+    print("worst: %s %.3e of scale (plain fp32 autograd with its own branch decisions: %.3e)" % worst)
+    if arch != "audio":
+        sc = float(dd64.abs().max())
+        e, e32 = float((grad_cond[:76].double() - dd64).abs().max()) / sc, float((dd32.double() - dd64).abs().max()) / sc
+        assert e <= max(2e-3, 0.5 * e32), (e, e32)
+

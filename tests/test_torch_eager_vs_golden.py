@@ -83,3 +83,38 @@ def test_gradients(weights_mod):
         if "grad_" + k in g.keys():
             close(gr, g["grad_" + k], 5e-3, 2e-3 * float(np.abs(g["grad_" + k]).max()) + 1e-9, "grad " + k)
     close(audio.grad, g["grad_audio"], 5e-3, 2e-3 * float(np.abs(g["grad_audio"]).max()), "grad audio")
+
+
+@pytest.mark.parametrize("arch", ["nerface", "nerface_static"])
+def test_nerface_forward_and_gradients(weights_mod, arch):
+    """The NeRFaceModel architectures of the eager restatement (the gradient oracle of their HIP backward): forward seam and the
+    reference's own parameter / expression gradients (tests/golden/make_golden_nerface.py, train mode, noise 0.1)."""
+    sd = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in weights_mod.hash_state_dict(0, 8.0, 30.0, model=arch).items()}
+    f = TE.EagerField(sd, arch=arch)
+    fld = load_golden(arch + "_field")
+    with torch.no_grad():
+        out = f.forward("fine", torch.from_numpy(fld["x"]), torch.from_numpy(fld["expression"]), torch.from_numpy(fld["pose"]))
+    tol = 2e-3 if arch == "nerface" else 1e-4      # 15 octaves: see test_oracle_nerface_vs_golden.py
+    close(out[:, :15], fld["boosted_raw_fine"][:, :15], tol, tol, "raw fine")
+    g = load_golden(arch + "_train_grads")
+    expr = torch.from_numpy(g["expression"]).requires_grad_(True)
+    mask = torch.zeros(32, 12)
+    mask[:, 0] = 1.0
+    log = golden_rand(g)
+    rand = [dict(t_rand=torch.from_numpy(log[0][1]), noise_c=torch.from_numpy(log[1][1]) * 0.1, u=torch.from_numpy(log[2][1]),
+                 noise_f=torch.from_numpy(log[3][1]) * 0.1)]
+    outs = TE.run_one_iter(f, torch.from_numpy(g["ro"]), torch.from_numpy(g["rd"]), float(g["near"]), float(g["far"]), expr,
+                           torch.from_numpy(g["pose"]), bg=torch.from_numpy(g["bg"]), rand=rand, perturb=True, noise_std=0.1, mask=mask)
+    loss = (outs[0] * torch.from_numpy(g["A"])).sum() + (outs[3] * torch.from_numpy(g["B"])).sum() + outs[7].sum() * 0.1
+    # the 15-octave model's fine pass is ill-conditioned in the resampled depths (a 1e-5 depth change turns the top octave by
+    # 0.16 rad), and so are its gradients: norms to 3 %, entries to 5 % of the tensor's scale; the 10-octave one as the audio model
+    rn, ra = (3e-2, 5e-2) if arch == "nerface" else (2e-3, 2e-3)
+    assert abs(loss.item() - float(g["loss"])) < rn * abs(float(g["loss"])) + 1e-3
+    loss.backward()
+    for k, ref_norm in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        gr = sd[k].grad
+        n = 0.0 if gr is None else float(gr.double().norm())
+        assert abs(n - ref_norm) <= rn * ref_norm + 1e-7, (k, n, ref_norm)
+        if "grad_" + k in g.keys():
+            close(gr, g["grad_" + k], 5e-3, ra * float(np.abs(g["grad_" + k]).max()) + 1e-9, "grad " + k)
+    close(expr.grad, g["grad_expression"], 5e-3, ra * float(np.abs(g["grad_expression"]).max()), "grad expression")
