@@ -79,7 +79,8 @@ def _save_png(path, arr):
 
 
 def render_frames(model, cfg, frames, hwf, background=None, pose_c=None, savedir=None, save_disparity=False, log=print):
-    """frames: iterable of dict(pose (3|4,4), audio (16,29), mask (H,W,12) optional, name optional).
+    """frames: iterable of dict(pose (3|4,4), audio (16,29) [AudioFaceModel] or expression (76,) [NeRFaceModel], mask (H,W,12)
+    optional, name optional).
     hwf = (H, W, intrinsics[fx, fy, cx, cy]).  Returns the list of per-frame outputs (dicts of tensors)."""
     H, W, focal = hwf
     results, times = [], []
@@ -89,7 +90,7 @@ def render_frames(model, cfg, frames, hwf, background=None, pose_c=None, savedir
         t0 = time.time()
         with torch.no_grad():
             pose = torch.as_tensor(fr["pose"], dtype=torch.float32, device=dev)[:3, :4].contiguous()
-            audio = torch.as_tensor(fr["audio"], dtype=torch.float32, device=dev)
+            audio = torch.as_tensor(fr["audio"] if "audio" in fr else fr["expression"], dtype=torch.float32, device=dev)
             mask = fr.get("mask")
             mask = torch.as_tensor(shrink(mask)).to(dev) if mask is not None else None
             ro, rd = get_ray_bundle(H, W, focal, pose)

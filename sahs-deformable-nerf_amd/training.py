@@ -86,3 +86,22 @@ def train_step(model, optimizer, cfg, step, image, mask, pose, intrinsics, audio
     for group in optimizer.param_groups:
         group["lr"] = learning_rate(cfg, step)
     return dict(loss=float(loss.detach()), psnr=mse2psnr(float(fine_mse.detach())), sample_prob=new_prob)
+
+
+def save_checkpoint(path, step, model, optimizer, loss, i_batch=0, background=None, latent_codes=None, pose_c=None, sample_prob=None):
+    """The checkpoint dict of train_stage_rays_auto.py:698-722 (same keys), so files written here load in the reference and
+    vice versa (its eval script reads model_state_dict / background / pose_c, eval_stage_rays.py:302-327)."""
+    torch.save({"iter": int(step), "i_batch": int(i_batch), "model_state_dict": model.state_dict(),
+                "optimizer_state_dict": optimizer.state_dict(), "loss": float(loss),
+                "background": None if background is None else background.detach().clone(),
+                "latent_codes": None if latent_codes is None else latent_codes.detach().clone(),
+                "pose_c": pose_c, "sample_prob": None if sample_prob is None else sample_prob.detach().clone()}, path)
+
+
+def resume(path, model, optimizer, device):
+    """train_stage_rays_auto.py:238-258: -> dict(start_iter, i_batch, background, latent_codes, sample_prob).  weights_only load."""
+    ck = torch.load(path, map_location=device, weights_only=True)
+    model.load_state_dict(ck["model_state_dict"])
+    optimizer.load_state_dict(ck["optimizer_state_dict"])
+    return dict(start_iter=int(ck["iter"]) + 1, i_batch=int(ck.get("i_batch", 0)), background=ck.get("background"),
+                latent_codes=ck.get("latent_codes"), sample_prob=ck.get("sample_prob"), pose_c=ck.get("pose_c"))

@@ -194,3 +194,28 @@ def test_nerface_model_state_dict_and_config_guard():
         sahs.NeRFaceModel(bad)
     with pytest.raises(NotImplementedError):
         sahs.AudioFaceModel(cfg)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """training.save_checkpoint / resume: the reference's checkpoint keys (train_stage_rays_auto.py:698-722), weights_only load."""
+    sahs = pkg()
+    Tr = pkg("training")
+    W = pkg("weights")
+    cfg = sahs.default_config("expression_static")
+    m = sahs.NeRFaceModel(cfg).load_flat(W.flatten_state_dict(W.hash_state_dict(3, model="nerface_static"), model="nerface_static"))
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    for p in m.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    opt.step()
+    sp = torch.arange(12, dtype=torch.float32) / 66
+    bgp = torch.rand(4, 4, 15)
+    path = str(tmp_path / "checkpoint00005.ckpt")
+    Tr.save_checkpoint(path, 5, m, opt, 0.25, i_batch=7, background=bgp, sample_prob=sp)
+    ck = torch.load(path, weights_only=True)
+    assert set(ck) == {"iter", "i_batch", "model_state_dict", "optimizer_state_dict", "loss", "background", "latent_codes", "pose_c", "sample_prob"}
+    m2 = sahs.NeRFaceModel(cfg)
+    opt2 = torch.optim.Adam(m2.parameters(), lr=5e-4)
+    st = Tr.resume(path, m2, opt2, "cpu")
+    assert st["start_iter"] == 6 and st["i_batch"] == 7 and torch.equal(st["sample_prob"], sp) and torch.equal(st["background"], bgp)
+    assert torch.equal(m2.flat_params(), m.flat_params())
+    assert opt2.state_dict()["state"][0]["step"] == opt.state_dict()["state"][0]["step"]
