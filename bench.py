@@ -169,8 +169,9 @@ def main():
     # HBM-side bytes of the dominant dispatch (a fine launch, 16.8 M samples) from the rocprofv3 PMC passes committed under
     # profiles/r1_final_pmc_summary.csv: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction for 16 B/lane streaming reads).
     # Algorithmic bytes for that launch: 1.074 GB of raw output + 0.07 GB of depths.  (Static: bench.py cannot collect PMCs.)
-    roof["traffic"] = {"fp32": 1.074e9 + 4.28e9, "bf16": 1.074e9 + 0.09e9}[args.precision]
-    roof["traffic_note"] = "bytes per fine launch; reads beyond the algorithmic 0.07 GB are L2 misses of the weight stream (L2 hit 99 %)"
+    roof["traffic"] = {"fp32": 1.074e9 + 2.19e9, "bf16": 1.074e9 + 0.09e9}[args.precision]
+    roof["traffic_note"] = ("bytes per fine launch (WRITE_SIZE + 2 x FETCH_SIZE); reads beyond the algorithmic 0.07 GB are L2 misses of the "
+                            "weight stream (L2 hit 99 %, 2-4 GB per launch from run to run = 10-20 GB/s: not a bound)")
     result = {
         "metric": "rendered rays/sec (coarse64+fine128, 8x256 MLP)", "value": value, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

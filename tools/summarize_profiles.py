@@ -15,7 +15,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 ks = glob.glob(os.path.join(base, "trace", "*", "*_kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(ks)))
 with open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (fp32 headline + bf16 leg)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (fp32 headline + bf16 leg + NeRFaceModel fp32 leg)\n")
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows:
@@ -27,14 +27,15 @@ shutil.copy(os.path.join(base, "bench_trace.json"), os.path.join(out, tag + "_be
 agg = collections.OrderedDict()
 for f in sorted(glob.glob(os.path.join(base, "pmc_*", "*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
-        k = "f32" if "field_forward_f32" in r["Kernel_Name"] else ("bf16" if "field_forward_bf16" in r["Kernel_Name"] else None)
+        kn = r["Kernel_Name"]
+        k = ("nerface_f32" if "sahs_nf::" in kn else "f32") if "field_forward_f32" in kn else ("bf16" if "field_forward_bf16" in kn else None)
         if k:
             agg.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
 stats = {r["Name"]: r for r in rows}
 dur = {}
 for name, r in stats.items():
     if "field_forward_f32" in name:
-        dur["f32"] = (float(r["MinNs"]), float(r["MaxNs"]), float(r["AverageNs"]))
+        dur["nerface_f32" if "sahs_nf::" in name else "f32"] = (float(r["MinNs"]), float(r["MaxNs"]), float(r["AverageNs"]))
     if "field_forward_bf16" in name:
         dur["bf16"] = (float(r["MinNs"]), float(r["MaxNs"]), float(r["AverageNs"]))
 lines = ["# rocprofv3 PMC summary (separate passes per counter group, tools/profile_r1.sh), bench.py --steps 1 --warmup 0",
@@ -43,7 +44,7 @@ lines = ["# rocprofv3 PMC summary (separate passes per counter group, tools/prof
 for (k, c), v in agg.items():
     lines.append("%s,%s,%s" % (k, c, ",".join("%.6g" % x for x in v[:4])))
 P_FINE = 16777216
-for k, peak_flop_per_mop in (("f32", 512), ("bf16", 512)):
+for k, peak_flop_per_mop in (("f32", 512), ("bf16", 512), ("nerface_f32", 512)):
     if k not in dur:
         continue
     t_fine = dur[k][1] * 1e-9   # the longest dispatch is a fine launch
@@ -58,8 +59,8 @@ for k, peak_flop_per_mop in (("f32", 512), ("bf16", 512)):
     clk = g("GRBM_GUI_ACTIVE") / 8 / t_fine
     lines.append("#   clock = GRBM_GUI_ACTIVE / 8 / time = %.2f GHz" % (clk / 1e9))
     lines.append("#   MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles) = %.1f %%" % (100 * g("SQ_VALU_MFMA_BUSY_CYCLES") / (1024 * g("GRBM_GUI_ACTIVE") / 8)))
-    mops = g("SQ_INSTS_VALU_MFMA_MOPS_F32") if k == "f32" else g("SQ_INSTS_VALU_MFMA_MOPS_BF16")
-    lines.append("#   executed MFMA FLOPs = MOPS x 512 = %.3e (algorithmic %.3e)" % (mops * 512, P_FINE * 1855744.0))
+    mops = g("SQ_INSTS_VALU_MFMA_MOPS_BF16") if k == "bf16" else g("SQ_INSTS_VALU_MFMA_MOPS_F32")
+    lines.append("#   executed MFMA FLOPs = MOPS x 512 = %.3e (algorithmic %.3e)" % (mops * 512, P_FINE * (1438336.0 if k == "nerface_f32" else 1855744.0)))
     lines.append("#   wave time: WAIT_ANY %.1f %%, WAIT_INST_ANY %.1f %%, ACTIVE_INST_ANY %.1f %% of SQ_WAVE_CYCLES; LDS bank conflict cycles / LDS instructions = %.3f" % (
         100 * g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 100 * g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), 100 * g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"),
         g("SQ_LDS_BANK_CONFLICT") / g("SQ_INSTS_LDS")))
