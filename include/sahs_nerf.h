@@ -10,7 +10,8 @@
  *  - every pointer is a DEVICE pointer to fp32 unless stated; the library never allocates,
  *    never synchronises and launches only on the given stream (hipStream_t passed as void*),
  *    so a caller may capture any sequence of calls in a hipGraph;
- *  - return 0 on success; non-zero = error, text via sahs_last_error() (thread-local);
+ *  - return 0 on success; non-zero = error, text via sahs_last_error() (thread-local); a call over zero rays (N == 0)
+ *    succeeds without launching anything (its buffers may be null);
  *  - "rays" is the reference's packed ray table, row = [ro3, rd3, near, far, ...] with
  *    `ray_stride` floats per row (train_utils.py:255-261 builds it with stride 20);
  *  - precision: SAHS_F32 = exact fp32 (f32 MFMA), SAHS_BF16 = bf16 MFMA operands, fp32 accumulate.

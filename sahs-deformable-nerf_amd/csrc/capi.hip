@@ -119,6 +119,7 @@ int sahs_get_ray_bundle(int H, int W, float fx, float fy, float cx, float cy, co
 
 int sahs_ray_uniforms(uint64_t seed, int stream_id, long ray0, long N, int S, float *out, void *stream)
 {
+    if (N == 0) return 0;
     REQUIRE(out && N >= 0 && S >= 1 && ray0 >= 0, "sahs_ray_uniforms");
     int e = sahs_ray_uniforms_launch(seed, stream_id, ray0, N, S, out, (hipStream_t)stream);
     return e ? hip_fail("sahs_ray_uniforms", e) : 0;
@@ -126,6 +127,7 @@ int sahs_ray_uniforms(uint64_t seed, int stream_id, long ray0, long N, int S, fl
 
 int sahs_stratified_depths(long N, int S, const float *rays, int ray_stride, int lindisp, const float *t_rand, float *z, void *stream)
 {
+    if (N == 0) return 0;
     REQUIRE(N >= 0 && S >= 1 && rays && z && ray_stride >= 8, "sahs_stratified_depths");
     int e = sahs_stratified_depths_launch(N, S, rays, ray_stride, lindisp, t_rand, z, (hipStream_t)stream);
     return e ? hip_fail("sahs_stratified_depths", e) : 0;
@@ -134,6 +136,7 @@ int sahs_stratified_depths(long N, int S, const float *rays, int ray_stride, int
 int sahs_field_forward(const void *packed, const float *frame, int level, long N, int S, const float *rays, int ray_stride,
                        const float *z, float *raw, float *dbg, int precision, void *stream)
 {
+    if (N == 0) return 0;
     REQUIRE(packed && frame && rays && z && raw, "sahs_field_forward");
     REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_field_forward(shape)");
     REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_field_forward(alignment)");
@@ -150,6 +153,7 @@ int sahs_composite_forward(long N, int S, const float *raw, const float *z, cons
                            const float *bg, int white_background, float *rgb, float *disp, float *acc, float *weights, float *depth,
                            void *stream)
 {
+    if (N == 0) return 0;
     REQUIRE(raw && z && rays && rgb && disp && acc && weights && depth && ray_stride >= 6, "sahs_composite_forward");
     REQUIRE(N >= 0 && S >= 1 && S <= 256 && ALIGNED16(raw), "sahs_composite_forward(shape: 1 <= S <= 256)");
     int e = sahs_composite_forward_launch(N, S, raw, z, rays, ray_stride, noise, bg, white_background, rgb, disp, acc, weights, depth,
@@ -160,6 +164,7 @@ int sahs_composite_forward(long N, int S, const float *raw, const float *z, cons
 int sahs_resample(long N, int S, int nf, const float *z, const float *weights, const float *u, float *z_samples, float *z_out,
                   int64_t *inds, void *stream)
 {
+    if (N == 0) return 0;
     REQUIRE(z && weights && z_out, "sahs_resample");
     REQUIRE(N >= 0 && S >= 3 && S <= 256 && nf >= 1 && nf <= 256, "sahs_resample(shape: 3 <= S <= 256, 1 <= nf <= 256)");
     int e = sahs_resample_launch(N, S, nf, 1, z, weights, u, z_samples, z_out, (long long *)inds, (hipStream_t)stream);
@@ -169,6 +174,7 @@ int sahs_resample(long N, int S, int nf, const float *z, const float *weights, c
 int sahs_sample_pdf(long N, int nb, int ns, const float *bins, const float *weights, const float *u, float *samples, int64_t *inds,
                     void *stream)
 {
+    if (N == 0) return 0;
     REQUIRE(bins && weights && samples, "sahs_sample_pdf");
     REQUIRE(N >= 0 && nb >= 2 && nb < 256 && ns >= 1 && ns <= 256, "sahs_sample_pdf(shape: 2 <= nb < 256, 1 <= ns <= 256)");
     int e = sahs_resample_launch(N, nb + 1, ns, 0, bins, weights, u, samples, nullptr, (long long *)inds, (hipStream_t)stream);
@@ -225,6 +231,7 @@ static int render_rays_chain(field_fn_t field, const char *who, const void *pack
                              float *raw, float *weights, float *rgb_c, float *disp_c, float *acc_c, float *rgb_f, float *disp_f,
                              float *acc_f, float *w_bg, float *depth_f, void *stream)
 {
+    if (N == 0) return 0;   // an empty ray chunk: nothing to launch (its tensors have null data pointers)
     REQUIRE(packed && frame && rays && z_c && raw && weights && rgb_c && disp_c && acc_c && w_bg && depth_f, who);
     REQUIRE(nf == 0 || (z_f && rgb_f && disp_f && acc_f), who);
     hipStream_t st = (hipStream_t)stream;
@@ -317,6 +324,7 @@ static int field_forward_model(int model, const void *packed, const float *frame
                                int ray_stride, const float *z, float *raw, float *dbg, int precision, void *stream)
 {
     if (model == SAHS_MODEL_AUDIO) return sahs_field_forward(packed, frame, level, N, S, rays, ray_stride, z, raw, dbg, precision, stream);
+    if (N == 0) return 0;
     REQUIRE(packed && frame && rays && z && raw, "sahs_model_field_forward");
     REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_model_field_forward(shape)");
     REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_model_field_forward(alignment)");
