@@ -11,7 +11,7 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(REPO, "sahs-deformable-nerf_amd", "build", "variants")
-VARIANTS = {"base": [], "nope": ["SAHS_ABLATE_NOPE"], "nobarrier": ["SAHS_ABLATE_NOBARRIER"], "noprio": ["SAHS_ABLATE_NOPRIO"], "nopack": ["SAHS_ABLATE_NOPACK"], "nopack_nodma": ["SAHS_ABLATE_NOPACK", "SAHS_ABLATE_NODMA"],
+VARIANTS = {"base": [],  "nope": ["SAHS_ABLATE_NOPE"], "nobarrier": ["SAHS_ABLATE_NOBARRIER"], "noprio": ["SAHS_ABLATE_NOPRIO"], "nopack": ["SAHS_ABLATE_NOPACK"], "nopack_nodma": ["SAHS_ABLATE_NOPACK", "SAHS_ABLATE_NODMA"],
             "nopack_nodma_nolds": ["SAHS_ABLATE_NOPACK", "SAHS_ABLATE_NODMA", "SAHS_ABLATE_NOLDSREAD"], "nodma": ["SAHS_ABLATE_NODMA"], "nomfma": ["SAHS_ABLATE_NOMFMA"], "nomfma_nodma": ["SAHS_ABLATE_NOMFMA", "SAHS_ABLATE_NODMA"],
             "noldsread": ["SAHS_ABLATE_NOLDSREAD"], "noldsread_nodma": ["SAHS_ABLATE_NOLDSREAD", "SAHS_ABLATE_NODMA"],
             "ntstore": ["SAHS_ABLATE_NTSTORE"], "noact": ["SAHS_ABLATE_NOACT"]}
