@@ -58,7 +58,7 @@ def predict_and_render_radiance(ray_batch, model, options, mode="train", driving
         rays = rays.contiguous()
     N, dev = rays.shape[0], rays.device
     packed, _ = model.packed()
-    frame = _frame if _frame is not None else model.frame(driving, pose)
+    frame = _frame if (_frame is not None or needs_grad) else model.frame(driving, pose)
     noise_std = float(opt.radiance_field_noise_std)
     nc, nf = int(opt.num_coarse), int(opt.num_fine)
     # draw order of the reference: rand(N,nc) [perturb] -> randn(N,nc) [noise] -> rand(N,nf) [perturb] -> randn(N,nc+nf) [noise]
@@ -105,7 +105,9 @@ def run_one_iter_of_nerf(height, width, focal_length, model, ray_origins, ray_di
     chunk = int(getattr(options.nerf, mode).chunksize)
     batches = get_minibatches(rays, chunksize=chunk)
     bgs = get_minibatches(background_prior, chunksize=chunk) if background_prior is not None else None
-    frame = model.frame(driving, pose)          # once per call (the reference recomputes it per point-chunk)
+    needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in model.parameters()) or (driving is not None and driving.requires_grad))
+    # once per call (the reference recomputes it per point-chunk); the differentiable op folds the conditioning itself
+    frame = None if needs_grad else model.frame(driving, pose)
     workspace = {}
     pred = [predict_and_render_radiance(b, model, options, mode, driving=driving, pose=pose, pose_c=pose_c,
                                         background_prior=bgs[i] if bgs is not None else None, latent_code=latent_code,
