@@ -522,6 +522,7 @@ struct Bwd {
     long P;
     const float *zero;     // 16-byte zero page (DMA source for out-of-range tile rows/columns)
     float *wal;            // scratch for 16-byte aligned copies of weight sub-matrices (the flat parameter buffer is not aligned)
+    long wal_cap = 0;
     long walo = 0;
     int err = 0;
     void check() { if (!err) err = (int)hipGetLastError(); }
@@ -540,6 +541,7 @@ struct Bwd {
         if (K % GK == 0 && al(dY, ldy)) {
             if (!al(W, ldw)) {
                 const long ldb = (N + 3) / 4 * 4;
+                if (walo + (long)K * ldb > wal_cap) { if (!err) err = (int)hipErrorOutOfMemory; return; }   // scratch sized for one level's weights
                 float *dst = wal + walo;
                 walo += (long)K * ldb;
                 const long tot = (long)K * N;
@@ -591,6 +593,7 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     Bwd b{stream, P};
     b.zero = ws + P * (256L * 3 + DIN_LD + 32 + 12) + DB_SCRATCH - 64;   // tail of the (zeroed) bias-gradient scratch, never written
     b.wal = ws + P * (256L * 3 + DIN_LD + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS;
+    b.wal_cap = WAL_FLOATS;
     const FlatOffsets &F = kFlat;
     const FlatOffsets::Lvl &Lv = F.lvl[level];
     float *gA = ws, *gB = gA + P * 256, *dfeat = gB + P * 256, *din = dfeat + P * 256, *dgridf = din + P * DIN_LD, *dxw = dgridf + P * 32,
@@ -605,6 +608,8 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     auto W = [&](long off) { return flat + off; };
     auto G = [&](long off) { return grad_flat + off; };
     int dbo = 0;   // running offset into db scratch
+    // bias-gradient slots of one level: BIAS_FLOATS-ish; the last 64 floats of the scratch are the DMA zero page
+    static_assert(BIAS_FLOATS + 16 * 40 <= DB_SCRATCH - 64, "bias-gradient scratch too small for this model");
     auto newdb = [&](int n) { float *p = db + dbo; dbo += (n + 3) / 4 * 4; return p; };
     auto add_bias = [&](float *dbl, long boff, int n) { axpy_kernel<<<1, 256, 0, stream>>>(n, dbl, G(boff)); b.check(); };
     auto consts = [&](long woff, long ld, int rows, int col0, int cols, const float *dbl, const float *c, float *dc) {
@@ -771,5 +776,6 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     (void)drv; (void)d_p36; (void)p36; (void)g3;   // no deformation nets: the gradient stops at the (input) point
 #endif
     (void)layer_params;
+    if (!b.err && dbo > DB_SCRATCH - 64) b.err = (int)hipErrorOutOfMemory;
     return b.err;
 }
