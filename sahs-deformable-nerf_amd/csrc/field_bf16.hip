@@ -42,6 +42,17 @@ struct CtxH {
     char *lds;
     int chunk, buf;
     int lane, h, wave;
+#ifdef SAHS_STAMP
+    // diagnostic build only (tools/stamp_bf16.py): s_memtime stamps of waves 0 and 4 of workgroup 0 for one sample tile, written to
+    // the dbg buffer (which the normal dbg writes then leave alone); no output value is computed from them
+    unsigned long long *stamps; int sidx; bool stamp_on;
+    __device__ __forceinline__ void stamp()
+    {
+        if (stamp_on) { if (lane == 0) stamps[sidx] = __builtin_amdgcn_s_memtime(); ++sidx; }
+    }
+#else
+    __device__ __forceinline__ void stamp() {}
+#endif
 
     // LDS-DMA of chunk c into buffer b, cut into pieces of 8 KB (one 1-KB global_load_lds per wave).
     // A piece costs the issuing wave ~100+ cycles of issue time, so the pieces of the NEXT chunk are spread
@@ -120,7 +131,9 @@ struct CtxH {
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// activation (slope in [0,1]: leaky relu == max(x, slope*x)) and fp32 -> bf16 pairs (v_cvt_pk_bf16_f32)
+// bias, activation (slope in [0,1]: leaky relu == max(x, slope*x); 0 = relu, 1 = none) and fp32 -> bf16 pairs (v_cvt_pk_bf16_f32).
+// Written on float pairs so that the adds and the slope products become v_pk_add_f32 / v_pk_mul_f32 (two values per VALU issue):
+// the repack is the largest non-MFMA item of a wave's instruction stream (tools/stamp_bf16.py).
 __device__ __forceinline__ Blk pack_act(const f32x16 acc, const __attribute__((address_space(3))) float *bias, float slope)   // bias: this lane's rows, LDS
 {
     Blk o;
@@ -131,12 +144,20 @@ __device__ __forceinline__ Blk pack_act(const f32x16 acc, const __attribute__((a
         const f32x4 b0 = *reinterpret_cast<lds_cf4>(bias + 16 * s), b1 = *reinterpret_cast<lds_cf4>(bias + 16 * s + 8);
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-            const float v0 = acc[8 * s + 2 * jp] + (jp < 2 ? b0[2 * jp] : b1[2 * jp - 4]);
-            const float v1 = acc[8 * s + 2 * jp + 1] + (jp < 2 ? b0[2 * jp + 1] : b1[2 * jp - 3]);
+            const f32x2 bb = (jp < 2) ? f32x2{b0[2 * jp], b0[2 * jp + 1]} : f32x2{b1[2 * jp - 4], b1[2 * jp - 3]};
+            const f32x2 v = f32x2{acc[8 * s + 2 * jp], acc[8 * s + 2 * jp + 1]} + bb;
 #ifdef SAHS_ABLATE_NOACT
-            const f32x2 a = {v0, v1};
+            const f32x2 a = v;
 #else
-            const f32x2 a = {fmaxf(v0, v0 * slope), fmaxf(v1, v1 * slope)};
+            f32x2 a;
+            if (slope == 1.0f) {
+                a = v;
+            } else if (slope == 0.0f) {
+                a = f32x2{fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
+            } else {
+                const f32x2 u = v * f32x2{slope, slope};
+                a = f32x2{fmaxf(v[0], u[0]), fmaxf(v[1], u[1])};
+            }
 #endif
             w[jp] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf16x2));
         }
@@ -166,6 +187,7 @@ __device__ __forceinline__ void dense_h(CtxH &cx, const Blk *in0, const Blk *in1
         const int nhw = (c + 1 < NT32 / G) ? G * KB * 1024 : NEXT_HW;          // constant after unrolling
         const int npieces = (nhw + H_THREADS * 8 - 1) / (H_THREADS * 8);        // 8 KB = 4096 halfwords per piece
         cx.begin_chunk(nhw);
+        cx.stamp();                                   // chunk start
         const bf16x8 *A = cx.cur() + cx.lane;
         bf16x8 a[A_PREFETCH];
 #pragma unroll
@@ -206,7 +228,9 @@ __device__ __forceinline__ void dense_h(CtxH &cx, const Blk *in0, const Blk *in1
 #pragma unroll
         for (int pc = (TOTAL + PSTEP - 1) / PSTEP; pc < DMA_PIECES; ++pc)
             if (pc < npieces) cx.issue_piece(pc);
+        cx.stamp();                                   // work done, before the barrier
         cx.end_chunk();
+        cx.stamp();                                   // after the barrier
     }
 }
 
@@ -232,10 +256,13 @@ template <int K0, int NEXT_HW>
 __device__ __forceinline__ void dense_h_out(CtxH &cx, const Blk *in0, f32x16 &acc, int bias_off, bool first)
 {
     cx.begin_chunk(NEXT_HW);
+    cx.stamp();
     const bf16x8 *A = cx.cur() + cx.lane;
     if (first) acc = cx.bias16_half(bias_off);
     acc = tile_mac<K0, (NEXT_HW + H_THREADS * 8 - 1) / (H_THREADS * 8)>(cx, A, in0, acc);
+    cx.stamp();
     cx.end_chunk();
+    cx.stamp();
 }
 
 // ---- positional encoding for the bf16 path ------------------------------------------------------
@@ -362,8 +389,20 @@ field_forward_bf16_kernel(const float *__restrict__ packed, const float *__restr
     }
     constexpr const LayerH *Ly = kProgH.layer;
 
+#ifdef SAHS_STAMP
+    unsigned long long *stamp_base = reinterpret_cast<unsigned long long *>(dbg);
+    dbg = nullptr;
+    int tile_no = 0;
+#endif
     const long ntiles = (P + H_PTS_PER_WG - 1) / H_PTS_PER_WG;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef SAHS_STAMP
+        cx.stamp_on = stamp_base != nullptr && blockIdx.x == 0 && tile_no == 3 && (cx.wave == 0 || cx.wave == 4);
+        cx.stamps = stamp_base + (cx.wave == 4 ? 512 : 0);
+        cx.sidx = 0;
+        ++tile_no;
+        cx.stamp();                                   // tile start
+#endif
         cx.refresh_bias_base();
         const long p_raw = tile * H_PTS_PER_WG + cx.wave * H_PTS_PER_WAVE + (cx.lane & 31);
         const long p = p_raw < P ? p_raw : P - 1;
