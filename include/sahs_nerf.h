@@ -112,10 +112,12 @@ int sahs_field_forward_save(const void *packed, const float *frame, int level, l
  * grid) and grad_cond (+=: [0:76] d driving, [80:116] d pose encoding).  P = N*S samples, P <= 4e6 per call. */
 int sahs_field_backward(const float *flat_params, const float *frame, int level, long P, const float *act_in, const float *d_raw,
                         float *grad_flat, float *grad_cond, float *workspace, void *stream);
-/* backward of sahs_composite_forward: any of d_rgb (N,15), d_disp, d_acc, d_depth, d_wlast (N) may be NULL -> d_raw (N,S,16). */
+/* backward of sahs_composite_forward: any of d_rgb (N,15), d_disp, d_acc, d_depth, d_wlast (N: gradient of weights[:, -1], the
+ * driver's 7th output), d_weights (N,S: gradient of the whole weights output, for the volume_render_radiance_field seam) may
+ * be NULL -> d_raw (N,S,16). */
 int sahs_composite_backward(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
                             const float *bg, int white_background, const float *d_rgb, const float *d_disp, const float *d_acc,
-                            const float *d_depth, const float *d_wlast, float *d_raw, void *stream);
+                            const float *d_depth, const float *d_wlast, const float *d_weights, float *d_raw, void *stream);
 /* grad_cond[0:76] -> AudioNet parameter gradients in grad_flat (+=) and, optionally, grad_audio (16,29) (+=). */
 int sahs_conditioning_backward(const float *flat_params, const float *audio, const float *grad_cond, float *grad_flat,
                                float *grad_audio, void *stream);

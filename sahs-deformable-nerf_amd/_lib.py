@@ -37,7 +37,7 @@ SIGNATURES = {
     "sahs_field_backward_workspace_words": (_L, [_L]),
     "sahs_field_forward_save": (_I, [_P, _P, _I, _L, _I, _P, _I, _P, _P, _P, _P]),
     "sahs_field_backward": (_I, [_P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
-    "sahs_composite_backward": (_I, [_L, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "sahs_composite_backward": (_I, [_L, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sahs_conditioning_backward": (_I, [_P, _P, _P, _P, _P, _P]),
     "sahs_model_param_count": (_L, [_I]),
     "sahs_model_packed_words": (_L, [_I, _I]),

@@ -16,7 +16,7 @@ int sahs_field_backward_launch(const float *flat, const float *frame, int level,
                                float *grad_flat, float *grad_cond, float *ws, hipStream_t stream);
 int sahs_composite_backward_launch(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
                                    const float *bg, int white_bkgd, const float *d_rgb, const float *d_disp, const float *d_acc,
-                                   const float *d_depth, const float *d_wlast, float *d_raw, hipStream_t stream);
+                                   const float *d_depth, const float *d_wlast, const float *d_weights, float *d_raw, hipStream_t stream);
 int sahs_conditioning_backward_launch(const float *flat, const float *audio, const float *grad_cond, float *grad_flat, float *grad_audio,
                                       hipStream_t stream);
 int sahs_field_forward_bf16_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
@@ -206,12 +206,13 @@ int sahs_field_backward(const float *flat_params, const float *frame, int level,
 
 int sahs_composite_backward(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
                             const float *bg, int white_background, const float *d_rgb, const float *d_disp, const float *d_acc,
-                            const float *d_depth, const float *d_wlast, float *d_raw, void *stream)
+                            const float *d_depth, const float *d_wlast, const float *d_weights, float *d_raw, void *stream)
 {
     REQUIRE(raw && z && rays && d_raw && ray_stride >= 6 && ALIGNED16(raw) && ALIGNED16(d_raw), "sahs_composite_backward");
     REQUIRE(N >= 0 && S >= 1 && S <= 256, "sahs_composite_backward(shape: 1 <= S <= 256)");
+    if (N == 0) return 0;
     int e = sahs_composite_backward_launch(N, S, raw, z, rays, ray_stride, noise, bg, white_background, d_rgb, d_disp, d_acc, d_depth, d_wlast,
-                                           d_raw, (hipStream_t)stream);
+                                           d_weights, d_raw, (hipStream_t)stream);
     return e ? hip_fail("sahs_composite_backward", e) : 0;
 }
 

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) composite_backward_kernel(long N, int S, 
                                                                  int white_bkgd, const float *__restrict__ d_rgb,
                                                                  const float *__restrict__ d_disp, const float *__restrict__ d_acc,
                                                                  const float *__restrict__ d_depth, const float *__restrict__ d_wlast,
-                                                                 float *__restrict__ d_raw)
+                                                                 const float *__restrict__ d_weights, float *__restrict__ d_raw)
 {
     const int lane = threadIdx.x & 63;
     const long stride = (long)gridDim.x * (blockDim.x >> 6);
@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(256) composite_backward_kernel(long N, int S, 
                 for (int k = 0; k < cnt; ++k) { if (lane == k) myT = Tl; Tl = Tl * rl(m.f, k); }
                 const float w = valid ? m.alpha * myT : 0.0f;
                 float dwv = gd * m.zs + ga + ((last && valid) ? gwl : 0.0f);
+                if (d_weights != nullptr && valid) dwv += d_weights[ray * S + s];
 #pragma unroll
                 for (int c = 0; c < 15; ++c) dwv += g[c] * m.col[c];
                 if (!valid) dwv = 0.0f;
@@ -253,14 +254,15 @@ using namespace sahs;
 
 extern "C" int sahs_composite_backward_launch(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride,
                                               const float *noise, const float *bg, int white_bkgd, const float *d_rgb, const float *d_disp,
-                                              const float *d_acc, const float *d_depth, const float *d_wlast, float *d_raw, hipStream_t stream)
+                                              const float *d_acc, const float *d_depth, const float *d_wlast, const float *d_weights,
+                                              float *d_raw, hipStream_t stream)
 {
     if (N <= 0) return 0;
     if (S < 1 || S > 256) return -2;
     long blocks = (N + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     composite_backward_kernel<<<(int)blocks, 256, 0, stream>>>(N, S, raw, z, rays, ray_stride, noise, bg, white_bkgd, d_rgb, d_disp, d_acc,
-                                                               d_depth, d_wlast, d_raw);
+                                                               d_depth, d_wlast, d_weights, d_raw);
     return (int)hipGetLastError();
 }
 

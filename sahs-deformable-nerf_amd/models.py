@@ -149,15 +149,20 @@ class _FieldModel(nn.Module):
         if latent_code is not None:
             raise NotImplementedError("latent codes are not used by the shipped configs (latent_code_dim=0)")
         driving = kwargs.get("audio", driving)
-        ops._no_grad_needed(x, driving, *self.parameters())
         packed, _ = self.packed()
-        frame = self.frame(driving, pose)
         P = x.shape[0]
         # a point is a zero-length ray: ro = xyz, z = 0  =>  ro + rd*0 == xyz exactly
         rays = torch.zeros(P, 8, dtype=torch.float32, device=x.device)
-        rays[:, :6] = x[:, :6]
+        rays[:, :6] = x[:, :6].detach()
         z = torch.zeros(P, 1, dtype=torch.float32, device=x.device)
-        raw = ops.field_forward(packed, frame, 0 if level == "coarse" else 1, rays, z, precision=self.precision, arch=self.arch)
+        lvl = 0 if level == "coarse" else 1
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or driving.requires_grad):
+            if self.precision != ops.SAHS_F32:
+                raise NotImplementedError("gradients run through the fp32 path; build the model with precision='fp32'")
+            raw = ops.FieldFn.apply(self.flat_params(differentiable=True), driving.to(torch.float32), pose.to(torch.float32), rays, z, packed,
+                                    lvl, self.arch)
+        else:
+            raw = ops.field_forward(packed, self.frame(driving, pose), lvl, rays, z, precision=self.precision, arch=self.arch)
         return raw.view(P, 16)
 
 

@@ -5,8 +5,9 @@ there is no eager/CPU path here.
 autograd: ``RenderRaysFn`` (one ray chunk of predict_and_render_radiance) is the differentiable op: its
 backward runs the HIP backward kernels (composite_backward, field_backward, conditioning_backward) and
 returns gradients for the flat parameter buffer and the audio window.  Importance resampling is not
-differentiated (the reference detaches it, train_utils.py:164).  The stand-alone seam functions
-(model(...), volume_render_radiance_field) are forward-only and raise if a gradient would be needed.
+differentiated (the reference detaches it, train_utils.py:164).  The stand-alone seams are differentiable too:
+``FieldFn`` behind model(level, x, driving, pose) (parameters and driving input) and ``CompositeFn`` behind
+volume_render_radiance_field (the radiance field), so the reference's own python driver can be run over them.
 """
 import ctypes
 
@@ -34,12 +35,6 @@ def _req(t, name, dtype=torch.float32):
     if t.dtype != dtype:
         raise _lib.SahsError("%s must be %s, got %s" % (name, dtype, t.dtype))
     return t if t.is_contiguous() else t.contiguous()
-
-
-def _no_grad_needed(*tensors):
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError("this seam is forward-only; gradients flow through run_one_iter_of_nerf / RenderRaysFn "
-                                  "(wrap the call in torch.no_grad())")
 
 
 ARCHS = ("audio", "nerface", "nerface_static")   # = SAHS_MODEL_AUDIO / _NERFACE / _NERFACE_STATIC of include/sahs_nerf.h
@@ -221,14 +216,71 @@ def field_backward(flat, frame, level, act, d_raw, grad_flat, grad_cond, arch="a
     check(f(_p(flat), _p(frame), int(level), P, _p(act), _p(d_raw), _p(grad_flat), _p(grad_cond), _p(ws), _stream()), name)
 
 
-def composite_backward(raw, z, rays, noise, bg, white_background, d_rgb, d_disp, d_acc, d_depth, d_wlast):
+def composite_backward(raw, z, rays, noise, bg, white_background, d_rgb, d_disp, d_acc, d_depth, d_wlast, d_weights=None):
     raw, z, rays = _req(raw, "raw"), _req(z, "z"), _req(rays, "rays")
     N, S = z.shape
     d_raw = torch.empty(N, S, 16, dtype=torch.float32, device=z.device)
-    gs = [_req(g, n) for g, n in ((d_rgb, "d_rgb"), (d_disp, "d_disp"), (d_acc, "d_acc"), (d_depth, "d_depth"), (d_wlast, "d_wlast"))]
+    gs = [_req(g, n) for g, n in ((d_rgb, "d_rgb"), (d_disp, "d_disp"), (d_acc, "d_acc"), (d_depth, "d_depth"), (d_wlast, "d_wlast"),
+                                  (d_weights, "d_weights"))]
     check(_lib.lib().sahs_composite_backward(N, S, _p(raw), _p(z), _p(rays), int(rays.shape[1]), _p(_req(noise, "noise")), _p(_req(bg, "bg")),
                                               int(bool(white_background)), *[_p(g) for g in gs], _p(d_raw), _stream()), "sahs_composite_backward")
     return d_raw
+
+
+class CompositeFn(torch.autograd.Function):
+    """volume_render_radiance_field (volume_rendering_utils.py:7-78) as a differentiable op (seam B3): gradient w.r.t. the radiance
+    field through sahs_composite_backward; depths and directions get none (the reference's callers never use those)."""
+
+    @staticmethod
+    def forward(ctx, raw, z, rays, noise, bg, white_background):
+        outs = composite_forward(raw, z, rays, noise=noise, bg=bg, white_background=white_background)
+        none = torch.empty(0, device=raw.device)
+        ctx.save_for_backward(raw.detach(), z, rays, noise if noise is not None else none, bg if bg is not None else none, outs[3][:, -1])
+        ctx.cfg = (bool(white_background), noise is not None, bg is not None)
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth):
+        raw, z, rays, noise, bg, w_last = ctx.saved_tensors
+        white, has_noise, has_bg = ctx.cfg
+        c = lambda t: None if t is None else t.contiguous().float()
+        d_raw = composite_backward(raw, z, rays, noise if has_noise else None, bg if has_bg else None, white, c(g_rgb), c(g_disp), c(g_acc),
+                                   c(g_depth), None, c(g_w))
+        if has_bg and g_rgb is not None:     # the last sample's 15 channels are used verbatim (:28-35): d = w_last * d_rgb
+            d_raw[:, -1, :15] += w_last[:, None] * g_rgb
+        return d_raw, None, None, None, None, None
+
+
+class FieldFn(torch.autograd.Function):
+    """The field evaluation of seam B2, model(level, x, driving, pose) -> (P, 16), differentiable w.r.t. the parameters (as the
+    canonical flat buffer) and the driving input; the sample points themselves get no gradient (no caller of the reference's asks
+    for one).  fp32.  Points are passed as zero-length rays, as in the no-grad path of the seam."""
+
+    @staticmethod
+    def forward(ctx, flat, driving, pose, rays, z, packed, level, arch):
+        frame = fold_conditioning(flat.detach(), driving.detach(), pose, arch=arch)
+        raw, act = field_forward_save(packed, frame, level, rays, z, arch)
+        ctx.save_for_backward(flat.detach(), driving.detach(), frame, act)
+        ctx.cfg = (level, arch)
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        flat, driving, frame, act = ctx.saved_tensors
+        level, arch = ctx.cfg
+        grad_flat = torch.zeros_like(flat)
+        grad_cond = torch.zeros(128, dtype=torch.float32, device=flat.device)
+        P = act.shape[0]
+        g = g_raw.contiguous().float().view(P, 16)
+        for s in range(0, P, 2_000_000):          # sahs_field_backward takes at most 4e6 samples per call
+            field_backward(flat, frame, level, act[s:s + 2_000_000], g[s:s + 2_000_000], grad_flat, grad_cond, arch)
+        if arch == "audio":
+            grad_drv = torch.zeros_like(driving)
+            check(_lib.lib().sahs_conditioning_backward(_p(flat), _p(driving), _p(grad_cond), _p(grad_flat), _p(grad_drv), _stream()),
+                  "sahs_conditioning_backward")
+        else:
+            grad_drv = grad_cond[:76].clone()
+        return grad_flat, grad_drv, None, None, None, None, None, None
 
 
 class RenderRaysFn(torch.autograd.Function):

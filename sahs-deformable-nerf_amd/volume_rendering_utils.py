@@ -12,7 +12,6 @@ def volume_render_radiance_field(radiance_field, depth_values, ray_directions, r
     15 colour channels (train_utils.py:135-136); ``background_prior`` here only selects the
     sigmoid+softmax / verbatim-last-sample colour rule (:28-35).  The noise draw happens here (:45-53).
     """
-    ops._no_grad_needed(radiance_field)
     N, S = depth_values.shape
     noise = None
     if radiance_field_noise_std > 0.0:
@@ -24,4 +23,8 @@ def volume_render_radiance_field(radiance_field, depth_values, ray_directions, r
         if background_prior.shape[1] != 15:
             raise NotImplementedError("background_prior must have 15 channels (rgb3 + seg12)")
         bg = radiance_field[:, -1, :15].contiguous()
+    if torch.is_grad_enabled() and radiance_field.requires_grad:      # differentiable w.r.t. radiance_field, as the reference's
+        if bg is not None:
+            bg = bg.detach()
+        return ops.CompositeFn.apply(radiance_field.contiguous().float(), depth_values, rays, noise, bg, bool(white_background))
     return ops.composite_forward(radiance_field, depth_values, rays, noise=noise, bg=bg, white_background=white_background)
