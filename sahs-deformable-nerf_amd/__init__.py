@@ -11,4 +11,5 @@ from .cfgnode import CfgNode, default_config        # noqa: F401
 from .models import AudioFaceModel, NeRFaceModel    # noqa: F401
 from .train_utils import run_one_iter_of_nerf, predict_and_render_radiance, run_network   # noqa: F401
 from .volume_rendering_utils import volume_render_radiance_field                        # noqa: F401
-from .nerf_helpers import get_ray_bundle, sample_pdf_2, mse2psnr                        # noqa: F401
+from .nerf_helpers import (get_ray_bundle, get_ray_bundle_by_mask, sample_pdf_2, mse2psnr, img2mse, meshgrid_xy, cumprod_exclusive,   # noqa: F401
+                           positional_encoding, get_embedding_function, get_minibatches, MaskMSELoss, MaskCrossEntropyLoss)

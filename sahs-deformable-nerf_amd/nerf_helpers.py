@@ -36,6 +36,53 @@ def sample_pdf_2(bins, weights, num_samples, det=False):
     return ops.sample_pdf(bins, weights, num_samples, u=u)
 
 
+def img2mse(img_src, img_tgt):
+    """nerf_helpers.py:65-66."""
+    return torch.nn.functional.mse_loss(img_src, img_tgt)
+
+
+def meshgrid_xy(tensor1, tensor2):
+    """nerf_helpers.py:84-96: np.meshgrid(..., indexing="xy")."""
+    ii, jj = torch.meshgrid(tensor1, tensor2, indexing="ij")
+    return ii.transpose(-1, -2), jj.transpose(-1, -2)
+
+
+def cumprod_exclusive(tensor):
+    """nerf_helpers.py:99-120: exclusive cumulative product along the last dimension (host utility; the renderer's
+    transmittance product runs inside composite_forward_kernel)."""
+    c = torch.cumprod(tensor, -1)
+    return torch.cat((torch.ones_like(c[..., :1]), c[..., :-1]), dim=-1)
+
+
+def positional_encoding(tensor, num_encoding_functions=6, include_input=True, log_sampling=True):
+    """nerf_helpers.py:305-349 as a host utility for callers that want the encoding itself (the field kernels evaluate it in
+    registers and never materialise it)."""
+    enc = [tensor] if include_input else []
+    if log_sampling:
+        bands = 2.0 ** torch.linspace(0.0, num_encoding_functions - 1, num_encoding_functions, dtype=tensor.dtype, device=tensor.device)
+    else:
+        bands = torch.linspace(2.0 ** 0.0, 2.0 ** (num_encoding_functions - 1), num_encoding_functions, dtype=tensor.dtype, device=tensor.device)
+    for f in bands:
+        enc += [torch.sin(tensor * f), torch.cos(tensor * f)]
+    return enc[0] if len(enc) == 1 else torch.cat(enc, dim=-1)
+
+
+def get_embedding_function(num_encoding_functions=6, include_input=True, log_sampling=True):
+    """nerf_helpers.py:352-359."""
+    return lambda x: positional_encoding(x, num_encoding_functions, include_input, log_sampling)
+
+
+def get_ray_bundle_by_mask(height, width, intrinsics, tform_cam2world, mask, center=(0.5, 0.5)):
+    """nerf_helpers.py:122-175 (square images, as there): pixels inside `mask` get the posed rays, the rest camera-frame
+    directions from the origin.  The posed rays come from the HIP ray kernel."""
+    intr = [float(v) for v in (intrinsics if len(intrinsics) >= 4 else [intrinsics[0], intrinsics[0], 0.5, 0.5])]
+    eye = torch.eye(3, 4, dtype=torch.float32, device=tform_cam2world.device)
+    ro, rd = ops.get_ray_bundle(height, width, intr, tform_cam2world.to(torch.float32).contiguous())
+    _, rd_cam = ops.get_ray_bundle(height, width, intr, eye)
+    m = mask[..., None].to(rd.dtype)
+    return m * ro, (1 - m) * rd_cam + m * rd
+
+
 def mse2psnr(mse):
     """nerf_helpers.py:69-73."""
     if mse == 0:

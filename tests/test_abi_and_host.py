@@ -219,3 +219,19 @@ def test_checkpoint_roundtrip(tmp_path):
     assert st["start_iter"] == 6 and st["i_batch"] == 7 and torch.equal(st["sample_prob"], sp) and torch.equal(st["background"], bgp)
     assert torch.equal(m2.flat_params(), m.flat_params())
     assert opt2.state_dict()["state"][0]["step"] == opt.state_dict()["state"][0]["step"]
+
+
+def test_host_helpers_vs_reference_vectors():
+    """The small helpers the reference's scripts import from `nerf` (positional_encoding & co., nerf_helpers.py) -- host utilities."""
+    from conftest import load_golden
+    H = pkg("nerf_helpers")
+    g = load_golden("pe")
+    x, w = torch.from_numpy(g["x"]), torch.from_numpy(g["w"])
+    assert np.abs(H.positional_encoding(x, 10).numpy() - g["pe_xyz"]).max() < 2e-6
+    assert np.abs(H.positional_encoding(w, 4).numpy() - g["pe_amb"]).max() < 2e-6
+    assert np.abs(H.get_embedding_function(3, False, True)(x).numpy() - g["pe_pose"]).max() < 2e-6
+    t = torch.tensor([[0.5, 2.0, 4.0], [1.0, 1.0, 3.0]])
+    assert torch.equal(H.cumprod_exclusive(t), torch.tensor([[1.0, 0.5, 1.0], [1.0, 1.0, 1.0]]))
+    ii, jj = H.meshgrid_xy(torch.arange(3.0), torch.arange(2.0))
+    assert ii.shape == (2, 3) and torch.equal(ii[0], torch.arange(3.0)) and torch.equal(jj[:, 0], torch.arange(2.0))
+    assert float(H.img2mse(torch.zeros(4), torch.ones(4))) == 1.0

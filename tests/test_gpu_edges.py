@@ -116,3 +116,20 @@ def test_error_behaviour(ops, setup):
     with pytest.raises(E):
         ops.pack_weights(T(fw), precision=7)
     assert "sahs_" in str(pytest.raises(E, ops.field_forward, packed, frame, 2, T(rays), torch.zeros(4, 8, device=dev())).value)
+
+
+def test_ray_bundle_by_mask():
+    """nerf_helpers.py:122-175: posed rays inside the mask, camera-frame rays from the origin outside."""
+    sahs = pkg()
+    g = load_golden("rays")
+    H = W = 8
+    c2w = T(g["c2w"])
+    intr = g["intrinsics"]
+    mask = (torch.rand(H, W, device=dev()) > 0.5).float()
+    ro_m, rd_m = sahs.get_ray_bundle_by_mask(H, W, intr, c2w, mask)
+    ro, rd = sahs.get_ray_bundle(H, W, intr, c2w)
+    _, rd_cam = sahs.get_ray_bundle(H, W, intr, torch.eye(3, 4, device=dev()))
+    inside = mask.bool()
+    assert torch.equal(ro_m[inside], ro[inside]) and torch.equal(rd_m[inside], rd[inside])
+    assert not bool(ro_m[~inside].any()) and torch.equal(rd_m[~inside], rd_cam[~inside])
+    assert bool((rd_cam[..., 2] == -1.0).all())
