@@ -243,10 +243,10 @@ __device__ __forceinline__ void grid_blocks(const float *__restrict__ grid, floa
         const long vox = inb ? (((long)cz * G_RES + cy) * G_RES + cx) : 0;
         const f32x4 *g = reinterpret_cast<const f32x4 *>(grid + vox * D_GRID) + q;
         const f32x4 g0 = g[0], g1 = g[4];
-        if (inb) {
+        // branch-free (weight 0 for a corner outside the grid; x + 0 == x): guarded corners become eight dependent fetch round trips
+        const float we = inb ? wt : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { out[0][r] = out[0][r] + g0[r] * wt; out[1][r] = out[1][r] + g1[r] * wt; }
-        }
+        for (int r = 0; r < 4; ++r) { out[0][r] = out[0][r] + g0[r] * we; out[1][r] = out[1][r] + g1[r] * we; }
     }
 }
 
