@@ -27,7 +27,7 @@ def build():
         print(mod.build(defines=VARIANTS[name], out=os.path.join(VDIR, "libsahs_%s.so" % name)))
 
 
-def time_one(precision, libpath=None):
+def time_one(precision, libpath=None, N=131072, S=128):
     import numpy as np
     import torch
     sys.path.insert(0, REPO)
@@ -42,7 +42,6 @@ def time_one(precision, libpath=None):
     rng = np.random.default_rng(0)
     frame = pkg.ops.fold_conditioning(flat, torch.from_numpy(rng.standard_normal((16, 29)).astype(np.float32)).to(dev),
                                       torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32)).to(dev))
-    N, S = 131072, 128
     rays = torch.zeros(N, 8, device=dev)
     rays[:, 2] = 0.8
     rays[:, 3:6] = torch.randn(N, 3, device=dev) * 0.15 + torch.tensor([0, 0, -1.0], device=dev)
