@@ -133,3 +133,36 @@ def test_ray_bundle_by_mask():
     assert torch.equal(ro_m[inside], ro[inside]) and torch.equal(rd_m[inside], rd[inside])
     assert not bool(ro_m[~inside].any()) and torch.equal(rd_m[~inside], rd_cam[~inside])
     assert bool((rd_cam[..., 2] == -1.0).all())
+
+
+def test_side_stream_and_graph_capture(ops, setup):
+    """The library launches only on the stream it is given and never allocates or synchronises: the same chunk rendered on a side
+    stream and replayed from a captured graph (torch.cuda.CUDAGraph = hipGraph) is bit-identical to the default-stream result."""
+    fw, packed, frame, drv, p36 = setup
+    N = 300
+    rays, rng = make_rays(N, 17)
+    rays_t = T(rays)
+    bg = T(np.concatenate([rng.uniform(0, 1, (N, 3)), np.ones((N, 1)), np.zeros((N, 11))], 1).astype(np.float32))
+    t_rand, u = T(rng.uniform(0, 1, (N, 64)).astype(np.float32)), T(rng.uniform(0, 1, (N, 64)).astype(np.float32))
+    run = lambda: ops.render_rays(packed, frame, rays_t, 64, 64, bg=bg, t_rand=t_rand, u=u)
+    ref = [o.clone() for o in run()]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        outs = run()
+    side.synchronize()
+    for a, b in zip(outs, ref):
+        assert torch.equal(a, b)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        run()                                   # warm-up on the capture stream
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            captured = run()
+    for o in captured:
+        o.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(captured, ref):
+        assert torch.equal(a, b)
