@@ -103,7 +103,8 @@ int sahs_render_rays(const void *packed, const float *frame, int precision, long
 
 /* ---- training path (BASELINE.json configs[4]: train_stage_rays_auto.py:437-499 calls loss.backward() through the path) ----
  * Gradients follow autograd of the reference graph.  fp32 only.  The backward is layer-wise over saved activations:
- * sahs_field_forward_save = sahs_field_forward that additionally writes sahs_act_words_per_sample() floats per sample. */
+ * sahs_field_forward_save = sahs_field_forward that additionally writes sahs_act_words_per_sample() floats per sample (an opaque
+ * buffer of N*S*words floats: one dense [N*S x width] array per layer; sahs_field_backward must be given the same P = N*S). */
 long sahs_act_words_per_sample(void);
 long sahs_field_backward_workspace_words(long P);
 int sahs_field_forward_save(const void *packed, const float *frame, int level, long N, int S, const float *rays, int ray_stride,

@@ -384,12 +384,11 @@ __global__ void __launch_bounds__(256) encode_backward_kernel(long P, const floa
                                                               float *__restrict__ d_xw, float *__restrict__ d_w)
 {
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
-        const float *a = actbuf + p * (long)act::STRIDE;
         float gx[3], gw[2];
-        pe_grad<3, L_XYZ, 1>(a + act::PEX, d_in + p * DIN_LD, gx);
+        pe_grad<3, L_XYZ, 1>(actbuf + (long)act::PEX * P + p * (16 * KB_XYZ), d_in + p * DIN_LD, gx);
         gw[0] = 0.0f; gw[1] = 0.0f;
 #if SAHS_MODEL != 2
-        pe_grad<AMB_DIM, L_AMB, AMB_INC>(a + act::PEW, d_in + p * DIN_LD + DIN_AMB, gw);
+        pe_grad<AMB_DIM, L_AMB, AMB_INC>(actbuf + (long)act::PEW * P + p * (16 * KB_AMB), d_in + p * DIN_LD + DIN_AMB, gw);
 #endif
         f32x4 t = *reinterpret_cast<const f32x4 *>(d_xw + p * 4);
         t[0] += gx[0]; t[1] += gx[1]; t[2] += gx[2];
@@ -412,7 +411,7 @@ __global__ void __launch_bounds__(256) grid_backward_kernel(long P, const float 
         const long p = p2 + h;
         const bool live = p < P;
         const long pc = live ? p : P - 1;
-        const float *a = actbuf + pc * (long)act::STRIDE + act::XW;
+        const float *a = actbuf + (long)act::XW * P + pc * 16;
         const float x = a[0], y = a[1], z = a[2];
         const float R1 = (float)(G_RES - 1);
         const float ix = ((x + 1.0f) / 2.0f) * R1, iy = ((y + 1.0f) / 2.0f) * R1, iz = ((z + 1.0f) / 2.0f) * R1;
@@ -478,7 +477,7 @@ __global__ void tanh_backward_kernel(long P, const float *__restrict__ actbuf, c
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float dx = actbuf[p * (long)act::STRIDE + act::DX + i];
+            const float dx = actbuf[(long)act::DX * P + p * 16 + i];
             g3[p * 4 + i] = d_xw[p * 4 + i] * (1.0f - dx * dx);
         }
         g3[p * 4 + 3] = 0.0f;
@@ -598,7 +597,7 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     const FlatOffsets::Lvl &Lv = F.lvl[level];
     float *gA = ws, *gB = gA + P * 256, *dfeat = gB + P * 256, *din = dfeat + P * 256, *dgridf = din + P * DIN_LD, *dxw = dgridf + P * 32,
           *dw = dxw + P * 4, *g3 = dw + P * 4, *db = g3 + P * 4, *grid_cl = db + DB_SCRATCH, *dgrid_cl = grid_cl + GRID_FLOATS;
-    const long AS = act::STRIDE;
+    // saved activations: one dense [P x width] array per layer, the array at column c of the act:: table starting at c * P
     if (hipMemsetAsync(db, 0, sizeof(float) * DB_SCRATCH, stream) != hipSuccess) return (int)hipGetLastError();
     if (hipMemsetAsync(dgrid_cl, 0, sizeof(float) * GRID_FLOATS, stream) != hipSuccess) return (int)hipGetLastError();
     const float *drv = frame + FRAME_DRV_OFF, *p36 = frame + FRAME_POSE_OFF;
@@ -629,51 +628,51 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     {
         const float *dseg = d_raw + 3;   // (P,12), ld 16
         float *dbl = newdb(N_SEG);
-        b.tn(dseg, 16, N_SEG, A + act::S + 384, AS, BR_H, G(Lv.segout_w), BR_H, dbl);
+        b.tn(dseg, 16, N_SEG, A + (long)(act::S + 384) * P, BR_H, BR_H, G(Lv.segout_w), BR_H, dbl);
         add_bias(dbl, Lv.segout_b, N_SEG);
-        b.nn(dseg, 16, N_SEG, W(Lv.segout_w), BR_H, BR_H, gA, 256, 0, A + act::S + 384, AS, 0.01f);
+        b.nn(dseg, 16, N_SEG, W(Lv.segout_w), BR_H, BR_H, gA, BR_H, 0, A + (long)(act::S + 384) * P, BR_H, 0.01f);
         float *cur = gA, *nxt = gB;
         for (int i = 3; i >= 1; --i) {   // layers_seg[i]: s_{i-1} (128) -> s_i
             float *d = newdb(BR_H);
-            b.tn(cur, 256, BR_H, A + act::S + 128 * (i - 1), AS, BR_H, G(Lv.seg_w[i]), BR_H, d);
+            b.tn(cur, BR_H, BR_H, A + (long)(act::S + 128 * (i - 1)) * P, BR_H, BR_H, G(Lv.seg_w[i]), BR_H, d);
             add_bias(d, Lv.seg_b[i], BR_H);
-            b.nn(cur, 256, BR_H, W(Lv.seg_w[i]), BR_H, BR_H, nxt, 256, 0, A + act::S + 128 * (i - 1), AS, 0.01f);
+            b.nn(cur, BR_H, BR_H, W(Lv.seg_w[i]), BR_H, BR_H, nxt, BR_H, 0, A + (long)(act::S + 128 * (i - 1)) * P, BR_H, 0.01f);
             float *t = cur; cur = nxt; nxt = t;
         }
         float *d = newdb(BR_H);   // layers_seg[0]: feat (256) -> s0
-        b.tn(cur, 256, BR_H, A + act::FEAT, AS, TR_H, G(Lv.seg_w[0]), TR_H, d);
+        b.tn(cur, BR_H, BR_H, A + (long)(act::FEAT) * P, TR_H, TR_H, G(Lv.seg_w[0]), TR_H, d);
         add_bias(d, Lv.seg_b[0], BR_H);
-        b.nn(cur, 256, BR_H, W(Lv.seg_w[0]), TR_H, TR_H, dfeat, 256, 0);       // feat has no activation
+        b.nn(cur, BR_H, BR_H, W(Lv.seg_w[0]), TR_H, TR_H, dfeat, 256, 0);       // feat has no activation
     }
     // ================= colour branch (modules.py:276-287) =================
     {
         const float *drgb = d_raw;   // (P,3), ld 16
         float *dbl = newdb(4);
-        b.tn(drgb, 16, 3, A + act::C + 384, AS, BR_H, G(Lv.rgb_w), BR_H, dbl);
+        b.tn(drgb, 16, 3, A + (long)(act::C + 384) * P, BR_H, BR_H, G(Lv.rgb_w), BR_H, dbl);
         add_bias(dbl, Lv.rgb_b, 3);
-        b.nn(drgb, 16, 3, W(Lv.rgb_w), BR_H, BR_H, gA, 256, 0, A + act::C + 384, AS, 0.01f);
+        b.nn(drgb, 16, 3, W(Lv.rgb_w), BR_H, BR_H, gA, BR_H, 0, A + (long)(act::C + 384) * P, BR_H, 0.01f);
         float *cur = gA, *nxt = gB;
         for (int i = 3; i >= 1; --i) {
             float *d = newdb(BR_H);
-            b.tn(cur, 256, BR_H, A + act::C + 128 * (i - 1), AS, BR_H, G(Lv.dir_w[i]), BR_H, d);
+            b.tn(cur, BR_H, BR_H, A + (long)(act::C + 128 * (i - 1)) * P, BR_H, BR_H, G(Lv.dir_w[i]), BR_H, d);
             add_bias(d, Lv.dir_b[i], BR_H);
-            b.nn(cur, 256, BR_H, W(Lv.dir_w[i]), BR_H, BR_H, nxt, 256, 0, A + act::C + 128 * (i - 1), AS, 0.01f);
+            b.nn(cur, BR_H, BR_H, W(Lv.dir_w[i]), BR_H, BR_H, nxt, BR_H, 0, A + (long)(act::C + 128 * (i - 1)) * P, BR_H, 0.01f);
             float *t = cur; cur = nxt; nxt = t;
         }
         // layers_dir[0]: [feat256 | dirPE27 | grid32] -> c0
         float *d = newdb(BR_H);
-        b.tn(cur, 256, BR_H, A + act::FEAT, AS, TR_H, G(Lv.dir_w[0]), D_DIR_IN, d);
-        b.tn(cur, 256, BR_H, A + act::DIR, AS, D_DIR, G(Lv.dir_w[0]) + TR_H, D_DIR_IN);
-        b.tn(cur, 256, BR_H, A + act::GRID, AS, D_GRID, G(Lv.dir_w[0]) + TR_H + D_DIR, D_DIR_IN);
+        b.tn(cur, BR_H, BR_H, A + (long)(act::FEAT) * P, TR_H, TR_H, G(Lv.dir_w[0]), D_DIR_IN, d);
+        b.tn(cur, BR_H, BR_H, A + (long)(act::DIR) * P, 32, D_DIR, G(Lv.dir_w[0]) + TR_H, D_DIR_IN);
+        b.tn(cur, BR_H, BR_H, A + (long)(act::GRID) * P, 32, D_GRID, G(Lv.dir_w[0]) + TR_H + D_DIR, D_DIR_IN);
         add_bias(d, Lv.dir_b[0], BR_H);
-        b.nn(cur, 256, BR_H, W(Lv.dir_w[0]), D_DIR_IN, TR_H, dfeat, 256, 1);
-        b.nn(cur, 256, BR_H, W(Lv.dir_w[0]) + TR_H + D_DIR, D_DIR_IN, D_GRID, dgridf, 32, 0);
+        b.nn(cur, BR_H, BR_H, W(Lv.dir_w[0]), D_DIR_IN, TR_H, dfeat, 256, 1);
+        b.nn(cur, BR_H, BR_H, W(Lv.dir_w[0]) + TR_H + D_DIR, D_DIR_IN, D_GRID, dgridf, 32, 0);
     }
     // ================= sigma = fc_alpha(feat) (modules.py:275) =================
     {
         const float *dsig = d_raw + 15;  // (P,1), ld 16
         float *dbl = newdb(4);
-        b.tn(dsig, 16, 1, A + act::FEAT, AS, TR_H, G(Lv.alpha_w), TR_H, dbl);
+        b.tn(dsig, 16, 1, A + (long)(act::FEAT) * P, TR_H, TR_H, G(Lv.alpha_w), TR_H, dbl);
         add_bias(dbl, Lv.alpha_b, 1);
         rank1_add_kernel<<<2048, 256, 0, stream>>>(P, TR_H, dsig, 16, W(Lv.alpha_w), dfeat, 256); b.check();
     }
@@ -681,29 +680,29 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     {
         // feat = fc_feat(t7)
         float *d = newdb(TR_H);
-        b.tn(dfeat, 256, TR_H, A + act::T + (TR_LAYERS - 1) * 256, AS, TR_H, G(Lv.feat_w), TR_H, d);
+        b.tn(dfeat, 256, TR_H, A + (long)(act::T + (TR_LAYERS - 1) * 256) * P, TR_H, TR_H, G(Lv.feat_w), TR_H, d);
         add_bias(d, Lv.feat_b, TR_H);
-        b.nn(dfeat, 256, TR_H, W(Lv.feat_w), TR_H, TR_H, gA, 256, 0, A + act::T + (TR_LAYERS - 1) * 256, AS, 0.01f);
+        b.nn(dfeat, 256, TR_H, W(Lv.feat_w), TR_H, TR_H, gA, 256, 0, A + (long)(act::T + (TR_LAYERS - 1) * 256) * P, TR_H, 0.01f);
         float *cur = gA, *nxt = gB;
         for (int i = TR_LAYERS - 1; i >= 1; --i) {   // layers_xyz[i]: input t_{i-1} (and, for i == 3, [PE(x') | PE(w) | pose36])
             float *dl = newdb(TR_H);
             const long ldw = (i == 3) ? TR_H + D_TR_IN : TR_H;
-            b.tn(cur, 256, TR_H, A + act::T + (i - 1) * 256, AS, TR_H, G(Lv.xyz_w[i]), ldw, dl);
+            b.tn(cur, 256, TR_H, A + (long)(act::T + (i - 1) * 256) * P, TR_H, TR_H, G(Lv.xyz_w[i]), ldw, dl);
             add_bias(dl, Lv.xyz_b[i], TR_H);
             if (i == 3) {
-                b.tn(cur, 256, TR_H, A + act::PEX, AS, D_XYZ, G(Lv.xyz_w[3]) + TR_H, ldw);
-                if (D_AMB > 0) b.tn(cur, 256, TR_H, A + act::PEW, AS, D_AMB, G(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw);
+                b.tn(cur, 256, TR_H, A + (long)(act::PEX) * P, 16 * KB_XYZ, D_XYZ, G(Lv.xyz_w[3]) + TR_H, ldw);
+                if (D_AMB > 0) b.tn(cur, 256, TR_H, A + (long)(act::PEW) * P, 16 * KB_AMB, D_AMB, G(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw);
                 consts(Lv.xyz_w[3], ldw, TR_H, TR_H + D_XYZ + D_AMB, D_TR_CONST, dl, trc, d_trc);
                 b.nn(cur, 256, TR_H, W(Lv.xyz_w[3]) + TR_H, ldw, D_XYZ, din, DIN_LD, 0);        // first writer of din stores,
                 if (D_AMB > 0) b.nn(cur, 256, TR_H, W(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw, D_AMB, din + DIN_AMB, DIN_LD, 0);   // layers_xyz[0] below accumulates
             }
-            b.nn(cur, 256, TR_H, W(Lv.xyz_w[i]), ldw, TR_H, nxt, 256, 0, A + act::T + (i - 1) * 256, AS, 0.01f);
+            b.nn(cur, 256, TR_H, W(Lv.xyz_w[i]), ldw, TR_H, nxt, 256, 0, A + (long)(act::T + (i - 1) * 256) * P, TR_H, 0.01f);
             float *t = cur; cur = nxt; nxt = t;
         }
         // layers_xyz[0]: [PE63(x') | PE18(w) | pose36] -> t0
         float *dl = newdb(TR_H);
-        b.tn(cur, 256, TR_H, A + act::PEX, AS, D_XYZ, G(Lv.xyz_w[0]), D_TR_IN, dl);
-        if (D_AMB > 0) b.tn(cur, 256, TR_H, A + act::PEW, AS, D_AMB, G(Lv.xyz_w[0]) + D_XYZ, D_TR_IN);
+        b.tn(cur, 256, TR_H, A + (long)(act::PEX) * P, 16 * KB_XYZ, D_XYZ, G(Lv.xyz_w[0]), D_TR_IN, dl);
+        if (D_AMB > 0) b.tn(cur, 256, TR_H, A + (long)(act::PEW) * P, 16 * KB_AMB, D_AMB, G(Lv.xyz_w[0]) + D_XYZ, D_TR_IN);
         add_bias(dl, Lv.xyz_b[0], TR_H);
         consts(Lv.xyz_w[0], D_TR_IN, TR_H, D_XYZ + D_AMB, D_TR_CONST, dl, trc, d_trc);
         b.nn(cur, 256, TR_H, W(Lv.xyz_w[0]), D_TR_IN, D_XYZ, din, DIN_LD, 1);
@@ -722,25 +721,25 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     // ================= hyper sheet (modules.py:444-462): w = fc_ambient(g5) =================
     {
         float *dbl = newdb(4);
-        b.tn(dw, 4, AMB_DIM, A + act::HH + 5 * 64, AS, HYP_H, G(F.hyp_fw), HYP_H, dbl);
+        b.tn(dw, 4, AMB_DIM, A + (long)(act::HH + 5 * 64) * P, HYP_H, HYP_H, G(F.hyp_fw), HYP_H, dbl);
         add_bias(dbl, F.hyp_fb, AMB_DIM);
-        b.nn(dw, 4, AMB_DIM, W(F.hyp_fw), HYP_H, HYP_H, gA, 256, 0, A + act::HH + 5 * 64, AS, 0.0f);
+        b.nn(dw, 4, AMB_DIM, W(F.hyp_fw), HYP_H, HYP_H, gA, HYP_H, 0, A + (long)(act::HH + 5 * 64) * P, HYP_H, 0.0f);
         float *cur = gA, *nxt = gB;
         for (int i = 5; i >= 1; --i) {
             float *dl = newdb(HYP_H);
             const long ldw = (i == 4) ? HYP_H + D_DEF_IN : HYP_H;
-            b.tn(cur, 256, HYP_H, A + act::HH + (i - 1) * 64, AS, HYP_H, G(F.hyp_w[i]), ldw, dl);
+            b.tn(cur, HYP_H, HYP_H, A + (long)(act::HH + (i - 1) * 64) * P, HYP_H, HYP_H, G(F.hyp_w[i]), ldw, dl);
             add_bias(dl, F.hyp_b[i], HYP_H);
             if (i == 4) {
-                b.tn(cur, 256, HYP_H, A + act::E, AS, D_XYZ, G(F.hyp_w[4]) + HYP_H, ldw);
+                b.tn(cur, HYP_H, HYP_H, A + (long)(act::E) * P, 16 * KB_XYZ, D_XYZ, G(F.hyp_w[4]) + HYP_H, ldw);
                 consts(F.hyp_w[4], ldw, HYP_H, HYP_H + D_XYZ, D_DRV, dl, drv, d_drv);
                 consts(F.hyp_w[4], ldw, HYP_H, HYP_H + D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);
             }
-            b.nn(cur, 256, HYP_H, W(F.hyp_w[i]), ldw, HYP_H, nxt, 256, 0, A + act::HH + (i - 1) * 64, AS, 0.0f);
+            b.nn(cur, HYP_H, HYP_H, W(F.hyp_w[i]), ldw, HYP_H, nxt, HYP_H, 0, A + (long)(act::HH + (i - 1) * 64) * P, HYP_H, 0.0f);
             float *t = cur; cur = nxt; nxt = t;
         }
         float *dl = newdb(HYP_H);
-        b.tn(cur, 256, HYP_H, A + act::E, AS, D_XYZ, G(F.hyp_w[0]), D_DEF_IN, dl);
+        b.tn(cur, HYP_H, HYP_H, A + (long)(act::E) * P, 16 * KB_XYZ, D_XYZ, G(F.hyp_w[0]), D_DEF_IN, dl);
         add_bias(dl, F.hyp_b[0], HYP_H);
         consts(F.hyp_w[0], D_DEF_IN, HYP_H, D_XYZ, D_DRV, dl, drv, d_drv);
         consts(F.hyp_w[0], D_DEF_IN, HYP_H, D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);
@@ -749,25 +748,25 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     {
         tanh_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, dxw, g3); b.check();
         float *dbl = newdb(4);
-        b.tn(g3, 4, 3, A + act::WH + 5 * 128, AS, WARP_H, G(F.warp_fw), WARP_H, dbl);
+        b.tn(g3, 4, 3, A + (long)(act::WH + 5 * 128) * P, WARP_H, WARP_H, G(F.warp_fw), WARP_H, dbl);
         add_bias(dbl, F.warp_fb, 3);
-        b.nn(g3, 4, 3, W(F.warp_fw), WARP_H, WARP_H, gA, 256, 0, A + act::WH + 5 * 128, AS, 0.0f);
+        b.nn(g3, 4, 3, W(F.warp_fw), WARP_H, WARP_H, gA, WARP_H, 0, A + (long)(act::WH + 5 * 128) * P, WARP_H, 0.0f);
         float *cur = gA, *nxt = gB;
         for (int i = 5; i >= 1; --i) {
             float *dl = newdb(WARP_H);
             const long ldw = (i == 4) ? WARP_H + D_DEF_IN : WARP_H;
-            b.tn(cur, 256, WARP_H, A + act::WH + (i - 1) * 128, AS, WARP_H, G(F.warp_w[i]), ldw, dl);
+            b.tn(cur, WARP_H, WARP_H, A + (long)(act::WH + (i - 1) * 128) * P, WARP_H, WARP_H, G(F.warp_w[i]), ldw, dl);
             add_bias(dl, F.warp_b[i], WARP_H);
             if (i == 4) {
-                b.tn(cur, 256, WARP_H, A + act::E, AS, D_XYZ, G(F.warp_w[4]) + WARP_H, ldw);
+                b.tn(cur, WARP_H, WARP_H, A + (long)(act::E) * P, 16 * KB_XYZ, D_XYZ, G(F.warp_w[4]) + WARP_H, ldw);
                 consts(F.warp_w[4], ldw, WARP_H, WARP_H + D_XYZ, D_DRV, dl, drv, d_drv);
                 consts(F.warp_w[4], ldw, WARP_H, WARP_H + D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);
             }
-            b.nn(cur, 256, WARP_H, W(F.warp_w[i]), ldw, WARP_H, nxt, 256, 0, A + act::WH + (i - 1) * 128, AS, 0.0f);
+            b.nn(cur, WARP_H, WARP_H, W(F.warp_w[i]), ldw, WARP_H, nxt, WARP_H, 0, A + (long)(act::WH + (i - 1) * 128) * P, WARP_H, 0.0f);
             float *t = cur; cur = nxt; nxt = t;
         }
         float *dl = newdb(WARP_H);
-        b.tn(cur, 256, WARP_H, A + act::E, AS, D_XYZ, G(F.warp_w[0]), D_DEF_IN, dl);
+        b.tn(cur, WARP_H, WARP_H, A + (long)(act::E) * P, 16 * KB_XYZ, D_XYZ, G(F.warp_w[0]), D_DEF_IN, dl);
         add_bias(dl, F.warp_b[0], WARP_H);
         consts(F.warp_w[0], D_DEF_IN, WARP_H, D_XYZ, D_DRV, dl, drv, d_drv);
         consts(F.warp_w[0], D_DEF_IN, WARP_H, D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);

@@ -291,8 +291,11 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         float *stash = lds + LDS_STASH_OFF + (cx.wave * F32_PTS_PER_WAVE + (cx.lane & 15)) * STASH_FLOATS;
         const bool dump = dbg != nullptr && q == 0 && p_raw < P;   // lanes holding feature 0 of tile 0
         float *dsl = dbg + p * DBG_STRIDE;
-        float *sv = (SAVE && p_raw < P) ? actbuf + p * (long)act::STRIDE + 4 * q : nullptr;   // this lane's slot in its sample's row
-#define SV(off) (SAVE && sv != nullptr ? sv + (off) : nullptr)
+        // saved activations are one dense [P x width] array per layer (array at column c of the act:: table starts at c * P):
+        // this lane's slot in its sample's row of array (c, w)
+        const bool sv_on = SAVE && p_raw < P;
+#define SVP(c, w) (actbuf + (long)(c) * P + p * (long)(w) + 4 * q)
+#define SV(c, w) (sv_on ? SVP(c, w) : nullptr)
         float x[3];
         {
             const float *rp = rays + (p / S) * ray_stride;
@@ -304,37 +307,37 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         // no deformation nets (use_warp False, use_ambient False): the template is queried at the raw point (models.py:316-327)
         if (q == 0) {
             stash[0] = x[0]; stash[1] = x[1]; stash[2] = x[2]; stash[3] = 0.0f; stash[4] = 0.0f;
-            if (SAVE && sv != nullptr) { sv[act::XW] = x[0]; sv[act::XW + 1] = x[1]; sv[act::XW + 2] = x[2]; }   // the grid backward reads it
+            if (sv_on) { float *d = SVP(act::XW, 16); d[0] = x[0]; d[1] = x[1]; d[2] = x[2]; }   // the grid backward reads it
         }
 #else
         f32x4 pe_x[KB_XYZ];
         {
             pe_blocks<3, L_XYZ, KB_XYZ>(x, q, pe_x);
-            if (SAVE && sv != nullptr) {
+            if (sv_on) {
 #pragma unroll
-                for (int b = 0; b < KB_XYZ; ++b) *reinterpret_cast<f32x4 *>(sv + act::E + 16 * b) = pe_x[b];
+                for (int b = 0; b < KB_XYZ; ++b) *reinterpret_cast<f32x4 *>(SVP(act::E, 16 * KB_XYZ) + 16 * b) = pe_x[b];
             }
         }
         // ---- warp field: dx = tanh(MLP) (modules.py:371-390) ----
         {
             f32x4 h[8], hn[8];
-            dense<KB_XYZ, 0, 8, CHF(L_W1)>(cx, pe_x, nullptr, h, Ly[L_W0].bias_off, false, 0.0f, SV(act::WH));
+            dense<KB_XYZ, 0, 8, CHF(L_W1)>(cx, pe_x, nullptr, h, Ly[L_W0].bias_off, false, 0.0f, SV(act::WH, 128));
             // W1..W3; the chunk after each is W2, W3, W4B.  One rolled loop where those have the same size (AudioFaceModel: 32 KB)
             constexpr int W_ROLLED = (CHF(L_W4B) == CHF(L_W2)) ? 3 : 2;
 #pragma unroll 1
             for (int l = 0; l < W_ROLLED; ++l) {
-                dense<8, 0, 8, CHF(L_W2)>(cx, h, nullptr, hn, Ly[L_W1].bias_off + 128 * l, false, 0.0f, SV(act::WH + 128 * (l + 1)));
+                dense<8, 0, 8, CHF(L_W2)>(cx, h, nullptr, hn, Ly[L_W1].bias_off + 128 * l, false, 0.0f, SV(act::WH + 128 * (l + 1), 128));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) h[i] = hn[i];
             }
             if (W_ROLLED == 2) {
-                dense<8, 0, 8, CHF(L_W4B)>(cx, h, nullptr, hn, Ly[L_W3].bias_off, false, 0.0f, SV(act::WH + 128 * 3));
+                dense<8, 0, 8, CHF(L_W4B)>(cx, h, nullptr, hn, Ly[L_W3].bias_off, false, 0.0f, SV(act::WH + 128 * 3, 128));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) h[i] = hn[i];
             }
             dense<KB_XYZ, 0, 8, CHF(L_W4A)>(cx, pe_x, nullptr, hn, Ly[L_W4B].bias_off, false, 1.0f);
-            dense<8, 0, 8, CHF(L_W5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::WH + 4 * 128));
-            dense<8, 0, 8, CHF(L_WF)>(cx, hn, nullptr, h, Ly[L_W5].bias_off, false, 0.0f, SV(act::WH + 5 * 128));
+            dense<8, 0, 8, CHF(L_W5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::WH + 4 * 128, 128));
+            dense<8, 0, 8, CHF(L_WF)>(cx, hn, nullptr, h, Ly[L_W5].bias_off, false, 0.0f, SV(act::WH + 5 * 128, 128));
             f32x4 o[1];
             dense<8, 0, 1, CHF(L_H0)>(cx, h, nullptr, o, Ly[L_WF].bias_off, false, 1.0f);
             if (q == 0) {
@@ -342,34 +345,34 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                 for (int i = 0; i < 3; ++i) {
                     const float dxv = tanhf(o[0][i]);
                     stash[i] = x[i] + dxv;                                            // models.py:305 (rows 0..2 live in lane quarter 0)
-                    if (SAVE && sv != nullptr) { sv[act::DX + i] = dxv; sv[act::XW + i] = x[i] + dxv; }
+                    if (sv_on) { SVP(act::DX, 16)[i] = dxv; SVP(act::XW, 16)[i] = x[i] + dxv; }
                 }
             }
         }
         // ---- hyper sheet: ambient w (modules.py:444-462) ----
         {
             f32x4 h[4], hn[4];
-            dense<KB_XYZ, 0, 4, CHF(L_H1)>(cx, pe_x, nullptr, h, Ly[L_H0].bias_off, false, 0.0f, SV(act::HH));
+            dense<KB_XYZ, 0, 4, CHF(L_H1)>(cx, pe_x, nullptr, h, Ly[L_H0].bias_off, false, 0.0f, SV(act::HH, 64));
             constexpr int H_ROLLED = (CHF(L_H4B) == CHF(L_H2)) ? 3 : 2;   // H1..H3 (next chunks: H2, H3, H4B)
 #pragma unroll 1
             for (int l = 0; l < H_ROLLED; ++l) {
-                dense<4, 0, 4, CHF(L_H2)>(cx, h, nullptr, hn, Ly[L_H1].bias_off + 64 * l, false, 0.0f, SV(act::HH + 64 * (l + 1)));
+                dense<4, 0, 4, CHF(L_H2)>(cx, h, nullptr, hn, Ly[L_H1].bias_off + 64 * l, false, 0.0f, SV(act::HH + 64 * (l + 1), 64));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) h[i] = hn[i];
             }
             if (H_ROLLED == 2) {
-                dense<4, 0, 4, CHF(L_H4B)>(cx, h, nullptr, hn, Ly[L_H3].bias_off, false, 0.0f, SV(act::HH + 64 * 3));
+                dense<4, 0, 4, CHF(L_H4B)>(cx, h, nullptr, hn, Ly[L_H3].bias_off, false, 0.0f, SV(act::HH + 64 * 3, 64));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) h[i] = hn[i];
             }
             dense<KB_XYZ, 0, 4, CHF(L_H4A)>(cx, pe_x, nullptr, hn, Ly[L_H4B].bias_off, false, 1.0f);
-            dense<4, 0, 4, CHF(L_H5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::HH + 4 * 64));
-            dense<4, 0, 4, CHF(L_HF)>(cx, hn, nullptr, h, Ly[L_H5].bias_off, false, 0.0f, SV(act::HH + 5 * 64));
+            dense<4, 0, 4, CHF(L_H5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::HH + 4 * 64, 64));
+            dense<4, 0, 4, CHF(L_HF)>(cx, hn, nullptr, h, Ly[L_H5].bias_off, false, 0.0f, SV(act::HH + 5 * 64, 64));
             f32x4 o[1];
             dense<4, 0, 1, CHF(L_T0)>(cx, h, nullptr, o, Ly[L_HF].bias_off, false, 1.0f);
             if (q == 0) {      // rows 0..AMB_DIM-1 of the one output tile
                 stash[3] = o[0][0]; stash[4] = (AMB_DIM > 1) ? o[0][1] : 0.0f;
-                if (SAVE && sv != nullptr) { sv[act::AW] = o[0][0]; sv[act::AW + 1] = stash[4]; }
+                if (sv_on) { SVP(act::AW, 16)[0] = o[0][0]; SVP(act::AW, 16)[1] = stash[4]; }
             }
         }
 #endif
@@ -390,18 +393,19 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
 #else
                 (void)amb;
 #endif
-                if (SAVE && sv != nullptr) {
+                if (sv_on) {
 #pragma unroll
-                    for (int b = 0; b < KB_XYZ + KB_AMB; ++b) *reinterpret_cast<f32x4 *>(sv + act::PEX + 16 * b) = in_tr[b];   // PEX blocks then PEW
+                    for (int b = 0; b < KB_XYZ + KB_AMB; ++b)
+                        *reinterpret_cast<f32x4 *>(b < KB_XYZ ? SVP(act::PEX, 16 * KB_XYZ) + 16 * b : SVP(act::PEW, 16 * KB_AMB) + 16 * (b - KB_XYZ)) = in_tr[b];
                 }
-                dense<KB_XYZ, KB_AMB, 16, CHF(L_T1)>(cx, in_tr, in_tr + KB_XYZ, h, Ly[L_T0].bias_off, false, 0.01f, SV(act::T));
+                dense<KB_XYZ, KB_AMB, 16, CHF(L_T1)>(cx, in_tr, in_tr + KB_XYZ, h, Ly[L_T0].bias_off, false, 0.01f, SV(act::T, 256));
             }
             if (dump) dsl[5] = h[0][0];
-            dense<16, 0, 16, CHF(L_T2)>(cx, h, nullptr, feat, Ly[L_T1].bias_off, false, 0.01f, SV(act::T + 256));
+            dense<16, 0, 16, CHF(L_T2)>(cx, h, nullptr, feat, Ly[L_T1].bias_off, false, 0.01f, SV(act::T + 256, 256));
             if (dump) dsl[6] = feat[0][0];
 #pragma unroll
             for (int i = 0; i < 16; ++i) h[i] = feat[i];
-            dense<16, 0, 16, CHF(L_T3B)>(cx, h, nullptr, feat, Ly[L_T2].bias_off, false, 0.01f, SV(act::T + 512));
+            dense<16, 0, 16, CHF(L_T3B)>(cx, h, nullptr, feat, Ly[L_T2].bias_off, false, 0.01f, SV(act::T + 512, 256));
             if (dump) dsl[7] = feat[0][0];
 #pragma unroll
             for (int i = 0; i < 16; ++i) h[i] = feat[i];
@@ -417,9 +421,9 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                 dense<KB_XYZ, KB_AMB, 16, CHF(L_T3A)>(cx, in_tr, in_tr + KB_XYZ, feat, Ly[L_T3B].bias_off, false, 1.0f);
             }
 #if SAHS_MODEL == 0
-            dense<16, 0, 16, CHF(L_T4)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768));
+            dense<16, 0, 16, CHF(L_T4)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768, 256));
 #else           // 4-layer trunk: the skip layer is the last one, fc_feat follows
-            dense<16, 0, 16, CHF(L_FEAT)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768));
+            dense<16, 0, 16, CHF(L_FEAT)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768, 256));
 #endif
             if (dump) dsl[8] = feat[0][0];
 #pragma unroll
@@ -427,13 +431,13 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
 #if SAHS_MODEL == 0
 #pragma unroll 1
             for (int l = 4; l <= 7; ++l) {     // T4..T7 (next chunks: T5, T6, T7, FEAT, all 32 KB)
-                dense<16, 0, 16, CHF(L_T5)>(cx, h, nullptr, feat, Ly[L_T4].bias_off + 256 * (l - 4), false, 0.01f, SV(act::T + 256 * l));
+                dense<16, 0, 16, CHF(L_T5)>(cx, h, nullptr, feat, Ly[L_T4].bias_off + 256 * (l - 4), false, 0.01f, SV(act::T + 256 * l, 256));
                 if (dump) dsl[5 + l] = feat[0][0];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) h[i] = feat[i];
             }
 #endif
-            dense<16, 0, 16, CHF(L_ALPHA)>(cx, h, nullptr, feat, Ly[L_FEAT].bias_off, false, 1.0f, SV(act::FEAT));
+            dense<16, 0, 16, CHF(L_ALPHA)>(cx, h, nullptr, feat, Ly[L_FEAT].bias_off, false, 1.0f, SV(act::FEAT, 256));
             if (dump) dsl[13] = feat[0][0];
         }
         dense<16, 0, 1, CHF(L_D0B)>(cx, feat, nullptr, fin, Ly[L_ALPHA].bias_off, false, 1.0f);
@@ -446,9 +450,9 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                 const float rd[3] = {rp[3], rp[4], rp[5]};
                 pe_blocks<3, 4, 2>(rd, q, in_d);                                  // models.py:340 (raw, un-normalised direction)
                 grid_blocks(grid, stash[0], stash[1], stash[2], q, in_d + 2);     // models.py:525
-                if (SAVE && sv != nullptr) {
+                if (sv_on) {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4 *>(sv + act::DIR + 16 * b) = in_d[b];   // DIR (2 blocks) then GRID (2)
+                    for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4 *>(b < 2 ? SVP(act::DIR, 32) + 16 * b : SVP(act::GRID, 32) + 16 * (b - 2)) = in_d[b];
                 }
             }
             if (dbg != nullptr && p_raw < P) {
@@ -458,15 +462,15 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
             }
             f32x4 c[8], cn[8];
             dense<2, 2, 8, CHF(L_D0A)>(cx, in_d, in_d + 2, c, Ly[L_D0B].bias_off, false, 1.0f);
-            dense<16, 0, 8, CHF(L_D1)>(cx, feat, nullptr, c, 0, true, 0.01f, SV(act::C));
+            dense<16, 0, 8, CHF(L_D1)>(cx, feat, nullptr, c, 0, true, 0.01f, SV(act::C, 128));
             if (dump) dsl[14] = c[0][0];
 #pragma unroll 1
             for (int l = 0; l < 2; ++l) {      // D1, D2
-                dense<8, 0, 8, CHF(L_D2)>(cx, c, nullptr, cn, Ly[L_D1].bias_off + 128 * l, false, 0.01f, SV(act::C + 128 * (l + 1)));
+                dense<8, 0, 8, CHF(L_D2)>(cx, c, nullptr, cn, Ly[L_D1].bias_off + 128 * l, false, 0.01f, SV(act::C + 128 * (l + 1), 128));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) c[i] = cn[i];
             }
-            dense<8, 0, 8, CHF(L_RGB)>(cx, c, nullptr, cn, Ly[L_D3].bias_off, false, 0.01f, SV(act::C + 384));
+            dense<8, 0, 8, CHF(L_RGB)>(cx, c, nullptr, cn, Ly[L_D3].bias_off, false, 0.01f, SV(act::C + 384, 128));
             if (dump) dsl[15] = cn[0][0];
             dense<8, 0, 1, CHF(L_S0)>(cx, cn, nullptr, fin, 0, true, 1.0f);
             if (dbg != nullptr && p_raw < P) *reinterpret_cast<f32x4 *>(dsl + 40 + 4 * q) = fin[0];
@@ -474,15 +478,15 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         // ---- seg branch (modules.py:289-294) ----
         {
             f32x4 s[8], sn[8];
-            dense<16, 0, 8, CHF(L_S1)>(cx, feat, nullptr, s, Ly[L_S0].bias_off, false, 0.01f, SV(act::S));
+            dense<16, 0, 8, CHF(L_S1)>(cx, feat, nullptr, s, Ly[L_S0].bias_off, false, 0.01f, SV(act::S, 128));
             if (dump) dsl[16] = s[0][0];
 #pragma unroll 1
             for (int l = 0; l < 2; ++l) {      // S1, S2
-                dense<8, 0, 8, CHF(L_S2)>(cx, s, nullptr, sn, Ly[L_S1].bias_off + 128 * l, false, 0.01f, SV(act::S + 128 * (l + 1)));
+                dense<8, 0, 8, CHF(L_S2)>(cx, s, nullptr, sn, Ly[L_S1].bias_off + 128 * l, false, 0.01f, SV(act::S + 128 * (l + 1), 128));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s[i] = sn[i];
             }
-            dense<8, 0, 8, CHF(L_SEG)>(cx, s, nullptr, sn, Ly[L_S3].bias_off, false, 0.01f, SV(act::S + 384));
+            dense<8, 0, 8, CHF(L_SEG)>(cx, s, nullptr, sn, Ly[L_S3].bias_off, false, 0.01f, SV(act::S + 384, 128));
             if (dump) dsl[17] = sn[0][0];
             dense<8, 0, 1, CHF(L_FIRST)>(cx, sn, nullptr, fin, 0, true, 1.0f);
         }

@@ -395,9 +395,10 @@ constexpr long PACKH_WORDS = PACKH_TABLE_OFF + ((NUM_CHUNKS_H + 1 + 3) / 4) * 4;
 }  // namespace SAHS_NS
 
 // =============================================================================================
-// Saved activations for the backward pass (field_bwd.hip).  One row per sample, fp32, every entry a whole number
-// of 16-feature blocks in the field kernel's B layout, so the forward kernel stores each finished tile with one
-// float4 per lane.  Hidden activations are stored POST activation (relu/leaky-relu keep the sign, so the
+// Saved activations for the backward pass (field_bwd.hip), fp32: ONE DENSE [P x width] ARRAY PER LAYER -- the array listed at
+// column c below starts at float c * P of the buffer and is indexed [sample][feature] -- so that the backward GEMMs stream their
+// operands sequentially (a row-per-sample interleaving made every operand a 19-KB-strided gather).  Every array is a whole
+// number of 16-feature blocks in the field kernel's B layout: the forward kernel stores each finished tile with one float4 per lane.  Hidden activations are stored POST activation (relu/leaky-relu keep the sign, so the
 // derivative mask is recovered from them); PE rows hold sin and cos of every octave, so the PE derivative needs
 // no trigonometry.
 // =============================================================================================

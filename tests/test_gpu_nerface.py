@@ -357,15 +357,18 @@ def test_field_backward_seam_vs_autograd(ops, nf, arch, level):
     kbx, kba, trl = {"audio": (4, 2, 8), "nerface": (6, 2, 4), "nerface_static": (4, 0, 4)}[arch]
     WH = 16 * kbx; HH = WH + 6 * 128 + 16; Tt = HH + 6 * 64 + 32 + 16 * kbx + 16 * kba; C = Tt + trl * 256 + 256 + 64; Ss = C + 512
     assert act.shape[1] == Ss + 512
+    P = N * S
+    flat_act = act.reshape(-1)
+    arr = lambda c, w: flat_act[c * P:(c + w) * P].view(P, w)      # one dense [P x width] array per layer, array (c, w) at c * P
     masks = {}
     for i in range(6):
-        masks["warp.%d" % i] = act[:, WH + 128 * i: WH + 128 * (i + 1)] > 0
-        masks["hyper.%d" % i] = act[:, HH + 64 * i: HH + 64 * (i + 1)] > 0
+        masks["warp.%d" % i] = arr(WH + 128 * i, 128) > 0
+        masks["hyper.%d" % i] = arr(HH + 64 * i, 64) > 0
     for i in range(trl):
-        masks["trunk.%d" % i] = act[:, Tt + 256 * i: Tt + 256 * (i + 1)] > 0
+        masks["trunk.%d" % i] = arr(Tt + 256 * i, 256) > 0
     for i in range(4):
-        masks["dir.%d" % i] = act[:, C + 128 * i: C + 128 * (i + 1)] > 0
-        masks["seg.%d" % i] = act[:, Ss + 128 * i: Ss + 128 * (i + 1)] > 0
+        masks["dir.%d" % i] = arr(C + 128 * i, 128) > 0
+        masks["seg.%d" % i] = arr(Ss + 128 * i, 128) > 0
 
     def autograd(dtype, use_masks):
         sd_t = {k: torch.from_numpy(v).to(dev()).to(dtype).requires_grad_(True) for k, v in sd_np.items()}
