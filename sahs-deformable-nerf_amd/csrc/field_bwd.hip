@@ -555,12 +555,15 @@ struct Bwd {
         check();
     }
     // dW[M x N] += dY[P x M]^T * X[P x N];  db != null: db[M] += column sums of dY (fused: the dY tiles are staged anyway).
-    // The sample dimension is cut into slabs so that every launch has ~6 workgroups per CU whatever the layer width.
+    // The sample dimension is cut into slabs of >= 512 samples, ~2 workgroups per CU per launch: a workgroup's fixed cost (ring fill,
+    // 64 atomics per lane) wants many K-steps per slab -- measured on the 2048-ray step: 1536 workgroups / 256-sample slabs 35.6 ms,
+    // 512 / 512 33.0 ms, 256 / 1024 34.5 ms; writing partial tiles and reducing them in a second pass instead of the atomics
+    // changed nothing at any setting (the atomics are not the cost).
     void tn(const float *dY, long ldy, int M, const float *X, long ldx, int N, float *dW, long ldw, float *db = nullptr)
     {
         const int tiles = ((N + GT - 1) / GT) * ((M + GT - 1) / GT);
-        long kslab = (P * tiles / 1536 + 15) / 16 * 16;
-        kslab = kslab < 256 ? 256 : (kslab > 8192 ? 8192 : kslab);
+        long kslab = (P * tiles / 512 + 15) / 16 * 16;
+        kslab = kslab < 512 ? 512 : (kslab > 8192 ? 8192 : kslab);
         dim3 g((N + GT - 1) / GT, (M + GT - 1) / GT, (unsigned)((P + kslab - 1) / kslab));
         if (al(dY, ldy) && al(X, ldx))
             gemm_dma_kernel<true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0, zero);
