@@ -316,6 +316,54 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, cons
             }
         }
     }
+    if (!TA && mode != 2 && ((reinterpret_cast<uintptr_t>(C) | (mask ? reinterpret_cast<uintptr_t>(mask) : 0)) & 15) == 0 && ldc % 4 == 0 &&
+        (mask == nullptr || ldm % 4 == 0)) {
+        // Data-gradient epilogue through LDS: the accumulator layout gives 64-byte row segments per store instruction (64 mask loads
+        // + 64 stores per lane); staged, every thread moves whole float4s of 512-byte rows (8 mask loads + 8 stores per lane per half).
+        constexpr int SLD = GT + 4;
+        float *stage = &smem[0][0][0];                      // 64 x 132 floats = 33 KB of the 48 KB ring, free after the K loop
+        __syncthreads();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) stage[(16 * i + 4 * q + r) * SLD + 64 * wn + 16 * j + c16] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = tid + 256 * e, row = idx >> 5, c4 = idx & 31;
+                const long m = m0 + 64 * half + row;
+                const int n = n0 + 4 * c4;
+                if (m < M && n < N) {
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * SLD + 4 * c4);
+                    if (n + 3 < N) {
+                        if (mask != nullptr) {
+                            const f32x4 mk = *reinterpret_cast<const f32x4 *>(mask + m * ldm + n);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] *= (mk[k] > 0.0f) ? 1.0f : slope;
+                        }
+                        f32x4 *dst = reinterpret_cast<f32x4 *>(C + m * ldc + n);
+                        if (mode == 1) { const f32x4 o = *dst; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+                        *dst = v;
+                    } else {
+                        for (int k = 0; k < 4 && n + k < N; ++k) {
+                            float x = v[k];
+                            if (mask != nullptr) x *= (mask[m * ldm + n + k] > 0.0f) ? 1.0f : slope;
+                            float *dst = C + m * ldc + n + k;
+                            *dst = (mode == 1) ? *dst + x : x;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
