@@ -364,6 +364,35 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, cons
         }
         return;
     }
+    if (TA && mode == 2) {
+        // Weight-gradient epilogue through LDS as well: one atomic instruction then covers 256 contiguous bytes of a dW row
+        // instead of four 64-byte segments of four rows.
+        constexpr int SLD = GT + 4;
+        float *stage = &smem[0][0][0];
+        __syncthreads();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) stage[(16 * i + 4 * q + r) * SLD + 64 * wn + 16 * j + c16] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int e = 0; e < 32; ++e) {
+                const int idx = tid + 256 * e, row = idx >> 7, col = idx & 127;
+                const long m = m0 + 64 * half + row;
+                const int n = n0 + col;
+                if (m < M && n < N) atomicAdd(C + m * ldc + n, stage[row * SLD + col]);
+            }
+            __syncthreads();
+        }
+        if (do_sum && tid < GT && m0 + tid < M) atomicAdd(rowsum + m0 + tid, cs);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
