@@ -689,8 +689,10 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     int dbo = 0;   // running offset into db scratch
     // bias-gradient slots of one level: BIAS_FLOATS-ish; the last 64 floats of the scratch are the DMA zero page
     static_assert(BIAS_FLOATS + 16 * 40 <= DB_SCRATCH - 64, "bias-gradient scratch too small for this model");
-    auto newdb = [&](int n) { float *p = db + dbo; dbo += (n + 3) / 4 * 4; return p; };
-    auto add_bias = [&](float *dbl, long boff, int n) { axpy_kernel<<<1, 256, 0, stream>>>(n, dbl, G(boff)); b.check(); };
+    // bias gradient of a layer: straight into the flat gradient (boff >= 0), or -- for the six layers whose folded per-frame
+    // constants need this call's db on its own -- into a scratch slot that add_bias then adds
+    auto newdb = [&](int n, long boff = -1) { if (boff >= 0) return G(boff); float *p = db + dbo; dbo += (n + 3) / 4 * 4; return p; };
+    auto add_bias = [&](float *dbl, long boff, int n) { if (dbl == G(boff)) return; axpy_kernel<<<1, 256, 0, stream>>>(n, dbl, G(boff)); b.check(); };
     auto consts = [&](long woff, long ld, int rows, int col0, int cols, const float *dbl, const float *c, float *dc) {
         const_cols_backward_kernel<<<cols, 256, 0, stream>>>(rows, cols, W(woff), G(woff), ld, col0, dbl, c, dc);
         b.check();
@@ -707,19 +709,19 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     const float *A = actbuf;
     {
         const float *dseg = d_raw + 3;   // (P,12), ld 16
-        float *dbl = newdb(N_SEG);
+        float *dbl = newdb(N_SEG, Lv.segout_b);
         b.tn(dseg, 16, N_SEG, A + (long)(act::S + 384) * P, BR_H, BR_H, G(Lv.segout_w), BR_H, dbl);
         add_bias(dbl, Lv.segout_b, N_SEG);
         b.nn(dseg, 16, N_SEG, W(Lv.segout_w), BR_H, BR_H, gA, BR_H, 0, A + (long)(act::S + 384) * P, BR_H, 0.01f);
         float *cur = gA, *nxt = gB;
         for (int i = 3; i >= 1; --i) {   // layers_seg[i]: s_{i-1} (128) -> s_i
-            float *d = newdb(BR_H);
+            float *d = newdb(BR_H, Lv.seg_b[i]);
             b.tn(cur, BR_H, BR_H, A + (long)(act::S + 128 * (i - 1)) * P, BR_H, BR_H, G(Lv.seg_w[i]), BR_H, d);
             add_bias(d, Lv.seg_b[i], BR_H);
             b.nn(cur, BR_H, BR_H, W(Lv.seg_w[i]), BR_H, BR_H, nxt, BR_H, 0, A + (long)(act::S + 128 * (i - 1)) * P, BR_H, 0.01f);
             float *t = cur; cur = nxt; nxt = t;
         }
-        float *d = newdb(BR_H);   // layers_seg[0]: feat (256) -> s0
+        float *d = newdb(BR_H, Lv.seg_b[0]);   // layers_seg[0]: feat (256) -> s0
         b.tn(cur, BR_H, BR_H, A + (long)(act::FEAT) * P, TR_H, TR_H, G(Lv.seg_w[0]), TR_H, d);
         add_bias(d, Lv.seg_b[0], BR_H);
         b.nn(cur, BR_H, BR_H, W(Lv.seg_w[0]), TR_H, TR_H, dfeat, 256, 0);       // feat has no activation
@@ -727,20 +729,20 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     // ================= colour branch (modules.py:276-287) =================
     {
         const float *drgb = d_raw;   // (P,3), ld 16
-        float *dbl = newdb(4);
+        float *dbl = newdb(4, Lv.rgb_b);
         b.tn(drgb, 16, 3, A + (long)(act::C + 384) * P, BR_H, BR_H, G(Lv.rgb_w), BR_H, dbl);
         add_bias(dbl, Lv.rgb_b, 3);
         b.nn(drgb, 16, 3, W(Lv.rgb_w), BR_H, BR_H, gA, BR_H, 0, A + (long)(act::C + 384) * P, BR_H, 0.01f);
         float *cur = gA, *nxt = gB;
         for (int i = 3; i >= 1; --i) {
-            float *d = newdb(BR_H);
+            float *d = newdb(BR_H, Lv.dir_b[i]);
             b.tn(cur, BR_H, BR_H, A + (long)(act::C + 128 * (i - 1)) * P, BR_H, BR_H, G(Lv.dir_w[i]), BR_H, d);
             add_bias(d, Lv.dir_b[i], BR_H);
             b.nn(cur, BR_H, BR_H, W(Lv.dir_w[i]), BR_H, BR_H, nxt, BR_H, 0, A + (long)(act::C + 128 * (i - 1)) * P, BR_H, 0.01f);
             float *t = cur; cur = nxt; nxt = t;
         }
         // layers_dir[0]: [feat256 | dirPE27 | grid32] -> c0
-        float *d = newdb(BR_H);
+        float *d = newdb(BR_H, Lv.dir_b[0]);
         b.tn(cur, BR_H, BR_H, A + (long)(act::FEAT) * P, TR_H, TR_H, G(Lv.dir_w[0]), D_DIR_IN, d);
         b.tn(cur, BR_H, BR_H, A + (long)(act::DIR) * P, 32, D_DIR, G(Lv.dir_w[0]) + TR_H, D_DIR_IN);
         b.tn(cur, BR_H, BR_H, A + (long)(act::GRID) * P, 32, D_GRID, G(Lv.dir_w[0]) + TR_H + D_DIR, D_DIR_IN);
@@ -751,7 +753,7 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     // ================= sigma = fc_alpha(feat) (modules.py:275) =================
     {
         const float *dsig = d_raw + 15;  // (P,1), ld 16
-        float *dbl = newdb(4);
+        float *dbl = newdb(4, Lv.alpha_b);
         b.tn(dsig, 16, 1, A + (long)(act::FEAT) * P, TR_H, TR_H, G(Lv.alpha_w), TR_H, dbl);
         add_bias(dbl, Lv.alpha_b, 1);
         rank1_add_kernel<<<2048, 256, 0, stream>>>(P, TR_H, dsig, 16, W(Lv.alpha_w), dfeat, 256); b.check();
@@ -759,13 +761,13 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     // ================= trunk (modules.py:267-274) =================
     {
         // feat = fc_feat(t7)
-        float *d = newdb(TR_H);
+        float *d = newdb(TR_H, Lv.feat_b);
         b.tn(dfeat, 256, TR_H, A + (long)(act::T + (TR_LAYERS - 1) * 256) * P, TR_H, TR_H, G(Lv.feat_w), TR_H, d);
         add_bias(d, Lv.feat_b, TR_H);
         b.nn(dfeat, 256, TR_H, W(Lv.feat_w), TR_H, TR_H, gA, 256, 0, A + (long)(act::T + (TR_LAYERS - 1) * 256) * P, TR_H, 0.01f);
         float *cur = gA, *nxt = gB;
         for (int i = TR_LAYERS - 1; i >= 1; --i) {   // layers_xyz[i]: input t_{i-1} (and, for i == 3, [PE(x') | PE(w) | pose36])
-            float *dl = newdb(TR_H);
+            float *dl = (i == 3) ? newdb(TR_H) : newdb(TR_H, Lv.xyz_b[i]);
             const long ldw = (i == 3) ? TR_H + D_TR_IN : TR_H;
             b.tn(cur, 256, TR_H, A + (long)(act::T + (i - 1) * 256) * P, TR_H, TR_H, G(Lv.xyz_w[i]), ldw, dl);
             add_bias(dl, Lv.xyz_b[i], TR_H);
@@ -800,13 +802,13 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
 #if SAHS_MODEL != 2
     // ================= hyper sheet (modules.py:444-462): w = fc_ambient(g5) =================
     {
-        float *dbl = newdb(4);
+        float *dbl = newdb(4, F.hyp_fb);
         b.tn(dw, 4, AMB_DIM, A + (long)(act::HH + 5 * 64) * P, HYP_H, HYP_H, G(F.hyp_fw), HYP_H, dbl);
         add_bias(dbl, F.hyp_fb, AMB_DIM);
         b.nn(dw, 4, AMB_DIM, W(F.hyp_fw), HYP_H, HYP_H, gA, HYP_H, 0, A + (long)(act::HH + 5 * 64) * P, HYP_H, 0.0f);
         float *cur = gA, *nxt = gB;
         for (int i = 5; i >= 1; --i) {
-            float *dl = newdb(HYP_H);
+            float *dl = (i == 4) ? newdb(HYP_H) : newdb(HYP_H, F.hyp_b[i]);
             const long ldw = (i == 4) ? HYP_H + D_DEF_IN : HYP_H;
             b.tn(cur, HYP_H, HYP_H, A + (long)(act::HH + (i - 1) * 64) * P, HYP_H, HYP_H, G(F.hyp_w[i]), ldw, dl);
             add_bias(dl, F.hyp_b[i], HYP_H);
@@ -827,13 +829,13 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     // ================= warp field (modules.py:371-390): x' = x + tanh(fc_final(h5)) =================
     {
         tanh_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, dxw, g3); b.check();
-        float *dbl = newdb(4);
+        float *dbl = newdb(4, F.warp_fb);
         b.tn(g3, 4, 3, A + (long)(act::WH + 5 * 128) * P, WARP_H, WARP_H, G(F.warp_fw), WARP_H, dbl);
         add_bias(dbl, F.warp_fb, 3);
         b.nn(g3, 4, 3, W(F.warp_fw), WARP_H, WARP_H, gA, WARP_H, 0, A + (long)(act::WH + 5 * 128) * P, WARP_H, 0.0f);
         float *cur = gA, *nxt = gB;
         for (int i = 5; i >= 1; --i) {
-            float *dl = newdb(WARP_H);
+            float *dl = (i == 4) ? newdb(WARP_H) : newdb(WARP_H, F.warp_b[i]);
             const long ldw = (i == 4) ? WARP_H + D_DEF_IN : WARP_H;
             b.tn(cur, WARP_H, WARP_H, A + (long)(act::WH + (i - 1) * 128) * P, WARP_H, WARP_H, G(F.warp_w[i]), ldw, dl);
             add_bias(dl, F.warp_b[i], WARP_H);
