@@ -482,47 +482,72 @@ __global__ void __launch_bounds__(256) grid_backward_kernel(long P, const float 
                                                             const float *__restrict__ grid_cl, float *__restrict__ d_grid_cl,
                                                             float *__restrict__ d_xw)
 {
+    // Consecutive samples are consecutive depths of one ray and a ray crosses a 1/16-wide cell in ~13 of its 128 samples, so each
+    // half-wave walks a run of GCH samples and keeps the eight corner contributions of the CURRENT cell in registers, flushing
+    // them (one 128-byte atomic burst per corner) only when the cell changes: ~10x fewer atomics than one flush per sample.
+    constexpr int GCH = 16;
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-    for (long p2 = wave * 2; p2 < P; p2 += nwaves * 2) {
-        const long p = p2 + h;
-        const bool live = p < P;
-        const long pc = live ? p : P - 1;
-        const float *a = actbuf + (long)act::XW * P + pc * 16;
-        const float x = a[0], y = a[1], z = a[2];
-        const float R1 = (float)(G_RES - 1);
-        const float ix = ((x + 1.0f) / 2.0f) * R1, iy = ((y + 1.0f) / 2.0f) * R1, iz = ((z + 1.0f) / 2.0f) * R1;
-        const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-        const float wx0 = (fx + 1.0f) - ix, wx1 = ix - fx, wy0 = (fy + 1.0f) - iy, wy1 = iy - fy, wz0 = (fz + 1.0f) - iz, wz1 = iz - fz;
-        const bool ok = fx >= -1.0f && fx <= (float)G_RES && fy >= -1.0f && fy <= (float)G_RES && fz >= -1.0f && fz <= (float)G_RES;
-        const int xi = ok ? (int)fx : -2, yi = ok ? (int)fy : -2, zi = ok ? (int)fz : -2;
-        const float g = live ? d_gridf[pc * 32 + c] : 0.0f;
-        float gix = 0.0f, giy = 0.0f, giz = 0.0f;
+    const float R1 = (float)(G_RES - 1);
+    auto flush = [&](int key, const float *acc) {
+        if (key < 0) return;
+        const int xi = (key & 255) - 2, yi = ((key >> 8) & 255) - 2, zi = (key >> 16) - 2;
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
-            const int bx = n & 1, by = (n >> 1) & 1, bz = n >> 2;
-            const int cx = xi + bx, cy = yi + by, cz = zi + bz;
-            const bool in = live && cx >= 0 && cx < G_RES && cy >= 0 && cy < G_RES && cz >= 0 && cz < G_RES;
-            if (in) {
-                const long v = (((long)cz * G_RES + cy) * G_RES + cx) * D_GRID + c;
+            const int cx = xi + (n & 1), cy = yi + ((n >> 1) & 1), cz = zi + (n >> 2);
+            if (cx >= 0 && cx < G_RES && cy >= 0 && cy < G_RES && cz >= 0 && cz < G_RES)
+                atomicAdd(d_grid_cl + (((long)cz * G_RES + cy) * G_RES + cx) * D_GRID + c, acc[n]);
+        }
+    };
+    for (long chunk = wave * 2 + h; chunk * GCH < P; chunk += nwaves * 2) {
+        float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        int cur = -1;
+        for (int k = 0; k < GCH; ++k) {
+            const long p = chunk * GCH + k;
+            const bool live = p < P;
+            const long pc = live ? p : P - 1;
+            const float *a = actbuf + (long)act::XW * P + pc * 16;
+            const float x = a[0], y = a[1], z = a[2];
+            const float ix = ((x + 1.0f) / 2.0f) * R1, iy = ((y + 1.0f) / 2.0f) * R1, iz = ((z + 1.0f) / 2.0f) * R1;
+            const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+            const float wx0 = (fx + 1.0f) - ix, wx1 = ix - fx, wy0 = (fy + 1.0f) - iy, wy1 = iy - fy, wz0 = (fz + 1.0f) - iz, wz1 = iz - fz;
+            const bool ok = live && fx >= -1.0f && fx <= (float)G_RES && fy >= -1.0f && fy <= (float)G_RES && fz >= -1.0f && fz <= (float)G_RES;
+            const int xi = ok ? (int)fx : -2, yi = ok ? (int)fy : -2, zi = ok ? (int)fz : -2;
+            const int key = ok ? (((zi + 2) << 16) | ((yi + 2) << 8) | (xi + 2)) : -1;
+            if (key != cur) {
+                flush(cur, acc);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) acc[n] = 0.0f;
+                cur = key;
+            }
+            const float g = live ? d_gridf[pc * 32 + c] : 0.0f;
+            float gix = 0.0f, giy = 0.0f, giz = 0.0f;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const int bx = n & 1, by = (n >> 1) & 1, bz = n >> 2;
+                const int cx = xi + bx, cy = yi + by, cz = zi + bz;
+                const bool in = ok && cx >= 0 && cx < G_RES && cy >= 0 && cy < G_RES && cz >= 0 && cz < G_RES;
                 const float wxb = bx ? wx1 : wx0, wyb = by ? wy1 : wy0, wzb = bz ? wz1 : wz0;
-                atomicAdd(d_grid_cl + v, g * ((wxb * wyb) * wzb));
-                const float t = g * grid_cl[v];
-                gix += t * (bx ? 1.0f : -1.0f) * wyb * wzb;
-                giy += t * (by ? 1.0f : -1.0f) * wxb * wzb;
-                giz += t * (bz ? 1.0f : -1.0f) * wxb * wyb;
+                acc[n] += g * ((wxb * wyb) * wzb);
+                if (in) {
+                    const float t = g * grid_cl[(((long)cz * G_RES + cy) * G_RES + cx) * D_GRID + c];
+                    gix += t * (bx ? 1.0f : -1.0f) * wyb * wzb;
+                    giy += t * (by ? 1.0f : -1.0f) * wxb * wzb;
+                    giz += t * (bz ? 1.0f : -1.0f) * wxb * wyb;
+                }
+            }
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                gix += __shfl_xor(gix, off, 64);
+                giy += __shfl_xor(giy, off, 64);
+                giz += __shfl_xor(giz, off, 64);
+            }
+            if (live && c == 0) {
+                const float sc = R1 / 2.0f;
+                *reinterpret_cast<f32x4 *>(d_xw + p * 4) = f32x4{gix * sc, giy * sc, giz * sc, 0.0f};
             }
         }
-#pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) {
-            gix += __shfl_xor(gix, off, 64);
-            giy += __shfl_xor(giy, off, 64);
-            giz += __shfl_xor(giz, off, 64);
-        }
-        if (live && c == 0) {
-            const float sc = R1 / 2.0f;
-            *reinterpret_cast<f32x4 *>(d_xw + p * 4) = f32x4{gix * sc, giy * sc, giz * sc, 0.0f};
-        }
+        flush(cur, acc);
     }
 }
 
@@ -794,7 +819,7 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
     {
         const int tb = (int)(GRID_FLOATS / 32 / 32);   // 32 voxels x 32 channels per block
         grid_transpose_kernel<<<tb, 256, 0, stream>>>(W(F.grid), grid_cl, 0); b.check();
-        const long gb = (P + 7) / 8;                    // 4 waves x 2 samples per block pass
+        const long gb = (P + 127) / 128;                // 4 waves x 2 runs of 16 samples per block pass
         grid_backward_kernel<<<(unsigned)(gb < 8192 ? gb : 8192), 256, 0, stream>>>(P, actbuf, dgridf, grid_cl, dgrid_cl, dxw); b.check();
         grid_transpose_kernel<<<tb, 256, 0, stream>>>(dgrid_cl, G(F.grid), 1); b.check();
         encode_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, din, dxw, dw); b.check();
