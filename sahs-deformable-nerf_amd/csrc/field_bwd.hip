@@ -1,11 +1,11 @@
 // field_bwd.hip -- gradients of the per-sample field (BASELINE.json configs[4]: training step through the HIP ops).
 //
-// Layer-wise backward over the activations saved by field_forward_f32_kernel<SAVE> (sahs::act layout):
-// for every dense layer   dW += dY^T X,   db += colsum(dY),   dX = (dY W) * act'(X)
-// run as fp32 MFMA GEMMs over all samples of the call, plus small kernels for the positional-encoding, tanh and
-// trilinear-grid derivatives.  This first version is NOT fused (activations and per-layer gradients go through
-// HBM: 19 KB + ~3.6 KB per sample); it exists to make the training path exact and native, the fused
-// recompute-in-backward kernel is the follow-up.  Conventions follow autograd of the reference graph
+// Layer-wise backward over the activations saved by field_forward_f32_kernel<SAVE> (sahs::act layout: one dense
+// [P x width] array per layer): for every dense layer   dW += dY^T X (+ db = column sums of dY, fused),   dX = (dY W) * act'(X)
+// run as fp32 MFMA GEMMs over all samples of the call (gemm_dma_kernel: operand tiles by LDS-DMA, epilogues staged through
+// LDS), plus small kernels for the positional-encoding, tanh and trilinear-grid derivatives.  Built once per model
+// (sahs_model.hpp).  Not fused across layers: activations and per-layer gradients go through HBM.
+// Conventions follow autograd of the reference graph
 // (models.py:514-528, modules.py:371-390 / 444-462 / 254-295): the per-frame constant inputs (driving, pose
 // encoding) get their weight-column gradients from the bias gradient (their value is the same for every sample:
 // dW[:, const] = db (x) c) and their own gradient from W[:, const]^T db.

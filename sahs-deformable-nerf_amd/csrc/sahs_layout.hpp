@@ -418,6 +418,6 @@ constexpr int DIR = FEAT + 256;         // PE27(rd), 32
 constexpr int GRID = DIR + 32;          // grid features, 32
 constexpr int C = GRID + 32;            // colour hidden c0..c3, 4 x 128
 constexpr int S = C + 4 * 128;          // seg hidden s0..s3, 4 x 128
-constexpr int STRIDE = S + 4 * 128;     // AudioFaceModel: 4768 floats = 19 KB per sample
+constexpr int STRIDE = S + 4 * 128;     // sum of the array widths; AudioFaceModel: 4752 floats = 19 KB per sample
 }  // namespace act
 }  // namespace SAHS_NS
