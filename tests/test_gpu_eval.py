@@ -52,3 +52,24 @@ def test_eval_frame_loop_checkpoint_to_png(weights_mod, tmp_path):
     assert np.abs(rgb - rgb_f).max() < 2e-3
     assert np.abs(png.astype(np.int32) - (np.clip(rgb_f[:, :3], 0, 1) * 255).astype(np.int32).reshape(H, W, 3)).max() <= 1
     assert out[0]["normals"].shape == (H - 1, W - 1, 3) and torch.isfinite(out[0]["normals"]).all()
+
+
+def test_eval_frame_loop_expression_model(tmp_path):
+    """The same frame loop over an expression-driven NeRFaceModel (frames carry `expression` instead of `audio`)."""
+    sahs = pkg()
+    E = pkg("evaluation")
+    W = pkg("weights")
+    dev = torch.device("cuda:0")
+    cfg = sahs.default_config("expression")
+    cfg.nerf.validation.perturb = False
+    fw = W.flatten_state_dict(W.hash_state_dict(0, 8.0, 30.0, model="nerface"), model="nerface")
+    model = sahs.NeRFaceModel(cfg).to(dev).load_flat(fw).eval()
+    H = Wd = 16
+    focal = np.array([1100.0 * Wd / 512, 1100.0 * Wd / 512, 0.5, 0.5], np.float32)
+    rng = np.random.default_rng(4)
+    frames = [dict(pose=np.concatenate([np.eye(3), [[0.0], [0.0], [0.5]]], 1).astype(np.float32),
+                   expression=(rng.standard_normal(76) * 0.5).astype(np.float32), name="f_%04d.png" % i) for i in range(2)]
+    out = E.render_frames(model, cfg, frames, (H, Wd, focal), background=torch.rand(H, Wd, 15), savedir=str(tmp_path / "o"), log=lambda s: None)
+    assert len(out) == 2 and out[0]["rgb"].shape == (H, Wd, 15) and bool(torch.isfinite(out[0]["rgb"]).all())
+    assert not torch.equal(out[0]["rgb"], out[1]["rgb"])          # the expression drives the render
+    assert os.path.getsize(tmp_path / "o" / "normals" / "f_0001.png") > 0

@@ -208,3 +208,48 @@ def test_model_seam_is_differentiable(weights_mod):
             continue
         assert float((p.grad - r).abs().max()) <= 3e-2 * float(r.abs().max()) + 1e-9, k
     assert float((audio.grad - a2.grad).abs().max()) <= 3e-2 * float(a2.grad.abs().max())
+
+
+def test_blockwise_backward_matches_kept_activations(weights_mod, monkeypatch):
+    """Ray chunks larger than RenderRaysFn.BLOCK_RAYS keep only the depths and re-run the field block by block in backward; the
+    gradients must equal those of the path that keeps the activations from the forward (same kernels, other summation split)."""
+    sahs = pkg()
+    ops = pkg("ops")
+    dev = torch.device("cuda:0")
+    cfg = sahs.default_config()
+    fw = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 8.0, 30.0))
+    g = torch.Generator(device=dev).manual_seed(21)
+    R = 300
+    audio = torch.randn(16, 29, device=dev, generator=g)
+    pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32)).to(dev)
+    ro = torch.zeros(R, 3, device=dev)
+    ro[:, 2] = 0.8
+    rd = torch.randn(R, 3, device=dev, generator=g) * 0.15 + torch.tensor([0, 0, -1.0], device=dev)
+    bg = torch.cat([torch.rand(R, 3, device=dev, generator=g), torch.ones(R, 1, device=dev), torch.zeros(R, 11, device=dev)], 1)
+    A, B = torch.randn(R, 15, device=dev, generator=g), torch.randn(R, 15, device=dev, generator=g)
+    draws = [torch.rand(R, 64, device=dev, generator=g), torch.randn(R, 64, device=dev, generator=g), torch.rand(R, 64, device=dev, generator=g),
+             torch.randn(R, 128, device=dev, generator=g)]
+
+    def grads(block):
+        monkeypatch.setattr(ops.RenderRaysFn, "BLOCK_RAYS", block)
+        model = sahs.AudioFaceModel(cfg).to(dev).load_flat(fw).train()
+        a = audio.clone().requires_grad_(True)
+        log = list(draws)
+        o_rand, o_randn = torch.rand, torch.randn
+        torch.rand = lambda *x, **k: log.pop(0)
+        torch.randn = lambda *x, **k: log.pop(0)
+        try:
+            outs = sahs.run_one_iter_of_nerf(0, 0, None, model, ro, rd, cfg, mode="train", driving=a, pose=pose, background_prior=bg)
+        finally:
+            torch.rand, torch.randn = o_rand, o_randn
+        ((outs[0] * A).sum() + (outs[3] * B).sum() + outs[7].sum() * 0.1).backward()
+        return [o.detach() for o in outs], {k: p.grad.clone() for k, p in model.named_parameters()}, a.grad.clone()
+
+    o_k, g_k, a_k = grads(4096)      # activations kept from the forward
+    o_b, g_b, a_b = grads(128)       # 300 rays in blocks of 128: recomputed in backward
+    for x, y in zip(o_k, o_b):
+        assert torch.equal(x, y)
+    for k in g_k:
+        scale = float(g_k[k].abs().max()) + 1e-12
+        assert float((g_k[k] - g_b[k]).abs().max()) <= 1e-4 * scale, k
+    assert float((a_k - a_b).abs().max()) <= 1e-4 * float(a_k.abs().max())
