@@ -138,30 +138,50 @@ def hash_normal(n, stream, seed=0):
     return (r * np.cos(2.0 * np.pi * u2)).astype(np.float32)
 
 
-def hash_state_dict(seed=0, density_bias=0.0, density_gain=1.0, model="audio"):
+# mean of fc_alpha's output (gain 1, before the bias shift) of the hdr variant over the W512 sample volume: subtracted so that the
+# density logit is centred and rays terminate at varying depths in both passes instead of all-transparent / all-opaque
+HDR_SIGMA_CENTER = {"coarse": -0.334, "fine": 1.172}
+
+
+def hash_state_dict(seed=0, density_bias=0.0, density_gain=1.0, model="audio", hdr=False):
     """Deterministic synthetic ``state_dict`` (numpy fp32 arrays, state_dict order).
 
     ``density_bias``/``density_gain`` give the *density-boosted* variant of SURVEY.md section 8(d):
     fc_alpha.weight is multiplied by ``density_gain`` and ``density_bias`` is added to
     fc_alpha.bias, so that rays terminate before the background sample and the composite /
     importance-sampling stages are actually exercised.
+
+    ``hdr=True`` is the *high-dynamic-range* variant: PyTorch's default initialiser shrinks the activation
+    variance by 6 per ReLU layer, so default-scale networks end in colour/seg logits of |x| < 0.1 and any accuracy test
+    on them is soft (a trained avatar has O(1)-O(10) activations and sharp features).  Here every hidden layer keeps its
+    activation variance (He scaling, U(+-sqrt(6/fan_in))), the colour/seg heads are scaled to logits of sigma ~ 2.5, the
+    feature grid to sigma 0.3 (reference: 0.01), and the warp head is damped so the deformation stays a few centimetres.
     """
     sd = OrderedDict()
     spec = canonical_spec(model)
     for t, (k, shape) in enumerate(spec):
         n = int(np.prod(shape))
         if k == "spatial_embeddings":
-            v = hash_normal(n, t, seed) * np.float32(0.01)
+            v = hash_normal(n, t, seed) * np.float32(0.3 if hdr else 0.01)
         else:
             wshape = shape if k.endswith(".weight") else dict(spec)[k[:-5] + ".weight"]
             fan_in = int(np.prod(wshape[1:]))
             bound = np.float32(1.0 / np.sqrt(fan_in))
             v = (hash_uniform(n, t, seed) * np.float32(2.0) - np.float32(1.0)) * bound
+            if hdr and k.endswith(".weight") and not k.startswith("audNet_head"):
+                if ".layers_" in k or k.endswith("fc_feat.weight"):
+                    v = v * np.float32(np.sqrt(6.0))
+                elif k.endswith("fc_rgb.weight") or k.endswith("fc_seg.weight"):
+                    v = v * np.float32(4.0)
+                elif k.endswith("fc_final.weight"):
+                    v = v * np.float32(0.05)
         v = v.astype(np.float32).reshape(shape)
         if k.endswith("fc_alpha.weight"):
             v = v * np.float32(density_gain)
         if k.endswith("fc_alpha.bias"):
             v = v + np.float32(density_bias)
+            if hdr and model == "audio":   # centre the density logit (its mean over the W512 volume, measured once for seed 0)
+                v = v - np.float32(density_gain * HDR_SIGMA_CENTER["fine" if ".fine." in k else "coarse"])
         sd[k] = v
     return sd
 

@@ -65,6 +65,47 @@ class RandCapture:
         torch.rand, torch.randn = self._rand, self._randn
 
 
+class RandFeed:
+    """Replay a captured draw log (in order) to torch.rand / torch.randn, cast to the dtype the caller asks for: the float64
+    yardstick runs consume exactly the draws of the fp32 run they are compared with."""
+
+    def __init__(self, log):
+        self.log = list(log)
+
+    def __enter__(self):
+        self._rand, self._randn = torch.rand, torch.randn
+
+        def make(kind):
+            def f(*a, **k):
+                knd, arr = self.log.pop(0)
+                assert knd == kind, (knd, kind)
+                return torch.from_numpy(arr).to(k.get("dtype", torch.float32))
+            return f
+
+        torch.rand, torch.randn = make("rand"), make("randn")
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randn = self._rand, self._randn
+        assert not self.log, "yardstick run consumed fewer draws than the fp32 run"
+
+
+class Float64Yardstick:
+    """Context for running the reference MODEL IN FLOAT64 (``model.double()``, double inputs) as the accuracy yardstick: how far
+    the reference's own fp32 result is from the exact value of the same formulas.  The one fp32 cast on the path,
+    ``coordinates.float()`` in sample_from_3dgrid (models.py:355), is made the identity on double tensors for the duration
+    (harness-level patch of Tensor.float, no reference edits), so the yardstick is float64 end to end."""
+
+    def __enter__(self):
+        self._float = torch.Tensor.float
+        orig = self._float
+        torch.Tensor.float = lambda t, *a, **k: t if t.dtype == torch.float64 else orig(t, *a, **k)
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.float = self._float
+
+
 def rot(ax, ay, az):
     cx, sx, cy, sy, cz, sz = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az)
     rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
@@ -90,9 +131,11 @@ def main():
         m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         return m.eval()
 
-    VARIANTS = {"default": dict(seed=0, density_bias=0.0, density_gain=1.0),
-                "boosted": dict(seed=0, density_bias=8.0, density_gain=30.0)}
+    VARIANTS = {"default": dict(seed=0, density_bias=0.0, density_gain=1.0, hdr=False),
+                "boosted": dict(seed=0, density_bias=8.0, density_gain=30.0, hdr=False),
+                "hdr": dict(seed=0, density_bias=2.0, density_gain=30.0, hdr=True)}   # high dynamic range (weights.hash_state_dict)
     models = {k: build_model(**v) for k, v in VARIANTS.items()}
+    models64 = {k: build_model(**v).double() for k, v in VARIANTS.items()}              # float64 yardsticks
     out = {}
 
     # ---- rays: get_ray_bundle (nerf_helpers.py:178-233) ----
@@ -141,6 +184,23 @@ def main():
             fld[vname + "_grid_coarse"] = m.sample_from_3dgrid("coarse", mapped[..., :3]).numpy()
             for lvl in ("coarse", "fine"):
                 fld[vname + "_raw_" + lvl] = m(lvl, xt, torch.from_numpy(audio), torch.from_numpy(pose), None).numpy()
+        # the same seams from the reference model in float64 (yardstick: |ref_fp32 - f64| is the reference's own round-off)
+        m64 = models64[vname]
+        with torch.no_grad(), Float64Yardstick():
+            xd, ad, pd = torch.from_numpy(x18).double(), torch.from_numpy(audio).double(), torch.from_numpy(pose).double()
+            drv = m64.audNet_head(ad.unsqueeze(0)).repeat(P, 1)
+            pe36 = m64.encode_pose_fn(ref.models.pose_to_euler_trans(pd.unsqueeze(0), "cpu")).repeat(P, 1)
+            assert drv.dtype == torch.float64 and pe36.dtype == torch.float64
+            mapped = m64.map_points(xd[:, :3], drv, pe36)
+            fld[vname + "_dx_f64"] = (mapped[:, :3] - xd[:, :3]).numpy()
+            fld[vname + "_w_f64"] = mapped[:, 3:].numpy()
+            g64 = m64.sample_from_3dgrid("coarse", mapped[..., :3])
+            assert g64.dtype == torch.float64
+            fld[vname + "_grid_coarse_f64"] = g64.numpy()
+            for lvl in ("coarse", "fine"):
+                r64 = m64(lvl, xd, ad, pd, None)
+                assert r64.dtype == torch.float64
+                fld[vname + "_raw_" + lvl + "_f64"] = r64.numpy()
     out["field"] = fld
 
     # ---- composite: volume_render_radiance_field (volume_rendering_utils.py:7-78) ----
@@ -223,7 +283,8 @@ def main():
     mask_e = np.zeros((He, We, 12), np.float32)
     mask_e[..., 0] = 1.0
 
-    def e2e(tag, model, mode, chunksize, perturb, noise_std):
+    def e2e(tag, vname, mode, chunksize, perturb, noise_std):
+        model = models[vname]
         c = cfg.clone() if hasattr(cfg, "clone") else cfg
         node = getattr(c.nerf, mode)
         old = (node.chunksize, node.perturb, node.radiance_field_noise_std)
@@ -235,6 +296,13 @@ def main():
                     He, We, intr_e, model, ro_e, rd_e, c, mode=mode, driving=torch.from_numpy(audio),
                     pose=torch.from_numpy(pose_e), pose_c=None, background_prior=torch.from_numpy(bg_e),
                     latent_code=None, inHead=torch.from_numpy(mask_e))
+            # float64 yardstick: the reference driver over the float64 model, double rays, the SAME draws
+            with torch.no_grad(), RandFeed(cap.log), Float64Yardstick():
+                r64 = ref.train_utils.run_one_iter_of_nerf(
+                    He, We, intr_e, models64[vname], ro_e.double(), rd_e.double(), c, mode=mode, driving=torch.from_numpy(audio).double(),
+                    pose=torch.from_numpy(pose_e).double(), pose_c=None, background_prior=torch.from_numpy(bg_e).double(),
+                    latent_code=None, inHead=torch.from_numpy(mask_e).double())
+            assert all(t.dtype == torch.float64 for t in r64)
         finally:
             node.chunksize, node.perturb, node.radiance_field_noise_std = old
         d = dict(H=He, W=We, intrinsics=intr_e, pose=pose_e, audio=audio, bg=bg_e, mode=mode, chunksize=chunksize,
@@ -242,16 +310,22 @@ def main():
                  num_coarse=node.num_coarse, num_fine=node.num_fine, ro=ro_e.numpy(), rd=rd_e.numpy())
         for nm, t in zip(("rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"), r):
             d["out_" + nm] = t.numpy()
+        for nm, t in zip(("rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"), r64):
+            d["f64_" + nm] = t.numpy()
         for i, (kind, arr) in enumerate(cap.log):
             d["rand_%02d_%s" % (i, kind)] = arr
         d["n_rand"] = len(cap.log)
+        d["variant"] = vname
         out[tag] = d
 
-    e2e("e2e_default_val", models["default"], "validation", 131072, True, 0.0)
-    e2e("e2e_boosted_val", models["boosted"], "validation", 131072, True, 0.0)
-    e2e("e2e_boosted_val_2chunks", models["boosted"], "validation", 128, True, 0.0)
-    e2e("e2e_boosted_det", models["boosted"], "validation", 131072, False, 0.0)
-    e2e("e2e_boosted_train_noise", models["boosted"], "train", 131072, True, 0.1)
+    e2e("e2e_default_val", "default", "validation", 131072, True, 0.0)
+    e2e("e2e_boosted_val", "boosted", "validation", 131072, True, 0.0)
+    e2e("e2e_boosted_val_2chunks", "boosted", "validation", 128, True, 0.0)
+    e2e("e2e_boosted_det", "boosted", "validation", 131072, False, 0.0)
+    e2e("e2e_boosted_train_noise", "boosted", "train", 131072, True, 0.1)
+    e2e("e2e_hdr_val", "hdr", "validation", 131072, True, 0.0)
+    e2e("e2e_hdr_det", "hdr", "validation", 131072, False, 0.0)
+    e2e("e2e_hdr_train_noise", "hdr", "train", 131072, True, 0.1)
 
     # ---- gradients (config[4] semantics): train mode, 32 rays, relu->relu.clone() harness shim ----
     F = torch.nn.functional
@@ -296,6 +370,94 @@ def main():
         g["grad_names"] = np.array([k for k, _ in mg.named_parameters()])
         g["grad_audio"] = audio_t.grad.numpy()
         out["train_grads"] = g
+
+        # ---- the reference's loss classes (nerf_helpers.py:14-62), weights as the training script builds them
+        #      (train_stage_rays_auto.py:268-271: ones(12), [7:9] = 2); class 5 is empty, class 11 has one pixel ----
+        Nl = 200
+        cls = rng.integers(0, 12, Nl)
+        cls[cls == 5] = 4
+        cls[cls == 11] = 10
+        cls[0] = 11
+        maskl = np.eye(12, dtype=np.float32)[cls]
+        pred_rgb = rng.uniform(0, 1, (Nl, 3)).astype(np.float32)
+        tgt_rgb = rng.uniform(0, 1, (Nl, 3)).astype(np.float32)
+        pred_seg = rng.dirichlet(np.ones(12) * 0.3, Nl).astype(np.float32)
+        pred_seg[3] = 0.0                      # a pixel whose predicted distribution is all zeros: log(0 + 1e-10)
+        spw = torch.ones(12)
+        spw[7:9] = 2
+        mse_l, ce_l = ref.nerf_helpers.MaskMSELoss(spw.clone()), ref.nerf_helpers.MaskCrossEntropyLoss(spw.clone())
+        lm = mse_l(torch.from_numpy(maskl), torch.from_numpy(pred_rgb), torch.from_numpy(tgt_rgb))
+        lc = ce_l(torch.from_numpy(maskl), torch.from_numpy(pred_seg), torch.from_numpy(maskl))
+        lm0 = ref.nerf_helpers.MaskMSELoss()(torch.from_numpy(maskl), torch.from_numpy(pred_rgb), torch.from_numpy(tgt_rgb))
+        out["losses"] = dict(mask=maskl, pred_rgb=pred_rgb, target_rgb=tgt_rgb, pred_seg=pred_seg, weights=spw.numpy(),
+                             mse=lm[0].numpy(), mse_masked=lm[1].numpy(), mse_weighted=lm[2].numpy(),
+                             ce=lc[0].numpy(), ce_masked=lc[1].numpy(), ce_weighted=lc[2].numpy(),
+                             mse_weighted_noweights=lm0[2].numpy())
+
+        # ---- one training step of train_stage_rays_auto.py:437-468 (loss recipe + sample_prob feedback) over the reference's
+        #      own renders, 32 rays, train mode (noise 0.1), hdr weights; fp32 and the float64 yardstick on the same draws ----
+        def train_step_capture(model, dt, log=None):
+            cls_t = rng_t.integers(0, 12, nr)
+            cls_t[cls_t == 5] = 4
+            mask_t = torch.from_numpy(np.eye(12, dtype=np.float32)[cls_t]).to(dt)
+            target = torch.from_numpy(tgt_t).to(dt)
+            a_t = torch.from_numpy(audio).to(dt).requires_grad_(True)
+            w12 = torch.ones(12, dtype=dt)
+            w12[7:9] = 2
+            mse_loss, cross_entropy_loss = ref.nerf_helpers.MaskMSELoss(w12.clone()), ref.nerf_helpers.MaskCrossEntropyLoss(w12.clone())
+            ctx = RandCapture() if log is None else RandFeed(log)
+            with ctx as cap:
+                rr = ref.train_utils.run_one_iter_of_nerf(
+                    He, We, intr_e, model, ro_g.to(dt), rd_g.to(dt), cfg, mode="train", driving=a_t, pose=torch.from_numpy(pose_e).to(dt),
+                    pose_c=None, background_prior=torch.from_numpy(bg_g).to(dt), latent_code=None, inHead=mask_t)
+            rgb_coarse, rgb_fine = rr[0], rr[3]
+            # train_stage_rays_auto.py:455-468, restated over the reference's loss classes
+            c_l2, m_c_l2, m_c_l2_w = mse_loss(mask_t, rgb_coarse[..., :3], target[..., :3])
+            c_ce, m_c_ce, m_c_ce_w = cross_entropy_loss(mask_t, rgb_coarse[..., 3:], mask_t)
+            c_loss = c_l2 + 0.02 * c_ce + 0.005 * torch.sum(m_c_l2[7:9] + m_c_ce[7:9])
+            f_l2, m_f_l2, m_f_l2_w = mse_loss(mask_t, rgb_fine[..., :3], target[..., :3])
+            f_ce, m_f_ce, m_f_ce_w = cross_entropy_loss(mask_t, rgb_fine[..., 3:], mask_t)
+            f_loss = f_l2 + 0.02 * f_ce + 0.005 * torch.sum(m_f_l2[7:9] + m_f_ce[7:9])
+            sample_prob = (m_c_l2_w + m_c_ce_w + m_f_l2_w + m_f_ce_w) / (m_c_l2_w.sum() + m_c_ce_w.sum() + m_f_l2_w.sum() + m_f_ce_w.sum())
+            loss = c_loss + f_loss
+            loss.backward()
+            return dict(cap=cap, outs=rr, loss=loss, sample_prob=sample_prob, parts=(c_l2, c_ce, f_l2, f_ce), audio_grad=a_t.grad,
+                        mask=mask_t, cls=cls_t)
+
+        rng_t = np.random.default_rng(77)
+        tgt_t = np.random.default_rng(78).uniform(0, 1, (nr, 3)).astype(np.float32)
+        mt = build_model(**VARIANTS["hdr"]).train()
+        torch.manual_seed(11)
+        t32 = train_step_capture(mt, torch.float32)
+        rng_t = np.random.default_rng(77)
+        mt64 = build_model(**VARIANTS["hdr"]).double().train()
+        with Float64Yardstick():
+            t64 = train_step_capture(mt64, torch.float64, log=t32["cap"].log)
+        ts = dict(sel=sel, ro=ro_g.numpy(), rd=rd_g.numpy(), bg=bg_g, audio=audio, pose=pose_e, target=tgt_t, mask=t32["mask"].numpy(),
+                  near=cfg.dataset.near, far=cfg.dataset.far, loss=t32["loss"].item(), loss_f64=t64["loss"].item(),
+                  sample_prob=t32["sample_prob"].detach().numpy(), sample_prob_f64=t64["sample_prob"].detach().numpy(),
+                  parts=np.array([float(x) for x in t32["parts"]]), parts_f64=np.array([float(x) for x in t64["parts"]]),
+                  grad_audio=t32["audio_grad"].numpy(), grad_audio_f64=t64["audio_grad"].numpy())
+        for nm, t, t6 in zip(("rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"), t32["outs"], t64["outs"]):
+            ts["out_" + nm] = t.detach().numpy()
+            ts["f64_" + nm] = t6.detach().numpy()
+        for i, (kind, arr) in enumerate(t32["cap"].log):
+            ts["rand_%02d_%s" % (i, kind)] = arr
+        ts["n_rand"] = len(t32["cap"].log)
+        norms, norms64 = [], []
+        for (k, p_), (_, p6) in zip(mt.named_parameters(), mt64.named_parameters()):
+            gr = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+            g6 = p6.grad if p6.grad is not None else torch.zeros_like(p6)
+            norms.append(float(gr.double().norm()))
+            norms64.append(float(g6.norm()))
+            if p_.numel() <= 4096 or k.endswith("bias"):
+                ts["grad_" + k], ts["grad64_" + k] = gr.numpy(), g6.numpy()
+            else:
+                st = max(1, p_.numel() // 2048)
+                ts["gradsub_" + k], ts["gradsub64_" + k] = gr.reshape(-1)[::st].numpy().copy(), g6.reshape(-1)[::st].numpy().copy()
+        ts["grad_norms"], ts["grad_norms_f64"] = np.array(norms, np.float64), np.array(norms64, np.float64)
+        ts["grad_names"] = np.array([k for k, _ in mt.named_parameters()])
+        out["train_step_hdr"] = ts
     finally:
         F.relu = orig_relu
 
@@ -329,8 +491,8 @@ def main():
 
     for name, d in out.items():
         d = dict(d)
-        if name.startswith("e2e") or name == "train_grads":
-            v = "default" if "default" in name else "boosted"
+        if name.startswith("e2e") or name.startswith("train_"):
+            v = "default" if "default" in name else ("hdr" if "hdr" in name else "boosted")
             d.update({"weights_" + k: val for k, val in VARIANTS[v].items()})
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
         print("%-28s %8.1f KB" % (name + ".npz", os.path.getsize(os.path.join(HERE, name + ".npz")) / 1024))

@@ -1,19 +1,21 @@
 """GPU parity tests proper: the HIP path (through the C ABI, via sahs-deformable-nerf_amd.ops) against
 the CPU oracle on seeded inputs and against the golden vectors generated from the real reference.
 
-Tolerances (fp32 path).  The oracle and the kernels share the summation order of every dense layer
-(k-ordered fmaf chain = f32 MFMA) except (i) the per-frame constant inputs, which the kernels fold
-into the bias, and (ii) libm vs ocml transcendentals (each <= 1-2 ulp).  Those ~1e-7 relative
-differences are amplified by the path's conditioning: the warped point feeds sin/cos(2^9 x), so a
-1e-7 change in dx moves the highest PE features by ~5e-5 and raw outputs by ~1e-4 (same amplification
-is visible between the oracle and the reference itself, test_oracle_vs_golden.py).  Integer work
-(searchsorted indices, given identical inputs) must be bit-exact.
+Tolerances (fp32 path), two kinds:
+ * fixed, at SURVEY.md section 8d's level (rtol 1e-4 / atol 1e-5 on the 8 outputs; tighter at the inner seams) on the
+   default-scale and density-boosted networks;
+ * the float64 yardstick (conftest.yardstick): the golden files also hold the reference MODEL RUN IN FLOAT64 on the same
+   inputs and draws; the HIP result must be as close to it as the reference's own fp32 result is (max and rms within 2x plus
+   32 ulps of the tensor's scale).  This is the only meaningful bound on the high-dynamic-range network ("hdr": He-scaled
+   layers, logits of sigma ~2.5, density logits of sigma ~6.5 x 30), where round-off is amplified to 1e-4 for the reference
+   itself.  Observed errors are printed in the terminal summary.
+Integer work (searchsorted indices, given identical inputs) must be bit-exact.
 """
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden_rand, load_golden, pkg
+from conftest import VARIANT_KW, golden_rand, golden_weights_kw, load_golden, pkg, yardstick
 
 pytestmark = pytest.mark.gpu
 
@@ -91,11 +93,10 @@ def test_conditioning(ops, packed_cache, flat_weights):
     close(frame[128:128 + 128], ref, 1e-5, 1e-6, "folded bias W0")
 
 
-@pytest.mark.parametrize("variant", ["default", "boosted"])
+@pytest.mark.parametrize("variant", ["default", "boosted", "hdr"])
 def test_field_vs_golden(ops, packed_cache, variant):
     g = load_golden("field")
-    kw = dict(default=dict(), boosted=dict(density_bias=8.0, density_gain=30.0))[variant]
-    flat, packed = packed_cache(**kw)
+    flat, packed = packed_cache(**VARIANT_KW[variant])
     frame = ops.fold_conditioning(flat, T(g["audio"]), T(g["pose"]))
     x = g["x"]
     P = x.shape[0]
@@ -104,14 +105,24 @@ def test_field_vs_golden(ops, packed_cache, variant):
     z = torch.zeros(P, 1, device=dev())
     raw_c, dx, w, grid = ops.field_forward(packed, frame, 0, T(rays), z, debug=True)
     raw_f = ops.field_forward(packed, frame, 1, T(rays), z)
-    close(dx.view(P, 3), g[variant + "_dx"], 1e-4, 2e-6, "dx")
-    close(w.view(P, 2), g[variant + "_w"], 1e-4, 2e-6, "w")
-    close(grid.view(P, 32), g[variant + "_grid_coarse"], 1e-3, 2e-6, "grid")
+    tag = "hip field[%s] " % variant
+    yardstick(dx.view(P, 3), g[variant + "_dx"], g[variant + "_dx_f64"], tag + "dx")
+    yardstick(w.view(P, 2), g[variant + "_w"], g[variant + "_w_f64"], tag + "w")
+    yardstick(grid.view(P, 32), g[variant + "_grid_coarse"], g[variant + "_grid_coarse_f64"], tag + "grid")
+    for lvl, raw in (("coarse", raw_c), ("fine", raw_f)):
+        r32, r64 = g[variant + "_raw_" + lvl], g[variant + "_raw_" + lvl + "_f64"]
+        yardstick(raw.view(P, 16)[:, :15], r32[:, :15], r64[:, :15], tag + "raw rgb/seg " + lvl)
+        yardstick(raw.view(P, 16)[:, 15], r32[:, 15], r64[:, 15], tag + "raw sigma " + lvl)
+    if variant == "hdr":
+        return          # round-off is amplified to 1e-4 on this network for the reference itself: the yardstick is the bound
+    close(dx.view(P, 3), g[variant + "_dx"], 1e-5, 5e-7, "dx")
+    close(w.view(P, 2), g[variant + "_w"], 1e-5, 5e-7, "w")
+    close(grid.view(P, 32), g[variant + "_grid_coarse"], 1e-4, 5e-7, "grid")
     scale = 30.0 if variant == "boosted" else 1.0
     for lvl, raw in (("coarse", raw_c), ("fine", raw_f)):
         raw = raw.view(P, 16)
-        close(raw[:, :15], g[variant + "_raw_" + lvl][:, :15], 1e-3, 1e-4, "raw rgb/seg " + lvl)
-        close(raw[:, 15], g[variant + "_raw_" + lvl][:, 15], 1e-3, 1e-4 * scale, "raw sigma " + lvl)
+        close(raw[:, :15], g[variant + "_raw_" + lvl][:, :15], 1e-4, 1e-6, "raw rgb/seg " + lvl)
+        close(raw[:, 15], g[variant + "_raw_" + lvl][:, 15], 1e-4, 1e-6 * scale, "raw sigma " + lvl)
 
 
 @pytest.mark.parametrize("N,S", [(37, 64), (19, 128), (5, 1), (3, 192)])
@@ -226,7 +237,7 @@ class FeedRand:
 
 
 @pytest.mark.parametrize("name", ["e2e_default_val", "e2e_boosted_val", "e2e_boosted_val_2chunks", "e2e_boosted_det",
-                                  "e2e_boosted_train_noise"])
+                                  "e2e_boosted_train_noise", "e2e_hdr_val", "e2e_hdr_det", "e2e_hdr_train_noise"])
 def test_end_to_end_vs_golden(name, flat_weights):
     """The drop-in run_one_iter_of_nerf against the reference's own outputs on identical rays/weights/random draws."""
     sahs = pkg()
@@ -236,7 +247,7 @@ def test_end_to_end_vs_golden(name, flat_weights):
     node = getattr(cfg.nerf, mode)
     node.chunksize, node.perturb, node.radiance_field_noise_std = int(g["chunksize"]), bool(g["perturb"]), float(g["noise_std"])
     model = sahs.AudioFaceModel(cfg).to(dev())
-    model.load_flat(flat_weights(int(g["weights_seed"]), float(g["weights_density_bias"]), float(g["weights_density_gain"])))
+    model.load_flat(flat_weights(**golden_weights_kw(g)))
     pose = T(g["pose"])
     ro, rd = sahs.get_ray_bundle(int(g["H"]), int(g["W"]), g["intrinsics"], pose)
     close(rd, g["rd"], 1e-6, 1e-7, "rd")
@@ -249,7 +260,10 @@ def test_end_to_end_vs_golden(name, flat_weights):
     for nm, o in zip(names, outs):
         ref = g["out_" + nm]
         assert tuple(o.shape) == tuple(ref.shape), (nm, o.shape, ref.shape)
-        close(o, ref, 2e-3, 2e-4, name + ":" + nm)
+        yardstick(o, ref, g["f64_" + nm], "hip %s:%s" % (name, nm), outlier_rays=0.0 if nm.endswith("_c") else 0.02, scale_floor=1.0,
+                  ray_shape=ref.shape[:2] if mode == "validation" else ref.shape[:1])
+        if "hdr" not in name:
+            close(o, ref, 1e-4, 1e-5, name + ":" + nm)      # fp32 kernels rtol 1e-4 / atol 1e-5 on all 8 outputs
 
 
 def test_model_seam_matches_driver(flat_weights):

@@ -9,7 +9,7 @@ times the first-layer weights (|W| <= 1/sqrt(199))."""
 import numpy as np
 import pytest
 
-from conftest import golden_rand, load_golden, pkg
+from conftest import golden_rand, load_golden, pkg, yardstick
 from oracle import oracle
 from test_oracle_vs_golden import close
 
@@ -80,6 +80,14 @@ def test_field(nf_flat, variant):
     for lvl, raw in (("coarse", raw_c), ("fine", raw_f)):
         close(raw[:, :15], g[variant + "_raw_" + lvl][:, :15], 2e-3, 2e-3, "raw rgb/seg " + lvl)
         close(raw[:, 15], g[variant + "_raw_" + lvl][:, 15], 2e-3, 2e-3 * scale, "raw sigma " + lvl)
+    # the float64 yardstick says what those 2e-3 are: the reference's own fp32 run is 3e-4 .. 6e-4 from the exact value here
+    # (sin/cos(2^14 x') of a warped point known to 7e-8), and the oracle must be no further than twice that
+    tag = "oracle nerface field[%s] " % variant
+    yardstick(dx, g[variant + "_dx"], g[variant + "_dx_f64"], tag + "dx")
+    yardstick(w, g[variant + "_w"], g[variant + "_w_f64"], tag + "w")
+    yardstick(grid, g[variant + "_grid_coarse"], g[variant + "_grid_coarse_f64"], tag + "grid")
+    for lvl, raw in (("coarse", raw_c), ("fine", raw_f)):
+        yardstick(raw, g[variant + "_raw_" + lvl], g[variant + "_raw_" + lvl + "_f64"], tag + "raw " + lvl)
 
 
 @pytest.mark.parametrize("name", ["nerface_e2e_val", "nerface_e2e_det", "nerface_static_e2e_val"])
@@ -112,4 +120,7 @@ def test_end_to_end(nf_flat, name):
         close(v, g["out_" + nm].reshape(v.shape), 5e-4, 1e-4, name + ": fine pass on reference depths: " + nm)
     for nm in ("rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"):
         close(o[nm], g["out_" + nm].reshape(o[nm].shape), 1e-2, 3e-3, name + ": chained " + nm)
+    for nm in ("rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"):   # and against the float64 run of the reference
+        yardstick(o[nm], g["out_" + nm], g["f64_" + nm], "oracle %s:%s" % (name, nm), outlier_rays=0.0 if nm.endswith("_c") else 0.02, scale_floor=1.0,
+                  ray_shape=(N,))
     assert float(np.mean(g["out_w_bg"])) < 0.5

@@ -10,7 +10,7 @@ falls within round-off of a cdf knot.
 import numpy as np
 import pytest
 
-from conftest import golden_rand, load_golden
+from conftest import VARIANT_KW, golden_rand, golden_weights_kw, load_golden, yardstick
 from oracle import oracle
 
 
@@ -48,11 +48,10 @@ def test_positional_encoding():
     close(oracle.positional_encoding(g["x"], 3, include_input=False), g["pe_pose"], 1e-6, 1e-6, "pe_pose")
 
 
-@pytest.mark.parametrize("variant", ["default", "boosted"])
+@pytest.mark.parametrize("variant", ["default", "boosted", "hdr"])
 def test_field(flat_weights, variant):
     g = load_golden("field")
-    kw = dict(default=dict(), boosted=dict(density_bias=8.0, density_gain=30.0))[variant]
-    flat = flat_weights(**kw)
+    flat = flat_weights(**VARIANT_KW[variant])
     drv = oracle.audionet(flat, g["audio"])
     p36 = oracle.pose_encoding(g["pose"])
     raw_c, dx, w, grid = oracle.field_forward(flat, 0, g["x"], drv, p36, debug=True)
@@ -61,10 +60,19 @@ def test_field(flat_weights, variant):
     close(w, g[variant + "_w"], 1e-4, 2e-6, "ambient w")
     # grid features and raw see PE(512 * warped point): round-off in dx (1e-7) is amplified ~512x
     close(grid, g[variant + "_grid_coarse"], 1e-3, 2e-6, "grid features")
-    scale = 30.0 if variant == "boosted" else 1.0
+    scale = 1.0 if variant == "default" else 30.0
     for lvl, raw in (("coarse", raw_c), ("fine", raw_f)):
         close(raw[:, :15], g[variant + "_raw_" + lvl][:, :15], 1e-3, 1e-4, "raw rgb/seg " + lvl)
         close(raw[:, 15], g[variant + "_raw_" + lvl][:, 15], 1e-3, 1e-4 * scale, "raw sigma " + lvl)
+    # accuracy against the reference model in float64: the oracle is as close to it as the reference's own fp32 run
+    tag = "oracle field[%s] " % variant
+    yardstick(dx, g[variant + "_dx"], g[variant + "_dx_f64"], tag + "dx")
+    yardstick(w, g[variant + "_w"], g[variant + "_w_f64"], tag + "w")
+    yardstick(grid, g[variant + "_grid_coarse"], g[variant + "_grid_coarse_f64"], tag + "grid")
+    for lvl, raw in (("coarse", raw_c), ("fine", raw_f)):
+        r32, r64 = g[variant + "_raw_" + lvl], g[variant + "_raw_" + lvl + "_f64"]
+        yardstick(raw[:, :15], r32[:, :15], r64[:, :15], tag + "raw rgb/seg " + lvl)
+        yardstick(raw[:, 15], r32[:, 15], r64[:, 15], tag + "raw sigma " + lvl)
 
 
 @pytest.mark.parametrize("tag,use_bg,use_noise,white", [("bg", True, False, False), ("bg_noise", True, True, False),
@@ -126,10 +134,11 @@ def _chunk_rand(g, nchunks):
 
 
 @pytest.mark.parametrize("name,nchunks", [("e2e_default_val", 1), ("e2e_boosted_val", 1), ("e2e_boosted_val_2chunks", 2),
-                                          ("e2e_boosted_det", 1), ("e2e_boosted_train_noise", 1)])
+                                          ("e2e_boosted_det", 1), ("e2e_boosted_train_noise", 1), ("e2e_hdr_val", 1),
+                                          ("e2e_hdr_det", 1), ("e2e_hdr_train_noise", 1)])
 def test_end_to_end(flat_weights, name, nchunks):
     g = load_golden(name)
-    flat = flat_weights(int(g["weights_seed"]), float(g["weights_density_bias"]), float(g["weights_density_gain"]))
+    flat = flat_weights(**golden_weights_kw(g))
     ro, rd = oracle.get_ray_bundle(int(g["H"]), int(g["W"]), g["intrinsics"], g["pose"])
     close(rd, g["rd"], 1e-6, 1e-7)
     outs = oracle.run_one_iter_of_nerf(flat, ro, rd, float(g["near"]), float(g["far"]), int(g["num_coarse"]), int(g["num_fine"]),
@@ -139,7 +148,10 @@ def test_end_to_end(flat_weights, name, nchunks):
     for nm, o in zip(names, outs):
         ref = g["out_" + nm].reshape(o.shape)
         # end-to-end: field round-off (1e-4 abs on raw) passes through sigmoid/softmax and the composite
-        close(o, ref, 2e-3, 2e-4, name + ":" + nm)
+        if "hdr" not in name:
+            close(o, ref, 2e-3, 2e-4, name + ":" + nm)
+        yardstick(o, ref, g["f64_" + nm], "oracle %s:%s" % (name, nm), outlier_rays=0.0 if nm.endswith("_c") else 0.02, scale_floor=1.0,
+                  ray_shape=(int(g["H"]) * int(g["W"]),))
     if "boosted" in name:
         assert float(np.mean(g["out_w_bg"])) < 0.5, "density-boosted fixture should terminate rays before the background"
 

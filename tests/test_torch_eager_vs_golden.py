@@ -4,12 +4,12 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_rand, load_golden
+from conftest import golden_rand, golden_weights_kw, load_golden, yardstick
 from oracle import torch_eager as TE
 
 
-def sd_torch(weights_mod, seed, bias, gain, requires_grad=False):
-    sd = {k: torch.from_numpy(v.copy()) for k, v in weights_mod.hash_state_dict(seed, bias, gain).items()}
+def sd_torch(weights_mod, seed, bias, gain, requires_grad=False, hdr=False):
+    sd = {k: torch.from_numpy(v.copy()) for k, v in weights_mod.hash_state_dict(seed, bias, gain, hdr=hdr).items()}
     if requires_grad:
         for v in sd.values():
             v.requires_grad_(True)
@@ -24,7 +24,7 @@ def close(a, b, rtol, atol, what=""):
     assert np.all(err <= tol), "%s: max err %.3e" % (what, err.max())
 
 
-@pytest.mark.parametrize("variant,kw", [("default", (0, 0.0, 1.0)), ("boosted", (0, 8.0, 30.0))])
+@pytest.mark.parametrize("variant,kw", [("default", (0, 0.0, 1.0)), ("boosted", (0, 8.0, 30.0)), ("hdr", (0, 2.0, 30.0, False, True))])
 def test_field(weights_mod, variant, kw):
     g = load_golden("field")
     f = TE.EagerField(sd_torch(weights_mod, *kw))
@@ -32,7 +32,8 @@ def test_field(weights_mod, variant, kw):
     with torch.no_grad():
         for lvl in ("coarse", "fine"):
             out = f.forward(lvl, x, torch.from_numpy(g["audio"]), torch.from_numpy(g["pose"]))
-            close(out, g[variant + "_raw_" + lvl], 1e-4, 1e-5 * (30 if variant == "boosted" else 1), "raw " + lvl)
+            close(out, g[variant + "_raw_" + lvl], 1e-4, 1e-5 * (1 if variant == "default" else 30), "raw " + lvl)
+            yardstick(out, g[variant + "_raw_" + lvl], g[variant + "_raw_" + lvl + "_f64"], "eager field[%s] raw %s" % (variant, lvl))
 
 
 def _rand_chunks(g, nchunks):
@@ -45,17 +46,21 @@ def _rand_chunks(g, nchunks):
 
 
 @pytest.mark.parametrize("name,nchunks", [("e2e_boosted_val", 1), ("e2e_boosted_val_2chunks", 2), ("e2e_boosted_det", 1),
-                                          ("e2e_boosted_train_noise", 1)])
+                                          ("e2e_boosted_train_noise", 1), ("e2e_hdr_val", 1), ("e2e_hdr_train_noise", 1)])
 def test_end_to_end(weights_mod, name, nchunks):
     g = load_golden(name)
-    f = TE.EagerField(sd_torch(weights_mod, int(g["weights_seed"]), float(g["weights_density_bias"]), float(g["weights_density_gain"])))
+    kw = golden_weights_kw(g)
+    f = TE.EagerField(sd_torch(weights_mod, kw["seed"], kw["density_bias"], kw["density_gain"], hdr=kw["hdr"]))
     with torch.no_grad():
         outs = TE.run_one_iter(f, torch.from_numpy(g["ro"]), torch.from_numpy(g["rd"]), float(g["near"]), float(g["far"]),
                                torch.from_numpy(g["audio"]), torch.from_numpy(g["pose"]), chunksize=int(g["chunksize"]),
                                bg=torch.from_numpy(g["bg"]), rand=_rand_chunks(g, nchunks), perturb=bool(g["perturb"]),
                                noise_std=float(g["noise_std"]))
     for nm, o in zip(["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"], outs):
-        close(o, g["out_" + nm].reshape(o.shape), 1e-4, 2e-5, name + ":" + nm)
+        if "hdr" not in name:      # SURVEY 8d's fp32 tolerance; the hdr network is held to the float64 yardstick instead
+            close(o, g["out_" + nm].reshape(o.shape), 1e-4, 2e-5, name + ":" + nm)
+        yardstick(o, g["out_" + nm], g["f64_" + nm], "eager %s:%s" % (name, nm), outlier_rays=0.0 if nm.endswith("_c") else 0.02, scale_floor=1.0,
+                  ray_shape=(int(g["H"]) * int(g["W"]),))
 
 
 def test_gradients(weights_mod):
