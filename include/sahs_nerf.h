@@ -126,7 +126,7 @@ int sahs_conditioning_backward(const float *flat_params, const float *audio, con
 /* ---- every built architecture behind one family ----
  * The reference builds its field model with getattr(models, cfg.models.mask.type)(cfg) (eval_stage_rays.py:299,
  * train_stage_rays_auto.py:116); the same path serves
- *   SAHS_MODEL_AUDIO           AudioFaceModel, config/audio/*.yml (models.py:381-528) -- the functions above;
+ *   SAHS_MODEL_AUDIO           AudioFaceModel, config/audio/<person>.yml (models.py:381-528) -- the functions above;
  *   SAHS_MODEL_NERFACE         NeRFaceModel, config/expression/person_2.yml / person_3.yml (models.py:189-378): warp + hyper
  *                              sheet on, 15-octave encodings, 1-D ambient coordinate, 4-layer trunk fed with the expression;
  *   SAHS_MODEL_NERFACE_STATIC  NeRFaceModel, config/expression/person_1.yml: use_warp False, use_ambient False.
@@ -161,6 +161,34 @@ int sahs_model_field_forward_save(int model, const void *packed, const float *fr
                                   int ray_stride, const float *z, float *raw, float *act_out, void *stream);
 int sahs_model_field_backward(int model, const float *flat_params, const float *frame, int level, long P, const float *act_in,
                               const float *d_raw, float *grad_flat, float *grad_cond, float *workspace, void *stream);
+
+/* Multiply-accumulates per sample evaluation that the field kernel of (model, precision) issues to the matrix pipe: the layer
+ * program's zero-padded tiles and k-blocks, without the per-frame constant columns (folded into biases once per frame).  The
+ * ALGORITHMIC count the roofline is quoted on is the reference's own (927,872 for AudioFaceModel). */
+long sahs_model_executed_macs_per_sample(int model, int precision);
+
+/* The 8-tuple of a ray side by side in one row of SAHS_ROW_COLUMNS floats -- the unit the multi-GPU all-gather of rendered
+ * pixels moves and the layout run_one_iter_of_nerf's chunk loop fills in place, so no per-chunk
+ * concatenation of eight tensors is needed (train_utils.py:298-319 does `torch.cat` per output). */
+#define SAHS_ROW_COLUMNS 36
+#define SAHS_ROW_RGB_C 0     /* 15: rgb3 + seg12 of the coarse pass */
+#define SAHS_ROW_DISP_C 15
+#define SAHS_ROW_ACC_C 16
+#define SAHS_ROW_RGB_F 17    /* 15 */
+#define SAHS_ROW_DISP_F 32
+#define SAHS_ROW_ACC_F 33
+#define SAHS_ROW_W_BG 34     /* weights[:, -1] of the fine pass (of the coarse pass when nf == 0) */
+#define SAHS_ROW_DEPTH_F 35
+/* sahs_composite_forward writing into such rows: the coarse pass (fine_pass 0) fills columns 0..16, the fine pass columns 17..35
+ * (incl. w_bg = weights[:, -1] and depth); weights (N,S) stays a dense array (the resampling reads it). */
+int sahs_composite_forward_rows(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
+                                const float *bg, int white_background, float *weights, float *rows, int row_ld, int fine_pass, void *stream);
+/* sahs_model_render_rays writing rows[r * row_ld + column] instead of eight dense arrays (row_ld >= 36; columns 17..33 are
+ * left untouched when nf == 0).  Workspace and draws as sahs_render_rays. */
+int sahs_model_render_rays_rows(int model, const void *packed, const float *frame, int precision, long N, const float *rays,
+                                int ray_stride, int Sc, int nf, int lindisp, int white_background, const float *bg, const float *t_rand,
+                                const float *noise_c, const float *u, const float *noise_f, float *z_c, float *z_f, float *raw,
+                                float *weights, float *rows, int row_ld, void *stream);
 
 #ifdef __cplusplus
 }

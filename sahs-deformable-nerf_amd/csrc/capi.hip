@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include "../../include/sahs_nerf.h"
+#include "sahs_common.hpp"
 #include "sahs_layout.hpp"
 
 using namespace sahs;
@@ -30,7 +31,7 @@ int sahs_stratified_depths_launch(long N, int S, const float *rays, int ray_stri
                                   hipStream_t stream);
 int sahs_composite_forward_launch(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
                                   const float *bg, int white_bkgd, float *rgb_map, float *disp, float *acc_map, float *weights,
-                                  float *depth, float *w_last, hipStream_t stream);
+                                  float *depth, float *w_last, int rgb_ld, int sc_ld, hipStream_t stream);
 int sahs_resample_launch(long N, int S, int nf, int from_z, const float *z, const float *weights, const float *u, float *z_samples,
                          float *z_out, long long *inds, hipStream_t stream);
 int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, long N, int S, float *out, hipStream_t stream);
@@ -40,6 +41,7 @@ int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, 
     long sahs_layout_packed_words_f32##sfx(void);                                                                                   \
     long sahs_layout_frame_words##sfx(void);                                                                                        \
     long sahs_layout_act_words##sfx(void);                                                                                          \
+    long sahs_layout_executed_macs##sfx(int precision);                                                                             \
     long sahs_field_backward_ws_words##sfx(long P);                                                                                 \
     int sahs_field_backward_launch##sfx(const float *flat, const float *frame, int level, long P, const float *actbuf,              \
                                         const float *d_raw, float *grad_flat, float *grad_cond, float *ws, hipStream_t stream);     \
@@ -69,14 +71,16 @@ static int hip_fail(const char *what, int e)
 #define REQUIRE(cond, name) do { if (!(cond)) return fail(1, "%s: invalid argument (%ld)", name, (long)__LINE__); } while (0)
 #define ALIGNED16(p) ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)
 
-static int num_cus()
+static int num_cus()     // of the CURRENT device (cached per device; the persistent field kernels launch one workgroup per CU)
 {
-    static int n = 0;
+    static std::atomic<int> cache[sahs_once::MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= sahs_once::MAX_DEVICES) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
     if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
+        int v = 0;
+        n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        cache[dev].store(n, std::memory_order_relaxed);
     }
     return n;
 }
@@ -157,7 +161,7 @@ int sahs_composite_forward(long N, int S, const float *raw, const float *z, cons
     REQUIRE(raw && z && rays && rgb && disp && acc && weights && depth && ray_stride >= 6, "sahs_composite_forward");
     REQUIRE(N >= 0 && S >= 1 && S <= 256 && ALIGNED16(raw), "sahs_composite_forward(shape: 1 <= S <= 256)");
     int e = sahs_composite_forward_launch(N, S, raw, z, rays, ray_stride, noise, bg, white_background, rgb, disp, acc, weights, depth,
-                                          nullptr, (hipStream_t)stream);
+                                          nullptr, 15, 1, (hipStream_t)stream);
     return e ? hip_fail("sahs_composite_forward", e) : 0;
 }
 
@@ -230,7 +234,7 @@ static int render_rays_chain(field_fn_t field, const char *who, const void *pack
                              const float *rays, int ray_stride, int Sc, int nf, int lindisp, int white_background, const float *bg,
                              const float *t_rand, const float *noise_c, const float *u, const float *noise_f, float *z_c, float *z_f,
                              float *raw, float *weights, float *rgb_c, float *disp_c, float *acc_c, float *rgb_f, float *disp_f,
-                             float *acc_f, float *w_bg, float *depth_f, void *stream)
+                             float *acc_f, float *w_bg, float *depth_f, void *stream, int rgb_ld = 15, int sc_ld = 1)
 {
     if (N == 0) return 0;   // an empty ray chunk: nothing to launch (its tensors have null data pointers)
     REQUIRE(packed && frame && rays && z_c && raw && weights && rgb_c && disp_c && acc_c && w_bg && depth_f, who);
@@ -240,9 +244,9 @@ static int render_rays_chain(field_fn_t field, const char *who, const void *pack
     if ((e = sahs_stratified_depths(N, Sc, rays, ray_stride, lindisp, t_rand, z_c, stream))) return e;
     if ((e = field(packed, frame, 0, N, Sc, rays, ray_stride, z_c, raw, nullptr, precision, stream))) return e;
     REQUIRE(Sc <= 256, who);
-    // depth_f doubles as the coarse depth scratch when there is no fine pass (the reference returns depth_fine only)
+    // the coarse depth is written only when there is no fine pass (the reference returns depth_fine only)
     e = sahs_composite_forward_launch(N, Sc, raw, z_c, rays, ray_stride, noise_c, bg, white_background, rgb_c, disp_c, acc_c, weights,
-                                      depth_f, nf == 0 ? w_bg : nullptr, st);
+                                      nf == 0 ? depth_f : nullptr, nf == 0 ? w_bg : nullptr, rgb_ld, sc_ld, st);
     if (e) return hip_fail(who, e);
     if (nf > 0) {
         const int Sf = Sc + nf;
@@ -250,7 +254,7 @@ static int render_rays_chain(field_fn_t field, const char *who, const void *pack
         if ((e = sahs_resample(N, Sc, nf, z_c, weights, u, nullptr, z_f, nullptr, stream))) return e;
         if ((e = field(packed, frame, 1, N, Sf, rays, ray_stride, z_f, raw, nullptr, precision, stream))) return e;
         e = sahs_composite_forward_launch(N, Sf, raw, z_f, rays, ray_stride, noise_f, bg, white_background, rgb_f, disp_f, acc_f,
-                                          weights, depth_f, w_bg, st);
+                                          weights, depth_f, w_bg, rgb_ld, sc_ld, st);
         if (e) return hip_fail(who, e);
     }
     return 0;
@@ -299,6 +303,11 @@ long sahs_model_packed_words(int model, int precision)
     if (model < 0 || model > 2) return -1;
     if (model == SAHS_MODEL_AUDIO) return sahs_packed_words(precision);
     return precision == SAHS_F32 ? kModels[model].packed_words_f32() : -1;
+}
+long sahs_model_executed_macs_per_sample(int model, int precision)
+{
+    if (model < 0 || model > 2 || (precision != SAHS_F32 && precision != SAHS_BF16)) return -1;
+    return model == 0 ? sahs_layout_executed_macs(precision) : (model == 1 ? sahs_layout_executed_macs_nf(precision) : sahs_layout_executed_macs_ns(precision));
 }
 long sahs_model_frame_words(int model) { return (model < 0 || model > 2) ? -1 : kModels[model].frame_words(); }
 
@@ -381,6 +390,36 @@ int sahs_model_render_rays(int model, const void *packed, const float *frame, in
     field_fn_t f = model == SAHS_MODEL_AUDIO ? sahs_field_forward : (model == SAHS_MODEL_NERFACE ? field_nf : field_ns);
     return render_rays_chain(f, "sahs_model_render_rays", packed, frame, precision, N, rays, ray_stride, Sc, nf, lindisp, white_background, bg,
                              t_rand, noise_c, u, noise_f, z_c, z_f, raw, weights, rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_bg, depth_f, stream);
+}
+
+int sahs_composite_forward_rows(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
+                                const float *bg, int white_background, float *weights, float *rows, int row_ld, int fine_pass, void *stream)
+{
+    if (N == 0) return 0;
+    REQUIRE(raw && z && rays && weights && rows && ray_stride >= 6 && row_ld >= SAHS_ROW_COLUMNS, "sahs_composite_forward_rows");
+    REQUIRE(N >= 0 && S >= 1 && S <= 256 && ALIGNED16(raw), "sahs_composite_forward_rows(shape: 1 <= S <= 256)");
+    int e = fine_pass ? sahs_composite_forward_launch(N, S, raw, z, rays, ray_stride, noise, bg, white_background, rows + SAHS_ROW_RGB_F,
+                                                      rows + SAHS_ROW_DISP_F, rows + SAHS_ROW_ACC_F, weights, rows + SAHS_ROW_DEPTH_F,
+                                                      rows + SAHS_ROW_W_BG, row_ld, row_ld, (hipStream_t)stream)
+                      : sahs_composite_forward_launch(N, S, raw, z, rays, ray_stride, noise, bg, white_background, rows + SAHS_ROW_RGB_C,
+                                                      rows + SAHS_ROW_DISP_C, rows + SAHS_ROW_ACC_C, weights, nullptr, nullptr, row_ld,
+                                                      row_ld, (hipStream_t)stream);
+    return e ? hip_fail("sahs_composite_forward_rows", e) : 0;
+}
+
+int sahs_model_render_rays_rows(int model, const void *packed, const float *frame, int precision, long N, const float *rays,
+                                int ray_stride, int Sc, int nf, int lindisp, int white_background, const float *bg, const float *t_rand,
+                                const float *noise_c, const float *u, const float *noise_f, float *z_c, float *z_f, float *raw,
+                                float *weights, float *rows, int row_ld, void *stream)
+{
+    REQUIRE_MODEL(model, "sahs_model_render_rays_rows");
+    if (N == 0) return 0;
+    REQUIRE(rows && row_ld >= SAHS_ROW_COLUMNS, "sahs_model_render_rays_rows(rows)");
+    field_fn_t f = model == SAHS_MODEL_AUDIO ? sahs_field_forward : (model == SAHS_MODEL_NERFACE ? field_nf : field_ns);
+    return render_rays_chain(f, "sahs_model_render_rays_rows", packed, frame, precision, N, rays, ray_stride, Sc, nf, lindisp, white_background,
+                             bg, t_rand, noise_c, u, noise_f, z_c, z_f, raw, weights, rows + SAHS_ROW_RGB_C, rows + SAHS_ROW_DISP_C,
+                             rows + SAHS_ROW_ACC_C, rows + SAHS_ROW_RGB_F, rows + SAHS_ROW_DISP_F, rows + SAHS_ROW_ACC_F, rows + SAHS_ROW_W_BG,
+                             rows + SAHS_ROW_DEPTH_F, stream, row_ld, row_ld);
 }
 
 }  // extern "C"

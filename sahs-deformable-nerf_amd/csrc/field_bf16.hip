@@ -566,13 +566,11 @@ extern "C" int sahs_field_forward_bf16_launch(const float *packed, const float *
     if (P <= 0) return 0;
     const long ntiles = (P + H_PTS_PER_WG - 1) / H_PTS_PER_WG;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_bf16_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static sahs_once::Flags attr_set;       // the large-LDS attribute is per device
+    hipError_t ae = sahs_once::per_device(attr_set, [&]() {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    });
+    if (ae != hipSuccess) return (int)ae;
     field_forward_bf16_kernel<<<grid, H_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg);
     return (int)hipGetLastError();
 }

@@ -507,16 +507,16 @@ extern "C" int SAHS_SYM(sahs_field_forward_f32_launch)(const float *packed, cons
     const long ntiles = (P + F32_PTS_PER_WG - 1) / F32_PTS_PER_WG;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     const size_t lds_bytes = (size_t)LDS_TOTAL_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static sahs_once::Flags attr_set;       // the large-LDS attribute is per device
+    hipError_t ae = sahs_once::per_device(attr_set, [&]() {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_f32_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_f32_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+        return e;
+    });
+    if (ae != hipSuccess) return (int)ae;
     if (actbuf != nullptr)
         field_forward_f32_kernel<true><<<grid, F32_THREADS, lds_bytes, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, actbuf);
     else

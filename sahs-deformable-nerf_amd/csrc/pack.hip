@@ -256,3 +256,15 @@ extern "C" long SAHS_SYM(sahs_layout_param_count)(void) { return kFlat.total; }
 extern "C" long SAHS_SYM(sahs_layout_packed_words_f32)(void) { return PACK_FLOATS; }
 extern "C" long SAHS_SYM(sahs_layout_frame_words)(void) { return FRAME_FLOATS; }
 extern "C" long SAHS_SYM(sahs_layout_act_words)(void) { return act::STRIDE; }
+// multiply-accumulates per sample evaluation that the field kernel ISSUES (padded tiles and k-blocks of the layer program; the
+// per-frame constant columns are folded into biases and not multiplied): the denominator of an executed-MFMA utilisation
+extern "C" long SAHS_SYM(sahs_layout_executed_macs)(int precision)
+{
+    long m = 0;
+    if (precision == 0) {
+        for (int i = 0; i < NUM_LAYERS; ++i) m += (long)kProg.layer[i].NT * 16 * kProg.layer[i].KB * 16;
+    } else {
+        for (int i = 0; i < hb::NUM_LAYERS_H; ++i) m += (long)hb::kProgH.layer[i].NT32 * 32 * hb::kProgH.layer[i].KB32 * 32;
+    }
+    return m;
+}

@@ -111,8 +111,9 @@ __global__ void __launch_bounds__(256) composite_forward_kernel(long N, int S, c
                                                                 const float *__restrict__ noise, const float *__restrict__ bg,
                                                                 int white_bkgd, float *__restrict__ rgb_map, float *__restrict__ disp,
                                                                 float *__restrict__ acc_map, float *__restrict__ weights,
-                                                                float *__restrict__ depth, float *__restrict__ w_last)
-{
+                                                                float *__restrict__ depth, float *__restrict__ w_last, int rgb_ld, int sc_ld)
+{   // rgb_ld / sc_ld: row strides of the 15-channel and of the per-ray scalar outputs (15 / 1 for separate dense arrays; 36 / 36
+    // when they are columns of one (N,36) row block = the 8-tuple of a ray side by side, the unit the multi-GPU all-gather moves)
     const int lane = threadIdx.x & 63;
     const long ray0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long stride = (long)gridDim.x * (blockDim.x >> 6);
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(256) composite_forward_kernel(long N, int S, c
             }
             const float w = valid ? alpha * myT : 0.0f;
             if (valid) weights[ray * S + s] = w;
-            if (valid && last && w_last != nullptr) w_last[ray] = w;
+            if (valid && last && w_last != nullptr) w_last[ray * sc_ld] = w;
 #pragma unroll
             for (int c = 0; c < 15; ++c) out[c] += w * col[c];
             dsum += w * zs;
@@ -191,13 +192,13 @@ __global__ void __launch_bounds__(256) composite_forward_kernel(long N, int S, c
             float o = out[0];
 #pragma unroll
             for (int c = 1; c < 15; ++c) o = (lane == c) ? out[c] : o;
-            rgb_map[ray * 15 + lane] = o;
+            rgb_map[ray * rgb_ld + lane] = o;
         }
         if (lane == 0) {
-            depth[ray] = dsum;
-            acc_map[ray] = asum;
+            if (depth != nullptr) depth[ray * sc_ld] = dsum;
+            acc_map[ray * sc_ld] = asum;
             const float dd = dsum / asum;
-            disp[ray] = (dd != dd) ? dd : 1.0f / (dd > 1e-10f ? dd : 1e-10f);
+            disp[ray * sc_ld] = (dd != dd) ? dd : 1.0f / (dd > 1e-10f ? dd : 1e-10f);
         }
     }
 }
@@ -306,12 +307,13 @@ extern "C" int sahs_stratified_depths_launch(long N, int S, const float *rays, i
 
 extern "C" int sahs_composite_forward_launch(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride,
                                              const float *noise, const float *bg, int white_bkgd, float *rgb_map, float *disp,
-                                             float *acc_map, float *weights, float *depth, float *w_last, hipStream_t stream)
+                                             float *acc_map, float *weights, float *depth, float *w_last, int rgb_ld, int sc_ld,
+                                             hipStream_t stream)
 {
     if (N <= 0) return 0;
     if (S < 1 || S > 64 * COMP_MAX_I) return -2;
     composite_forward_kernel<<<blocks_for(N, 4, 8192), 256, 0, stream>>>(N, S, raw, z, rays, ray_stride, noise, bg, white_bkgd,
-                                                                        rgb_map, disp, acc_map, weights, depth, w_last);
+                                                                        rgb_map, disp, acc_map, weights, depth, w_last, rgb_ld, sc_ld);
     return (int)hipGetLastError();
 }
 

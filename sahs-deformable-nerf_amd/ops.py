@@ -24,6 +24,8 @@ def _p(t):
 
 
 def _stream():
+    """The launch stream: torch's current stream of the CURRENT device.  Every tensor handed to an op must live on that device
+    (_req enforces it), so a kernel is never enqueued on another device's stream or launched without that device's attributes."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -34,6 +36,9 @@ def _req(t, name, dtype=torch.float32):
         raise _lib.SahsError("%s must be a GPU tensor (the HIP path has no CPU fallback)" % name)
     if t.dtype != dtype:
         raise _lib.SahsError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if t.device.index != torch.cuda.current_device():
+        raise _lib.SahsError("%s lives on %s but the current device is cuda:%d: one process drives one GPU (call "
+                             "torch.cuda.set_device first, as torchrun-style launchers do)" % (name, t.device, torch.cuda.current_device()))
     return t if t.is_contiguous() else t.contiguous()
 
 
@@ -53,6 +58,11 @@ def _fn(name, arch="audio"):
 
 def param_count(arch="audio"):
     return int(_fn("param_count", arch)[0]())
+
+
+def executed_macs_per_sample(arch="audio", precision=SAHS_F32):
+    """MACs per sample evaluation the field kernel issues to the matrix pipe (padded tiles, constants folded away)."""
+    return int(_fn("executed_macs_per_sample", arch)[0](precision))
 
 
 def pack_weights(flat, precision=SAHS_F32, arch="audio"):
@@ -194,11 +204,62 @@ def render_rays(packed, frame, rays, num_coarse, num_fine, precision=SAHS_F32, l
     return rgb_c, disp_c, acc_c, None, None, None, w_bg, depth_f
 
 
+ROW_COLUMNS = 36      # SAHS_ROW_* of include/sahs_nerf.h: rgb_c 0:15, disp_c 15, acc_c 16, rgb_f 17:32, disp_f 32, acc_f 33, w_bg 34, depth_f 35
+
+
+def composite_forward_rows(raw, z, rays, rows, fine_pass, noise=None, bg=None, white_background=False, weights=None):
+    """composite_forward writing its ray outputs into the (N, 36) row block ``rows`` (coarse pass: columns 0..16; fine pass: 17..35);
+    returns the dense (N, S) weights."""
+    raw, z, rays, noise, bg = _req(raw, "radiance_field"), _req(z, "depth_values"), _req(rays, "rays"), _req(noise, "noise"), _req(bg, "background_prior")
+    N, S = z.shape
+    if not (rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 2 and rows.shape[0] == N and rows.shape[1] >= ROW_COLUMNS and rows.stride(1) == 1):
+        raise _lib.SahsError("rows must be a GPU fp32 (N, >=36) tensor with unit column stride")
+    if weights is None or tuple(weights.shape) != (N, S):
+        weights = torch.empty(N, S, dtype=torch.float32, device=z.device)
+    check(_lib.lib().sahs_composite_forward_rows(N, S, _p(raw), _p(z), _p(rays), int(rays.shape[1]), _p(noise), _p(bg), int(bool(white_background)),
+                                                  _p(weights), _p(rows), int(rows.stride(0)), int(bool(fine_pass)), _stream()), "sahs_composite_forward_rows")
+    return weights
+
+
+def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=SAHS_F32, lindisp=False, white_background=False, bg=None,
+                     t_rand=None, noise_c=None, u=None, noise_f=None, workspace=None, arch="audio"):
+    """predict_and_render_radiance for one ray chunk, written IN PLACE into ``rows`` (N, 36): the 8-tuple of every ray side by
+    side (a row block of the frame's (R, 36) buffer, which is also what the multi-GPU all-gather moves), so a chunk loop needs
+    no per-chunk concatenation.  Returns ``rows``."""
+    packed, frame, rays = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays")
+    bg, t_rand, noise_c, u, noise_f = (_req(t, n) for t, n in ((bg, "background_prior"), (t_rand, "t_rand"), (noise_c, "noise_c"),
+                                                               (u, "u"), (noise_f, "noise_f")))
+    N = rays.shape[0]
+    if not (isinstance(rows, torch.Tensor) and rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 2 and rows.shape[0] == N
+            and rows.shape[1] >= ROW_COLUMNS and rows.stride(1) == 1):
+        raise _lib.SahsError("rows must be a GPU fp32 (N, >=36) tensor with unit column stride")
+    dev = rays.device
+    Sf = num_coarse + num_fine
+    ws = workspace if workspace is not None else {}
+
+    def buf(name, *shape):
+        t = ws.get(name)
+        if t is None or tuple(t.shape) != shape or t.device != dev:
+            t = torch.empty(*shape, dtype=torch.float32, device=dev)
+            ws[name] = t
+        return t
+
+    z_c, z_f = buf("z_c", N, num_coarse), buf("z_f", N, Sf)
+    raw, weights = buf("raw", N, Sf, 16), buf("weights", N, Sf)
+    f, name = _fn("render_rays_rows", arch)
+    check(f(_p(packed), _p(frame), precision, N, _p(rays), int(rays.shape[1]), int(num_coarse), int(num_fine),
+            int(bool(lindisp)), int(bool(white_background)), _p(bg), _p(t_rand), _p(noise_c), _p(u), _p(noise_f),
+            _p(z_c), _p(z_f), _p(raw), _p(weights), _p(rows), int(rows.stride(0)), _stream()), name)
+    return rows
+
+
 # ---------------------------------------------------------------------------------------------------------
 # training path
 # ---------------------------------------------------------------------------------------------------------
 def field_forward_save(packed, frame, level, rays, z, arch="audio"):
-    """fp32 field forward that also returns the saved activations (N*S, act_words) for field_backward."""
+    """fp32 field forward that also returns the saved activations for field_backward: ONE buffer of P * act_words floats laid out
+    as a dense [P x width] plane per layer (plane c starts at float c * P; sahs_layout.hpp, namespace act) -- NOT one row per
+    sample, so it can only be handed to field_backward whole, with the same P."""
     packed, frame, rays, z = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays"), _req(z, "z")
     N, S = z.shape
     raw = torch.empty(N, S, 16, dtype=torch.float32, device=z.device)
@@ -256,24 +317,36 @@ class FieldFn(torch.autograd.Function):
     canonical flat buffer) and the driving input; the sample points themselves get no gradient (no caller of the reference's asks
     for one).  fp32.  Points are passed as zero-length rays, as in the no-grad path of the seam."""
 
+    BLOCK = 2_000_000     # samples per saved-activation block (sahs_field_backward takes at most 4e6 per call; 19 KB each)
+
     @staticmethod
     def forward(ctx, flat, driving, pose, rays, z, packed, level, arch):
         frame = fold_conditioning(flat.detach(), driving.detach(), pose, arch=arch)
-        raw, act = field_forward_save(packed, frame, level, rays, z, arch)
-        ctx.save_for_backward(flat.detach(), driving.detach(), frame, act)
-        ctx.cfg = (level, arch)
-        return raw
+        # the saved activations are plane-per-layer over the P of ONE forward call, so a large batch is cut into blocks HERE and
+        # each block keeps its own buffer (a row slice of one big buffer would hand the backward the wrong planes)
+        N = z.shape[0]
+        rows = max(1, FieldFn.BLOCK // max(1, z.shape[1]))
+        raws, acts = [], []
+        for s in range(0, N, rows):
+            r, a = field_forward_save(packed, frame, level, rays[s:s + rows].contiguous(), z[s:s + rows].contiguous(), arch)
+            raws.append(r)
+            acts.append(a)
+        ctx.save_for_backward(flat.detach(), driving.detach(), frame, *acts)
+        ctx.cfg = (level, arch, rows * z.shape[1])
+        return raws[0] if len(raws) == 1 else torch.cat(raws, dim=0)
 
     @staticmethod
     def backward(ctx, g_raw):
-        flat, driving, frame, act = ctx.saved_tensors
-        level, arch = ctx.cfg
+        flat, driving, frame = ctx.saved_tensors[:3]
+        acts = ctx.saved_tensors[3:]
+        level, arch, block = ctx.cfg
         grad_flat = torch.zeros_like(flat)
         grad_cond = torch.zeros(128, dtype=torch.float32, device=flat.device)
-        P = act.shape[0]
-        g = g_raw.contiguous().float().view(P, 16)
-        for s in range(0, P, 2_000_000):          # sahs_field_backward takes at most 4e6 samples per call
-            field_backward(flat, frame, level, act[s:s + 2_000_000], g[s:s + 2_000_000], grad_flat, grad_cond, arch)
+        g = g_raw.contiguous().float().view(-1, 16)
+        if sum(a.shape[0] for a in acts) != g.shape[0]:
+            raise _lib.SahsError("FieldFn.backward: %d gradient rows for %d saved samples" % (g.shape[0], sum(a.shape[0] for a in acts)))
+        for i, act in enumerate(acts):
+            field_backward(flat, frame, level, act, g[i * block: i * block + act.shape[0]], grad_flat, grad_cond, arch)
         if arch == "audio":
             grad_drv = torch.zeros_like(driving)
             check(_lib.lib().sahs_conditioning_backward(_p(flat), _p(driving), _p(grad_cond), _p(grad_flat), _p(grad_drv), _stream()),
@@ -338,8 +411,12 @@ class RenderRaysFn(torch.autograd.Function):
             sl = slice(s, e)
             rb = rays[sl].contiguous()
             bgb = None if bg is None else bg[sl].contiguous()
-            for level, z, noise, grads in ((1, z_f, noise_f, (g_rgb_f, g_disp_f, g_acc_f, g_depth_f, g_wbg)),
-                                           (0, z_c, noise_c, (g_rgb_c, g_disp_c, g_acc_c, None, None))):
+            if nf > 0:
+                passes = ((1, z_f, noise_f, (g_rgb_f, g_disp_f, g_acc_f, g_depth_f, g_wbg)),
+                          (0, z_c, noise_c, (g_rgb_c, g_disp_c, g_acc_c, None, None)))
+            else:     # coarse only (train_utils.py:148-149): depth and weights[:, -1] of the 8-tuple are the COARSE pass's
+                passes = ((0, z_c, noise_c, (g_rgb_c, g_disp_c, g_acc_c, g_depth_f, g_wbg)),)
+            for level, z, noise, grads in passes:
                 if all(g is None for g in grads):
                     continue
                 zb = z[sl].contiguous()

@@ -32,6 +32,11 @@ def partition_invariant_rng(seed, ray_offset=0):
         _RAY_RNG = prev
 
 
+def unpack_rows(rows):
+    """(n, 36) row block (ops.render_rays_rows) -> the reference's 8-tuple as column views (flat shapes)."""
+    return [rows[:, 0:15], rows[:, 15], rows[:, 16], rows[:, 17:32], rows[:, 32], rows[:, 33], rows[:, 34], rows[:, 35]]
+
+
 def run_network(level, network_fn, pts, ray_batch, chunksize, use_viewdirs, driving=None, pose=None, pose_c=None,
                 latent_code=None, spatial_embeddings=None):
     """train_utils.py:9-50: evaluate the field at explicit points pts (N,S,3) -> (N,S,16)."""
@@ -46,9 +51,10 @@ def run_network(level, network_fn, pts, ray_batch, chunksize, use_viewdirs, driv
 
 def predict_and_render_radiance(ray_batch, model, options, mode="train", driving=None, pose=None, pose_c=None,
                                 background_prior=None, latent_code=None, spatial_embeddings=None, ray_dirs_fake=None,
-                                _frame=None, _workspace=None, _ray0=0):
+                                _frame=None, _workspace=None, _ray0=0, _rows=None):
     """train_utils.py:72-206 for one ray chunk -> the 8-tuple
-    (rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine, weights_fine[:, -1], depth_fine)."""
+    (rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine, weights_fine[:, -1], depth_fine).
+    _rows (driver-internal): an (N, 36) row block to fill in place instead (ops.render_rays_rows); returns None then."""
     if latent_code is not None:
         raise NotImplementedError("latent codes are not used by the shipped audio configs")
     opt = getattr(options.nerf, mode)
@@ -83,6 +89,11 @@ def predict_and_render_radiance(ray_batch, model, options, mode="train", driving
         flat = model.flat_params(differentiable=True)
         return ops.RenderRaysFn.apply(flat, driving.to(torch.float32), pose.to(torch.float32), rays.detach(), bg, t_rand, noise_c, u, noise_f,
                                       packed, nc, nf, bool(opt.lindisp), bool(opt.white_background), arch)
+    if _rows is not None:
+        ops.render_rays_rows(packed, frame, rays, nc, nf, _rows, precision=model.precision, lindisp=bool(opt.lindisp),
+                             white_background=bool(opt.white_background), bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f,
+                             workspace=_workspace, arch=arch)
+        return None
     return ops.render_rays(packed, frame, rays, nc, nf, precision=model.precision, lindisp=bool(opt.lindisp),
                            white_background=bool(opt.white_background), bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f,
                            workspace=_workspace, arch=arch)
@@ -109,12 +120,26 @@ def run_one_iter_of_nerf(height, width, focal_length, model, ray_origins, ray_di
     # once per call (the reference recomputes it per point-chunk); the differentiable op folds the conditioning itself
     frame = None if needs_grad else model.frame(driving, pose)
     workspace = {}
-    pred = [predict_and_render_radiance(b, model, options, mode, driving=driving, pose=pose, pose_c=pose_c,
-                                        background_prior=bgs[i] if bgs is not None else None, latent_code=latent_code,
-                                        _frame=frame, _workspace=workspace if len(batches) == 1 or b.shape[0] == chunk else None,
-                                        _ray0=i * chunk)
-            for i, b in enumerate(batches)]
-    images = [torch.cat(im, dim=0) if im[0] is not None else None for im in zip(*pred)]
+    if needs_grad:
+        pred = [predict_and_render_radiance(b, model, options, mode, driving=driving, pose=pose, pose_c=pose_c,
+                                            background_prior=bgs[i] if bgs is not None else None, latent_code=latent_code,
+                                            _frame=frame, _workspace=workspace if len(batches) == 1 or b.shape[0] == chunk else None,
+                                            _ray0=i * chunk)
+                for i, b in enumerate(batches)]
+        images = [torch.cat(im, dim=0) if im[0] is not None else None for im in zip(*pred)]
+    else:
+        # every chunk writes its rays' 8-tuples straight into its row block of ONE (R, 36) buffer (the reference concatenates
+        # eight lists of per-chunk tensors, train_utils.py:298-301)
+        rows = torch.empty(rays.shape[0], ops.ROW_COLUMNS, dtype=torch.float32, device=rays.device)
+        for i, b in enumerate(batches):
+            s0 = i * chunk
+            predict_and_render_radiance(b, model, options, mode, driving=driving, pose=pose, pose_c=pose_c,
+                                        background_prior=bgs[i] if bgs is not None else None, latent_code=latent_code, _frame=frame,
+                                        _workspace=workspace if len(batches) == 1 or b.shape[0] == chunk else None, _ray0=s0,
+                                        _rows=rows[s0:s0 + b.shape[0]])
+        images = [c.contiguous() for c in unpack_rows(rows)]
+        if int(getattr(options.nerf, mode).num_fine) == 0:
+            images[3] = images[4] = images[5] = None
     if mode == "validation":
         shape3, shape2 = tuple(ray_directions.shape), tuple(ray_directions.shape[:-1])
         shapes = [shape3, shape2, shape2]
@@ -124,7 +149,7 @@ def run_one_iter_of_nerf(height, width, focal_length, model, ray_origins, ray_di
             shapes[0] = shape2 + (15,)
             if len(shapes) > 3:
                 shapes[3] = shape2 + (15,)
-        images = [im.view(s) if im is not None else None for im, s in zip(images, shapes)]
+        images = [im.reshape(s) if im is not None else None for im, s in zip(images, shapes)]
         if hasattr(options.models, "fine"):
             return tuple(images)
         return tuple(images + [None, None, None])

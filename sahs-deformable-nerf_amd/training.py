@@ -27,10 +27,22 @@ def sample_training_rays(probs, num_rays, generator=None):
     return torch.multinomial(probs, num_rays, replacement=False, generator=generator)
 
 
+def sample_prob_weights(device=None, dtype=torch.float32):
+    """train_stage_rays_auto.py:268-269: the per-class weights both loss modules are built with -- ones(12) with the mouth
+    classes 7 and 8 doubled.  They do not enter the loss value, only the weighted per-class losses that become the next
+    step's sampling distribution (:466-468)."""
+    w = torch.ones(12, device=device, dtype=dtype)
+    w[7:9] = 2
+    return w
+
+
 def stage1_loss(rgb_coarse, rgb_fine, target_rgb, mask, mse_loss=None, ce_loss=None):
-    """-> (loss, new_sample_prob, fine_mse).  rgb_*: (R,15) = [rgb3 | seg12]; target_rgb (R,3); mask (R,12) one-hot."""
-    mse_loss = mse_loss or MaskMSELoss()
-    ce_loss = ce_loss or MaskCrossEntropyLoss()
+    """train_stage_rays_auto.py:455-468 -> (loss, new_sample_prob, fine_mse).  rgb_*: (R,15) = [rgb3 | seg12]; target_rgb (R,3);
+    mask (R,12) one-hot.  The loss modules default to the script's own (:270-271: weights ones(12), [7:9] = 2)."""
+    if mse_loss is None:
+        mse_loss = MaskMSELoss(sample_prob_weights(mask.device, rgb_coarse.dtype))
+    if ce_loss is None:
+        ce_loss = MaskCrossEntropyLoss(sample_prob_weights(mask.device, rgb_coarse.dtype))
     total, weighted = 0.0, []
     fine_mse = None
     for rgb in (rgb_coarse, rgb_fine):

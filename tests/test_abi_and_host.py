@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, pkg
+from conftest import load_golden, REPO, pkg
 
 
 def header_functions():
@@ -117,6 +117,44 @@ def test_masked_losses_match_their_definition():
     ce = -(mask * torch.log(p + 1e-10)).sum(-1)
     assert torch.allclose(glob, ce.mean()) and torch.allclose(per[3], (ce * mask[:, 3]).sum() / max(1.0, float(mask[:, 3].sum())))
     assert abs(H.mse2psnr(0.01) - 20.0) < 1e-12 and H.mse2psnr(0) == 50.0
+
+
+def test_masked_losses_vs_reference_classes():
+    """a16: MaskMSELoss / MaskCrossEntropyLoss against the outputs of the reference's own classes (nerf_helpers.py:14-62,
+    tests/golden/losses.npz: weights ones(12) with [7:9] = 2 as train_stage_rays_auto.py:268-271 builds them, class 5 empty,
+    class 11 a single pixel, one pixel whose predicted distribution is all zeros)."""
+    H, Tr = pkg("nerf_helpers"), pkg("training")
+    g = load_golden("losses")
+    t = lambda k: torch.from_numpy(g[k])
+    w = Tr.sample_prob_weights()
+    assert np.array_equal(w.numpy(), g["weights"])
+    assert int(g["mask"][:, 5].sum()) == 0 and int(g["mask"][:, 11].sum()) == 1
+    for cls, args, pre in ((H.MaskMSELoss, (t("mask"), t("pred_rgb"), t("target_rgb")), "mse"),
+                           (H.MaskCrossEntropyLoss, (t("mask"), t("pred_seg"), t("mask")), "ce")):
+        glob, per, wper = cls(w.clone())(*args)
+        assert np.allclose(glob.numpy(), g[pre], rtol=1e-6, atol=0), (pre, float(glob), float(g[pre]))
+        assert np.allclose(per.numpy(), g[pre + "_masked"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(wper.numpy(), g[pre + "_weighted"], rtol=1e-6, atol=1e-9)
+        assert float(per[5]) == 0.0
+    assert np.allclose(H.MaskMSELoss()(t("mask"), t("pred_rgb"), t("target_rgb"))[2].numpy(), g["mse_weighted_noweights"], rtol=1e-6)
+
+
+def test_loss_recipe_and_sampling_feedback_vs_reference():
+    """f-2: stage1_loss (train_stage_rays_auto.py:455-468: l2 + 0.02 CE + 0.005 mouth per pass; sample_prob = normalised sum of the
+    four weighted per-class losses) over the REFERENCE's own renders of tests/golden/train_step_hdr.npz reproduces the loss and the
+    next step's sampling distribution the reference computed."""
+    Tr = pkg("training")
+    g = load_golden("train_step_hdr")
+    t = lambda k: torch.from_numpy(g[k])
+    loss, prob, fine_mse = Tr.stage1_loss(t("out_rgb_c"), t("out_rgb_f"), t("target"), t("mask"))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    assert np.allclose(prob.numpy(), g["sample_prob"], rtol=2e-6, atol=1e-9)
+    assert abs(float(fine_mse) - float(g["parts"][2])) <= 1e-6 * float(g["parts"][2])
+    assert abs(float(prob.sum()) - 1.0) < 1e-6 and float(prob[5]) == 0.0     # class 5 never sampled: no feedback mass
+    # float64 inputs: the float64 run of the reference
+    loss64, prob64, _ = Tr.stage1_loss(t("f64_rgb_c"), t("f64_rgb_f"), t("target").double(), t("mask").double())
+    assert abs(float(loss64) - float(g["loss_f64"])) <= 1e-12 * abs(float(g["loss_f64"]))
+    assert np.allclose(prob64.numpy(), g["sample_prob_f64"], rtol=1e-12)
 
 
 def test_training_host_logic():

@@ -28,10 +28,17 @@ def psnr(a, b):
     return 99.0 if mse == 0 else -10.0 * np.log10(mse)
 
 
-def test_bf16_field_vs_oracle(flat_weights):
+# per-variant bounds on the bf16 field error against the fp32 oracle: ~3x the observed values (gpurun_out/bf16_field_stats.json,
+# printed by the test): dx max, rgb/seg logit rms, density logit rms relative to its mean magnitude
+BF16_BOUNDS = {"boosted": dict(dx_max=2e-3, col_rms=3e-4, sig_rel=5e-3), "hdr": dict(dx_max=2e-3, col_rms=1.5e-1, sig_rel=6e-2)}
+
+
+@pytest.mark.parametrize("variant", ["boosted", "hdr"])
+def test_bf16_field_vs_oracle(flat_weights, variant):
+    from conftest import VARIANT_KW
     ops, lib = pkg("ops"), pkg("_lib")
     g = load_golden("cond")
-    fw = flat_weights(density_bias=8.0, density_gain=30.0)
+    fw = flat_weights(**VARIANT_KW[variant])
     flat = T(fw)
     packed = ops.pack_weights(flat, lib.SAHS_BF16)
     frame = ops.fold_conditioning(flat, T(g["audio"]), T(g["pose"]))
@@ -56,12 +63,16 @@ def test_bf16_field_vs_oracle(flat_weights):
                             col_max=float(e_col.max()), col_rms=float(np.sqrt((e_col ** 2).mean())), sig_max=float(e_sig.max()),
                             sig_rms=float(np.sqrt((e_sig ** 2).mean())), sig_scale=float(np.abs(ref[:, 15]).mean()),
                             grid_max=float(np.abs(grid.view(-1, 32).cpu().numpy() - rgrid).max()))
+        stats[level]["col_scale"] = float(np.sqrt((ref[:, :15] ** 2).mean()))
         assert np.isfinite(raw).all()
-        assert stats[level]["dx_max"] < 2e-2 and stats[level]["col_rms"] < 2e-2, stats[level]
-        assert stats[level]["sig_rms"] < 0.05 * stats[level]["sig_scale"] + 0.5, stats[level]
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-    json.dump(stats, open(os.path.join(REPO, "gpurun_out", "bf16_field_stats.json"), "w"), indent=1)
-    print(json.dumps(stats))
+    json.dump(stats, open(os.path.join(REPO, "gpurun_out", "bf16_field_stats_%s.json" % variant), "w"), indent=1)
+    print(variant, json.dumps(stats))
+    b = BF16_BOUNDS[variant]
+    for level in (0, 1):
+        st = stats[level]
+        assert st["dx_max"] < b["dx_max"] and st["col_rms"] < b["col_rms"], (variant, st)
+        assert st["sig_rms"] < b["sig_rel"] * st["sig_scale"], (variant, st)
 
 
 def test_bf16_full_frame_psnr(weights_mod):
@@ -69,23 +80,24 @@ def test_bf16_full_frame_psnr(weights_mod):
     cfg = sahs.default_config()
     H = W = 512
     R = H * W
-    fw = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 8.0, 30.0))
-    fw_t = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(1, 8.0, 30.0))      # pseudo-target: a different network
+    # the HIGH-DYNAMIC-RANGE network (O(1) activations, logits of sigma ~2.5, semi-transparent volume): on default-scale weights
+    # every logit is < 0.1 and a bf16-vs-fp32 PSNR of 100 dB says nothing.  Pseudo-target: the SAME network
+    # rendered in fp32 under other random draws.
+    fw = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 2.0, 30.0, hdr=True))
     m32 = sahs.AudioFaceModel(cfg, precision="fp32").to(dev()).load_flat(fw)
     m16 = sahs.AudioFaceModel(cfg, precision="bf16").to(dev()).load_flat(fw)
-    mt = sahs.AudioFaceModel(cfg, precision="fp32").to(dev()).load_flat(fw_t)
     rng = np.random.default_rng(42)
     audio, pose = T(rng.standard_normal((16, 29)).astype(np.float32)), T(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32))
     intr = np.array([1200.0, 1200.0, 0.5, 0.5], np.float32)
     bg = torch.cat([torch.rand(R, 3, device=dev()), torch.ones(R, 1, device=dev()), torch.zeros(R, 11, device=dev())], 1)
     ro, rd = sahs.get_ray_bundle(H, W, intr, pose)
 
-    def render(model):
-        torch.manual_seed(7)   # same random draws for every model
+    def render(model, seed=7):
+        torch.manual_seed(seed)   # same random draws for the two kernels
         with torch.no_grad():
             return sahs.run_one_iter_of_nerf(H, W, intr, model, ro, rd, cfg, mode="validation", driving=audio, pose=pose, background_prior=bg)
 
-    o32, o16, ot = render(m32), render(m16), render(mt)
+    o32, o16, ot = render(m32), render(m16), render(m32, seed=8)
     rgb32, rgb16, rgbt = o32[3][..., :3], o16[3][..., :3], ot[3][..., :3]
     res = dict(psnr_bf16_vs_fp32=psnr(rgb16, rgb32), psnr_fp32_vs_target=psnr(rgb32, rgbt), psnr_bf16_vs_target=psnr(rgb16, rgbt),
                max_abs_rgb=float((rgb16 - rgb32).abs().max()), seg_max_abs=float((o16[3][..., 3:] - o32[3][..., 3:]).abs().max()),
@@ -93,5 +105,8 @@ def test_bf16_full_frame_psnr(weights_mod):
     res["delta_psnr"] = abs(res["psnr_bf16_vs_target"] - res["psnr_fp32_vs_target"])
     json.dump(res, open(os.path.join(REPO, "gpurun_out", "bf16_psnr.json"), "w"), indent=1)
     print(json.dumps(res))
+    res["w_bg_mean"] = float(o32[6].mean())
+    json.dump(res, open(os.path.join(REPO, "gpurun_out", "bf16_psnr.json"), "w"), indent=1)
+    assert 0.02 < res["w_bg_mean"] < 0.9, "the volume must be semi-transparent for the protocol to mean anything"
     assert res["delta_psnr"] <= 0.05, res      # north_star: PSNR within 0.05 dB of the reference
     assert res["psnr_bf16_vs_fp32"] > 35.0, res
