@@ -15,6 +15,12 @@ SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "field_f32.hip", "field_bf1
 MODEL_SOURCES = ["pack.hip", "field_f32.hip", "field_bwd.hip"]
 # field kernels: no sNaN-quieting v_max before every fmaxf (activations); NaNs still propagate through the MFMAs
 FIELD_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
+# Kernels whose correctness or speed rests on an exact count of the wave's vector-memory instructions (a counted s_waitcnt vmcnt
+# behind LDS-DMA) must not get scratch: a spill reload is a VMEM instruction the count does not know about.  The build reads the
+# compiler's own resource remarks and FAILS if one of them has a non-zero scratch size (substring of the mangled name -> max bytes).
+# The headline forward kernel (audio model, no activation saving) is held to zero scratch as a performance guard (a reload's wait
+# also drains its in-flight weight prefetch); its activation-saving and NeRFace builds do spill a little (build/resource_usage.txt).
+NO_SCRATCH = {"gemm_dma_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb0E": 0}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-math-errno", "-Wall", "-Wno-unused-function"]
 
 
@@ -24,6 +30,25 @@ def _stale():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "sahs_nerf.h")]
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _resource_usage(remarks):
+    """Parse clang's -Rpass-analysis=kernel-resource-usage remarks -> {mangled kernel name: dict}."""
+    out, cur = {}, None
+    keys = {"TotalSGPRs": "sgpr", "VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occ",
+            "LDS Size [bytes/block]": "lds"}
+    for line in remarks.splitlines():
+        if "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].replace("[-Rpass-analysis=kernel-resource-usage]", "").strip()
+        if body.startswith("Function Name:"):
+            cur = body.split(":", 1)[1].strip()
+            out[cur] = dict(sgpr=0, vgpr=0, agpr=0, scratch=0, occ=0, lds=0)
+        elif cur is not None and ":" in body:
+            k, v = body.rsplit(":", 1)
+            if k.strip() in keys:
+                out[cur][keys[k.strip()]] = int(v)
+    return out
 
 
 def build(force=False, verbose=False, defines=(), out=None):
@@ -41,13 +66,28 @@ def build(force=False, verbose=False, defines=(), out=None):
         obj = os.path.join(HERE, "build", (os.path.basename(out) + "." if out else "") + src.replace(".hip", ".m%d.o" % model if model else ".o"))
         objs.append(obj)
         extra = (FIELD_FLAGS if src.startswith("field_") else []) + (["-DSAHS_MODEL=%d" % model] if model else [])
-        cmd = [hipcc] + FLAGS + extra + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + extra + ["-D" + d for d in defines] + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd)))
+        procs.append((src, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+    usage = {}
     for src, p in procs:
-        if p.wait() != 0:
+        err = p.communicate()[1]
+        diag = [l for l in err.splitlines() if "[-Rpass-analysis=kernel-resource-usage]" not in l and not l.lstrip().startswith(("|", "^")) and
+                not (l[:1] == " " and l.strip()[:1].isdigit() and "|" in l)]
+        if diag and (verbose or p.returncode != 0):
+            print("\n".join(diag), file=sys.stderr)
+        if p.returncode != 0:
             raise RuntimeError("hipcc failed on " + src)
+        usage.update(_resource_usage(err))
+    bad = ["%s: %d bytes/lane of scratch" % (k, v["scratch"]) for k, v in usage.items() for name, cap in NO_SCRATCH.items()
+           if name in k and v["scratch"] > cap]
+    if bad and not defines:      # ablation builds (defines) are diagnostics and may spill
+        raise RuntimeError("kernels that rely on a counted vmcnt must not use scratch:\n  " + "\n  ".join(bad))
+    with open(os.path.join(HERE, "build", "resource_usage.txt"), "w") as f:
+        for k in sorted(usage):
+            f.write("%-110s vgpr %3d agpr %3d sgpr %3d scratch %4d lds %6d occupancy %d\n" % (
+                k, usage[k]["vgpr"], usage[k]["agpr"], usage[k]["sgpr"], usage[k]["scratch"], usage[k]["lds"], usage[k]["occ"]))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
     return LIB

@@ -276,7 +276,11 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, cons
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     float cs = 0.0f;
 
-    issue(0);
+    // vmcnt accounting of the K loop (audited on the ISA, tools/check_isa.py; the build fails if this kernel gets scratch): the only
+    // vector-memory instructions a wave executes between kernel entry and the end of the loop are its 4 LDS-DMA instructions per
+    // issue(); they complete in issue order, so "vmcnt(4)" at step t means step t has landed while step t+1 may still be in flight --
+    // and any further VMEM instruction the compiler might ever add there could only make that wait stricter, never weaker.
+    if (T > 0) issue(0);      // an empty K slab (k_lo >= K) issues nothing and falls through to a zero contribution
     if (T > 1) issue(1);
     for (int t = 0; t < T; ++t) {
         if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
