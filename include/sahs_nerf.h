@@ -27,6 +27,7 @@ extern "C" {
 #define SAHS_ABI_VERSION 1
 #define SAHS_F32 0
 #define SAHS_BF16 1
+#define SAHS_BF16_2W 2   /* the same arithmetic and packed stream as SAHS_BF16 through the earlier 2-waves-per-SIMD kernel (A/B reference) */
 
 int sahs_abi_version(void);
 const char *sahs_last_error(void);

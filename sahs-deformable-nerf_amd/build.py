@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsahs_nerf.so")
-SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "field_f32.hip", "field_bf16.hip", "field_bwd.hip", "train_bwd.hip"]
+SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "field_f32.hip", "field_bf16.hip", "field_bf16w.hip", "field_bwd.hip", "train_bwd.hip"]
 # sources built again for the NeRFaceModel architectures (csrc/sahs_model.hpp: -DSAHS_MODEL=1 / 2, symbols suffixed _nf / _ns)
 MODEL_SOURCES = ["pack.hip", "field_f32.hip", "field_bwd.hip"]
 # field kernels: no sNaN-quieting v_max before every fmaxf (activations); NaNs still propagate through the MFMAs
@@ -21,7 +21,11 @@ FIELD_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
 # The headline forward kernel (audio model, no activation saving) is held to zero scratch as a performance guard (a reload's wait
 # also drains its in-flight weight prefetch); its activation-saving and NeRFace builds do spill a little (build/resource_usage.txt).
 NO_SCRATCH = {"gemm_dma_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb0E": 0}
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-math-errno", "-Wall", "-Wno-unused-function"]
+# field_bf16w.hip (one wave per SIMD, 512 registers): MFMA accumulators must live in ARCH VGPRs.  Left to its heuristics the compiler
+# puts them in AGPRs, and every accumulator value the activation code touches then costs a v_accvgpr_read -- which, unlike plain VALU
+# work, does NOT hide under the wave's own MFMAs (tools/micro/mfma_valu_overlap.hip: 2 reads per MFMA = 55 cycles per MFMA instead of 36).
+PER_FILE_FLAGS = {"field_bf16w.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-fno-math-errno", "-Wall", "-Wno-unused-function"]
 
 
 def _stale():
@@ -65,7 +69,7 @@ def build(force=False, verbose=False, defines=(), out=None):
     for src, model in [(s, 0) for s in SOURCES] + [(s, m) for m in (1, 2) for s in MODEL_SOURCES]:
         obj = os.path.join(HERE, "build", (os.path.basename(out) + "." if out else "") + src.replace(".hip", ".m%d.o" % model if model else ".o"))
         objs.append(obj)
-        extra = (FIELD_FLAGS if src.startswith("field_") else []) + (["-DSAHS_MODEL=%d" % model] if model else [])
+        extra = (FIELD_FLAGS if src.startswith("field_") else []) + (["-DSAHS_MODEL=%d" % model] if model else []) + ([] if "SAHS_NOTHING" in defines else PER_FILE_FLAGS.get(src, []))
         cmd = [hipcc] + FLAGS + extra + ["-D" + d for d in defines] + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

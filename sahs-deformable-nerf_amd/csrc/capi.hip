@@ -20,6 +20,8 @@ int sahs_composite_backward_launch(long N, int S, const float *raw, const float 
                                    const float *d_depth, const float *d_wlast, const float *d_weights, float *d_raw, hipStream_t stream);
 int sahs_conditioning_backward_launch(const float *flat, const float *audio, const float *grad_cond, float *grad_flat, float *grad_audio,
                                       hipStream_t stream);
+int sahs_field_forward_bf16w_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
+                                    const float *zvals, float *raw, float *dbg, int num_cu, hipStream_t stream);
 int sahs_field_forward_bf16_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                    const float *zvals, float *raw, float *dbg, int num_cu, hipStream_t stream);
 int sahs_fold_conditioning_launch(const float *flat, const float *audio, const float *pose, int pose_ld, float *frame, hipStream_t stream);
@@ -92,7 +94,7 @@ const char *sahs_last_error(void) { return g_err; }
 long sahs_param_count(void) { return kFlat.total; }
 long sahs_packed_words(int precision)
 {
-    return precision == SAHS_F32 ? PACK_FLOATS : (precision == SAHS_BF16 ? hb::PACKH_WORDS : -1);
+    return precision == SAHS_F32 ? PACK_FLOATS : ((precision == SAHS_BF16 || precision == SAHS_BF16_2W) ? hb::PACKH_WORDS : -1);
 }
 long sahs_frame_words(void) { return FRAME_FLOATS; }
 
@@ -100,7 +102,7 @@ int sahs_pack_weights(const float *flat_params, void *packed, int precision, voi
 {
     REQUIRE(flat_params && packed, "sahs_pack_weights");
     REQUIRE(ALIGNED16(packed), "sahs_pack_weights(packed alignment)");
-    if (precision != SAHS_F32 && precision != SAHS_BF16) return fail(2, "sahs_pack_weights: unknown precision %s%ld", "", precision);
+    if (precision != SAHS_F32 && precision != SAHS_BF16 && precision != SAHS_BF16_2W) return fail(2, "sahs_pack_weights: unknown precision %s%ld", "", precision);
     int e = precision == SAHS_F32 ? sahs_pack_weights_f32_launch(flat_params, (float *)packed, (hipStream_t)stream)
                                   : sahs_pack_weights_bf16_launch(flat_params, (float *)packed, (hipStream_t)stream);
     return e ? hip_fail("sahs_pack_weights", e) : 0;
@@ -144,12 +146,15 @@ int sahs_field_forward(const void *packed, const float *frame, int level, long N
     REQUIRE(packed && frame && rays && z && raw, "sahs_field_forward");
     REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_field_forward(shape)");
     REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_field_forward(alignment)");
-    if (precision != SAHS_F32 && precision != SAHS_BF16) return fail(2, "sahs_field_forward: unknown precision %s%ld", "", precision);
+    if (precision != SAHS_F32 && precision != SAHS_BF16 && precision != SAHS_BF16_2W) return fail(2, "sahs_field_forward: unknown precision %s%ld", "", precision);
     int e = precision == SAHS_F32
                 ? sahs_field_forward_f32_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, nullptr, num_cus(),
                                                 (hipStream_t)stream)
-                : sahs_field_forward_bf16_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(),
-                                                 (hipStream_t)stream);
+                : (precision == SAHS_BF16
+                       ? sahs_field_forward_bf16w_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(),
+                                                         (hipStream_t)stream)
+                       : sahs_field_forward_bf16_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(),
+                                                        (hipStream_t)stream));
     return e ? hip_fail("sahs_field_forward", e) : 0;
 }
 

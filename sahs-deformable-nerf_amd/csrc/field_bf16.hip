@@ -12,6 +12,7 @@
 //  * skip layers are not split here: a tile's accumulator runs over [hidden | re-injected encoding].
 // Roofline: MFMA-bound against the dense bf16 peak (~2.5 PFLOP/s).
 #include <hip/hip_runtime.h>
+#include <utility>
 #include "sahs_common.hpp"
 #include "sahs_layout.hpp"
 
@@ -22,7 +23,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct Blk { bf16x8 s[2]; };   // 32 features of this lane's sample, as the two k-step B fragments
 
-constexpr int H_THREADS = 512;
+#ifndef SAHS_BF16_WAVES
+#define SAHS_BF16_WAVES 8
+#endif
+#ifndef SAHS_BF16_APF
+#define SAHS_BF16_APF 0       // 0: A-fragment reads left to the compiler; N > 0: inline-asm ds_read_b128, N fragments ahead, counted lgkmcnt
+#endif
+constexpr int H_THREADS = 64 * SAHS_BF16_WAVES;
 constexpr int H_PTS_PER_WAVE = 32;
 constexpr int H_PTS_PER_WG = (H_THREADS / WAVE) * H_PTS_PER_WAVE;   // 256
 constexpr int LDS_BUF_BYTES = CHUNK_HW_MAX * 2;                       // 64 KB each, two of them
@@ -168,7 +175,41 @@ __device__ __forceinline__ Blk pack_act(const f32x16 acc, const __attribute__((a
 }
 
 constexpr int DMA_PIECES = LDS_BUF_BYTES / (H_THREADS * 16);   // 8 pieces of 8 KB cover the largest chunk
-constexpr int A_PREFETCH = 3;   // A fragments (ds_read_b128 each) kept in flight ahead of the MFMA that consumes them
+constexpr int A_PREFETCH = SAHS_BF16_APF > 0 ? SAHS_BF16_APF : 3;   // A fragments (ds_read_b128 each) kept in flight ahead of the MFMA that consumes them
+
+// ---- hand-issued A-fragment reads ---------------------------------------------------------------------------------------------
+// Left to the compiler, the reads of the "ring" below are sunk next to their uses (ds_read, ds_read, s_waitcnt lgkmcnt(0), MFMA ...:
+// the full LDS latency is exposed every two or three MFMAs; tools/check_isa.py).  Issued as volatile asm they stay where they are
+// written -- A_PREFETCH fragments ahead of the MFMA that consumes them -- and each MFMA waits only for ITS fragment with a counted
+// lgkmcnt (LDS returns in order; the persistent loop has no scalar loads that could share the counter out of order).  The
+// destination registers are unprotected until that wait (cdna_hip_programming.md section 5.7): nothing but the MFMA reads them.
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p; }
+template <int OFF>       // OFF: byte offset, an instruction immediate (< 64 KB: one chunk buffer)
+__device__ __forceinline__ void a_read(bf16x8 &dst, uint32_t addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+    __builtin_amdgcn_sched_barrier(0);      // the MFMA that consumes a LATER fragment must not be scheduled above this read's wait
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm()
+{
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+    __builtin_amdgcn_sched_barrier(0);      // hipcc would otherwise hoist a register-only MFMA above the wait (guide rule 18)
+}
+__device__ __forceinline__ void wait_lgkm_n(int n)      // n is a constant after unrolling: the switch folds to one s_waitcnt
+{
+    switch (n) {
+    case 0: wait_lgkm<0>(); break;
+    case 1: wait_lgkm<1>(); break;
+    case 2: wait_lgkm<2>(); break;
+    case 3: wait_lgkm<3>(); break;
+    case 4: wait_lgkm<4>(); break;
+    case 5: wait_lgkm<5>(); break;
+    case 6: wait_lgkm<6>(); break;
+    default: wait_lgkm<7>(); break;
+    }
+}
 
 // hidden layer: NT32 output tiles, activation, bf16 repack.  A chunk is one flat run of G*KB*2 MFMAs;
 // the A-fragment reads run A_PREFETCH steps ahead, across tile boundaries.
@@ -190,11 +231,38 @@ __device__ __forceinline__ void dense_h(CtxH &cx, const Blk *in0, const Blk *in1
         cx.stamp();                                   // chunk start
         const bf16x8 *A = cx.cur() + cx.lane;
         bf16x8 a[A_PREFETCH];
+#if SAHS_BF16_APF
+        const uint32_t abase = lds_addr_of(A);
+        [&]<int... Is>(std::integer_sequence<int, Is...>) { (a_read<Is * 1024>(a[Is], abase), ...); }(std::make_integer_sequence<int, A_PREFETCH>{});
+#else
 #pragma unroll
         for (int i = 0; i < A_PREFETCH; ++i) a[i] = A[i * 64];
+#endif
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;      // bias is added at repack time: the chain starts from an inline zero
+#if SAHS_BF16_APF
+        auto mfma_step = [&]<int I>() {       // I is a compile-time constant: the read offsets are instruction immediates
+            constexpr int k = I % STEPS, b = k >> 1, st = k & 1;
+            const Blk &x = (b < K0) ? in0[b] : ((b < K0 + K1) ? in1[b - K0] : in2[b - K0 - K1]);
+            wait_lgkm<((TOTAL - 1 - I) < (A_PREFETCH - 1) ? (TOTAL - 1 - I) : (A_PREFETCH - 1))>();    // fragment I has landed
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[I % A_PREFETCH], x.s[st], acc, 0, 0, 0);
+            if constexpr (I + A_PREFETCH < TOTAL) a_read<(I + A_PREFETCH) * 1024>(a[I % A_PREFETCH], abase);
+        };
+        auto full_step = [&]<int I>() {
+            constexpr int g = I / STEPS, k = I % STEPS;
+            if (I % PSTEP == 0 && I / PSTEP < npieces) cx.issue_piece(I / PSTEP);
+            mfma_step.template operator()<I>();
+            if constexpr (k == STEPS - 1) {
+                Blk o = pack_act(acc, cx.bias_ptr(bias_off + 32 * (c * G + g)), slope);
+                asm volatile("" : "+v"(o.s[0]), "+v"(o.s[1]));
+                out[c * G + g] = o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            }
+        };
+        [&]<int... Is>(std::integer_sequence<int, Is...>) { (full_step.template operator()<Is>(), ...); }(std::make_integer_sequence<int, TOTAL>{});
+#else
 #pragma unroll
         for (int i = 0; i < TOTAL; ++i) {
             const int g = i / STEPS, k = i % STEPS, b = k >> 1, st = k & 1;
@@ -225,6 +293,7 @@ __device__ __forceinline__ void dense_h(CtxH &cx, const Blk *in0, const Blk *in1
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
             }
         }
+#endif
 #pragma unroll
         for (int pc = (TOTAL + PSTEP - 1) / PSTEP; pc < DMA_PIECES; ++pc)
             if (pc < npieces) cx.issue_piece(pc);
@@ -238,6 +307,19 @@ template <int K0, int NPIECES>
 __device__ __forceinline__ f32x16 tile_mac(CtxH &cx, const bf16x8 *A, const Blk *in0, f32x16 acc)
 {
     bf16x8 a[A_PREFETCH];
+    constexpr int TOTAL = K0 * 2;
+#if SAHS_BF16_APF
+    const uint32_t abase = lds_addr_of(A);
+    constexpr int PRE = A_PREFETCH < TOTAL ? A_PREFETCH : TOTAL;
+    [&]<int... Is>(std::integer_sequence<int, Is...>) { (a_read<Is * 1024>(a[Is], abase), ...); }(std::make_integer_sequence<int, PRE>{});
+    auto step = [&]<int I>() {
+        if (I < NPIECES) cx.issue_piece(I);
+        wait_lgkm<((TOTAL - 1 - I) < (A_PREFETCH - 1) ? (TOTAL - 1 - I) : (A_PREFETCH - 1))>();
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[I % A_PREFETCH], in0[I >> 1].s[I & 1], acc, 0, 0, 0);
+        if constexpr (I + A_PREFETCH < TOTAL) a_read<(I + A_PREFETCH) * 1024>(a[I % A_PREFETCH], abase);
+    };
+    [&]<int... Is>(std::integer_sequence<int, Is...>) { (step.template operator()<Is>(), ...); }(std::make_integer_sequence<int, TOTAL>{});
+#else
 #pragma unroll
     for (int i = 0; i < A_PREFETCH; ++i) a[i] = A[i * 64];
 #pragma unroll
@@ -246,6 +328,7 @@ __device__ __forceinline__ f32x16 tile_mac(CtxH &cx, const bf16x8 *A, const Blk 
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % A_PREFETCH], in0[i >> 1].s[i & 1], acc, 0, 0, 0);
         if (i + A_PREFETCH < K0 * 2) a[i % A_PREFETCH] = A[(i + A_PREFETCH) * 64];
     }
+#endif
 #pragma unroll
     for (int pc = K0 * 2; pc < NPIECES; ++pc) cx.issue_piece(pc);
     return acc;

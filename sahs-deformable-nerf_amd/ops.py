@@ -14,9 +14,9 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import SAHS_F32, SAHS_BF16, check
+from ._lib import SAHS_F32, SAHS_BF16, SAHS_BF16_2W, check
 
-PRECISIONS = {"fp32": SAHS_F32, "f32": SAHS_F32, "bf16": SAHS_BF16}
+PRECISIONS = {"fp32": SAHS_F32, "f32": SAHS_F32, "bf16": SAHS_BF16, "bf16_2w": SAHS_BF16_2W}   # bf16_2w: the round-1 kernel, A/B reference
 
 
 def _p(t):

@@ -14,7 +14,11 @@ VDIR = os.path.join(REPO, "sahs-deformable-nerf_amd", "build", "variants")
 VARIANTS = {"base": [],  "nope": ["SAHS_ABLATE_NOPE"], "nobarrier": ["SAHS_ABLATE_NOBARRIER"], "noprio": ["SAHS_ABLATE_NOPRIO"], "nopack": ["SAHS_ABLATE_NOPACK"], "nopack_nodma": ["SAHS_ABLATE_NOPACK", "SAHS_ABLATE_NODMA"],
             "nopack_nodma_nolds": ["SAHS_ABLATE_NOPACK", "SAHS_ABLATE_NODMA", "SAHS_ABLATE_NOLDSREAD"], "nodma": ["SAHS_ABLATE_NODMA"], "nomfma": ["SAHS_ABLATE_NOMFMA"], "nomfma_nodma": ["SAHS_ABLATE_NOMFMA", "SAHS_ABLATE_NODMA"],
             "noldsread": ["SAHS_ABLATE_NOLDSREAD"], "noldsread_nodma": ["SAHS_ABLATE_NOLDSREAD", "SAHS_ABLATE_NODMA"],
-            "ntstore": ["SAHS_ABLATE_NTSTORE"], "noact": ["SAHS_ABLATE_NOACT"]}
+            "ntstore": ["SAHS_ABLATE_NTSTORE"], "noact": ["SAHS_ABLATE_NOACT"],
+            # round 2: hand-issued A-fragment reads N fragments ahead with counted lgkmcnt; one wave per SIMD (4 waves)
+            "apf3": ["SAHS_BF16_APF=3"], "apf4": ["SAHS_BF16_APF=4"], "apf6": ["SAHS_BF16_APF=6"], "apf8": ["SAHS_BF16_APF=8"],
+            "wnopack": ["SAHS_ABLATE_NOPACK"], "wagpr": ["SAHS_NOTHING"], "wnoaccread": ["SAHS_ABLATE_NOACCREAD"], "wnodma": ["SAHS_ABLATE_NODMA"], "wnopack_nodma": ["SAHS_ABLATE_NOPACK", "SAHS_ABLATE_NODMA"],
+            "w4": ["SAHS_BF16_WAVES=4"], "w4apf6": ["SAHS_BF16_WAVES=4", "SAHS_BF16_APF=6"]}
 
 
 def build():
