@@ -8,7 +8,10 @@ background prior on, hash-filled HIGH-DYNAMIC-RANGE weights (weights.hash_state_
 semi-transparent volume, so that accuracy figures mean something), synthetic audio/pose.  A "step" is one frame
 through the drop-in driver's launch sequence (ray bundle, conditioning fold, and per 131,072-ray chunk: depths,
 coarse field, composite, resample+sort, fine field, composite), every ray's 8-tuple written in place into one
-(R, 36) row block.  Inputs are resident in HBM.
+(R, 36) row block.  Inputs are resident in HBM.  fp32: the fine field is two launches -- the deformation nets for the
+64 NEW depths, then the radiance net for all 128 sorted depths -- because the deformed points of the 64 coarse depths
+are kept from the coarse launch instead of being recomputed as the reference does (bit-identical outputs; the
+roofline still counts the reference's algorithmic FLOPs, frac_executed the instructions actually issued).
 
 N GPUs (torchrun, one process per GPU): the frame's rays are split into N contiguous blocks (no exchange while
 rendering), then ONE all-gather of the 36 floats/ray rows (RCCL).  Total work is fixed => "scaling": "strong".
@@ -103,7 +106,7 @@ def run_headline(renderer, num_rays, world, rank, steps, warmup, dist, gather, s
 # the HIP renderer: the drop-in driver's launch chain with HIP events around the field launches
 # ---------------------------------------------------------------------------------------------------------------------------
 class HipRenderer:
-    def __init__(self, pkg, dev, size, precision="fp32", arch="audio", num_fine=None, weights=HDR):
+    def __init__(self, pkg, dev, size, precision="fp32", arch="audio", num_fine=None, weights=HDR, share_deformation=True):
         W = pkg.weights
         self.pkg, self.ops, self.dev, self.arch, self.precision_name = pkg, pkg.ops, dev, arch, precision
         rng = np.random.default_rng(42)
@@ -132,7 +135,12 @@ class HipRenderer:
         self.prec = self.model.precision
         self.packed, _ = self.model.packed()
         self.flop_per_sample = FLOP_PER_SAMPLE[arch]
-        self.exec_flop_per_sample = 2 * self.ops.executed_macs_per_sample(arch, self.prec)
+        # fp32: the deformation nets are evaluated once per depth (sahs_model_field_forward_split), as the drop-in driver does
+        self.split = precision == "fp32" and share_deformation
+        ex = lambda part: 2 * self.ops.executed_macs_per_sample(arch, self.prec, part)
+        self.exec_flop_per_sample = ex(0)
+        # executed FLOPs per RAY: coarse = nc whole-network evaluations; fine = nf deformation + (nc + nf) radiance evaluations when split
+        self.exec_flop_per_ray = (self.nc * ex(0) + self.nf * ex(1) + (self.nc + self.nf) * ex(2)) if self.split else (2 * self.nc + self.nf) * ex(0)
         self.ws = {}
         self.record = False
         self.field_events = []
@@ -155,17 +163,31 @@ class HipRenderer:
             t_rand = ops.ray_uniforms(self.seed, 0, lo + s, N, nc, dev)     # keyed by GLOBAL ray index: the frame does not depend on N GPUs
             z_c = ops.stratified_depths(rb, nc, False, t_rand)
             e0, e1, e2, e3 = ev(), ev(), ev(), ev()
+            split = self.split and nf > 0
+            if split:     # the deformation nets once per depth (ops.render_rays_rows share_deformation): coarse launch also emits x', w
+                xw, key = self.ws.get(("xw", N)), ("xw", N)
+                if xw is None:
+                    xw = self.ws[key] = torch.empty(N, nc + nf, 8, dtype=torch.float32, device=dev)
             e0.record()
-            raw = ops.field_forward(self.packed, frame, 0, rb, z_c, precision=self.prec, out=self.ws.get(("raw", N, nc)), arch=self.arch)
+            if split:
+                raw = ops.field_forward_split(self.packed, frame, 0, ops.FIELD_ALL, rb, xw, z=z_c, out=self.ws.get(("raw", N, nc)), arch=self.arch)
+            else:
+                raw = ops.field_forward(self.packed, frame, 0, rb, z_c, precision=self.prec, out=self.ws.get(("raw", N, nc)), arch=self.arch)
             e1.record()
             self.ws[("raw", N, nc)] = raw
             wts = ops.composite_forward_rows(raw, z_c, rb, rw, False, bg=bgb, weights=self.ws.get(("w", N, nc)))
             self.ws[("w", N, nc)] = wts
             if nf > 0:
                 u = ops.ray_uniforms(self.seed, 1, lo + s, N, nf, dev)
-                z_f = ops.resample(z_c, wts, nf, u=u)
-                e2.record()
-                raw_f = ops.field_forward(self.packed, frame, 1, rb, z_f, precision=self.prec, out=self.ws.get(("raw", N, nc + nf)), arch=self.arch)
+                if split:
+                    z_f, z_new, src = ops.resample_merge(z_c, wts, nf, u=u)
+                    e2.record()
+                    ops.field_forward_split(self.packed, frame, 1, ops.FIELD_DEFORM, rb, xw, z=z_new, xw_col0=nc, arch=self.arch)
+                    raw_f = ops.field_forward_split(self.packed, frame, 1, ops.FIELD_RADIANCE, rb, xw, src=src, out=self.ws.get(("raw", N, nc + nf)), arch=self.arch)
+                else:
+                    z_f = ops.resample(z_c, wts, nf, u=u)
+                    e2.record()
+                    raw_f = ops.field_forward(self.packed, frame, 1, rb, z_f, precision=self.prec, out=self.ws.get(("raw", N, nc + nf)), arch=self.arch)
                 e3.record()
                 self.ws[("raw", N, nc + nf)] = raw_f
                 self.ws[("w", N, nc + nf)] = ops.composite_forward_rows(raw_f, z_f, rb, rw, True, bg=bgb, weights=self.ws.get(("w", N, nc + nf)))
@@ -186,7 +208,8 @@ class HipRenderer:
                 "passes of this command, per fine launch; bench.py cannot collect PMCs)", "launches": len(self.field_events),
                 "avg_launch_ms": field_ms / max(1, len(self.field_events)), "flop_per_sample": self.flop_per_sample,
                 "flop_per_sample_executed": self.exec_flop_per_sample,
-                "frac_executed": samples * self.exec_flop_per_sample / (field_ms * 1e-3) / 1e12 / peak,
+                "shared_deformation": self.split,
+                "frac_executed": (samples / (2 * self.nc + self.nf)) * self.exec_flop_per_ray / (field_ms * 1e-3) / 1e12 / peak,
                 "field_time_share": field_ms * 1e-3 / dt}
 
 

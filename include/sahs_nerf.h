@@ -167,6 +167,8 @@ int sahs_model_field_backward(int model, const float *flat_params, const float *
  * program's zero-padded tiles and k-blocks, without the per-frame constant columns (folded into biases once per frame).  The
  * ALGORITHMIC count the roofline is quoted on is the reference's own (927,872 for AudioFaceModel). */
 long sahs_model_executed_macs_per_sample(int model, int precision);
+/* the same for a part of the network: 0 all of it, 1 the deformation nets, 2 the radiance net (sahs_model_field_forward_split) */
+long sahs_model_executed_macs_part(int model, int precision, int part);
 
 /* The 8-tuple of a ray side by side in one row of SAHS_ROW_COLUMNS floats -- the unit the multi-GPU all-gather of rendered
  * pixels moves and the layout run_one_iter_of_nerf's chunk loop fills in place, so no per-chunk
@@ -184,12 +186,29 @@ long sahs_model_executed_macs_per_sample(int model, int precision);
  * (incl. w_bg = weights[:, -1] and depth); weights (N,S) stays a dense array (the resampling reads it). */
 int sahs_composite_forward_rows(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
                                 const float *bg, int white_background, float *weights, float *rows, int row_ld, int fine_pass, void *stream);
+/* z_vals_mid + sample_pdf_2 + cat + sort as sahs_resample, also returning the merge permutation: src (N,S+nf) int32, position s of the
+ * sorted row holds element src[s] of cat(z, z_samples) (train_utils.py:166; equal values keep that order). */
+int sahs_resample_merge(long N, int S, int nf, const float *z, const float *weights, const float *u, float *z_samples, float *z_out,
+                        int32_t *src, void *stream);
+
+/* The field evaluated in parts.  The deformation nets (WarpFieldMLP, HyperSheetMLP: one instance for both levels, models.py:231-254)
+ * map a sample point x to (x', w); the fine pass's depths are sort(cat(coarse depths, new depths)), so the reference's fine pass
+ * repeats the deformation of every coarse sample.  mode 0: the whole network for (N,S) depths z, also writing [x'0 x'1 x'2 w0 w1 . . .]
+ * of every sample to xw[ray][xw_col0 + s] (xw: (N, xw_row, 8) floats); mode 1: the deformation nets only (raw unused); mode 2: the
+ * radiance net of `level` only, for S samples per ray whose (x', w) are xw[ray][src[ray][s]] (z unused).  Same arithmetic on the same
+ * operands as sahs_model_field_forward: bit-identical raw.  fp32; not for SAHS_MODEL_NERFACE_STATIC (no deformation nets). */
+int sahs_model_field_forward_split(int model, const void *packed, const float *frame, int level, int mode, long N, int S, const float *rays,
+                                   int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src,
+                                   void *stream);
+
 /* sahs_model_render_rays writing rows[r * row_ld + column] instead of eight dense arrays (row_ld >= 36; columns 17..33 are
- * left untouched when nf == 0).  Workspace and draws as sahs_render_rays. */
+ * left untouched when nf == 0).  Workspace and draws as sahs_render_rays.  Optional extra workspace xw (N,Sc+nf,8) floats, src
+ * (N,Sc+nf) int32, z_new (N,nf) floats: when all three are given (fp32, nf > 0) the chain evaluates the deformation nets once per
+ * depth (sahs_model_field_forward_split) -- 6 % less matrix work per frame, identical results. */
 int sahs_model_render_rays_rows(int model, const void *packed, const float *frame, int precision, long N, const float *rays,
                                 int ray_stride, int Sc, int nf, int lindisp, int white_background, const float *bg, const float *t_rand,
                                 const float *noise_c, const float *u, const float *noise_f, float *z_c, float *z_f, float *raw,
-                                float *weights, float *rows, int row_ld, void *stream);
+                                float *weights, float *rows, int row_ld, float *xw, int32_t *src, float *z_new, void *stream);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,7 @@ int sahs_composite_forward_launch(long N, int S, const float *raw, const float *
                                   const float *bg, int white_bkgd, float *rgb_map, float *disp, float *acc_map, float *weights,
                                   float *depth, float *w_last, int rgb_ld, int sc_ld, hipStream_t stream);
 int sahs_resample_launch(long N, int S, int nf, int from_z, const float *z, const float *weights, const float *u, float *z_samples,
-                         float *z_out, long long *inds, hipStream_t stream);
+                         float *z_out, long long *inds, int *src, hipStream_t stream);
 int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, long N, int S, float *out, hipStream_t stream);
 // the NeRFaceModel builds of pack.hip / field_f32.hip (sahs_model.hpp: SAHS_MODEL=1 suffix _nf, SAHS_MODEL=2 suffix _ns)
 #define SAHS_DECLARE_MODEL(sfx)                                                                                                      \
@@ -43,7 +43,7 @@ int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, 
     long sahs_layout_packed_words_f32##sfx(void);                                                                                   \
     long sahs_layout_frame_words##sfx(void);                                                                                        \
     long sahs_layout_act_words##sfx(void);                                                                                          \
-    long sahs_layout_executed_macs##sfx(int precision);                                                                             \
+    long sahs_layout_executed_macs##sfx(int precision, int part);                                                                             \
     long sahs_field_backward_ws_words##sfx(long P);                                                                                 \
     int sahs_field_backward_launch##sfx(const float *flat, const float *frame, int level, long P, const float *actbuf,              \
                                         const float *d_raw, float *grad_flat, float *grad_cond, float *ws, hipStream_t stream);     \
@@ -52,7 +52,10 @@ int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, 
                                            hipStream_t stream);                                                                     \
     int sahs_field_forward_f32_launch##sfx(const float *packed, const float *frame, int level, long P, int S, const float *rays,   \
                                            int ray_stride, const float *zvals, float *raw, float *dbg, float *actbuf, int num_cu,   \
-                                           hipStream_t stream);
+                                           hipStream_t stream);                                                                     \
+    int sahs_field_forward_f32_split_launch##sfx(const float *packed, const float *frame, int level, int mode, long P, int S,      \
+                                                 const float *rays, int ray_stride, const float *zvals, float *raw, float *xw,      \
+                                                 int xw_row, int xw_col0, const int *src, int num_cu, hipStream_t stream);
 SAHS_DECLARE_MODEL()
 SAHS_DECLARE_MODEL(_nf)
 SAHS_DECLARE_MODEL(_ns)
@@ -176,8 +179,18 @@ int sahs_resample(long N, int S, int nf, const float *z, const float *weights, c
     if (N == 0) return 0;
     REQUIRE(z && weights && z_out, "sahs_resample");
     REQUIRE(N >= 0 && S >= 3 && S <= 256 && nf >= 1 && nf <= 256, "sahs_resample(shape: 3 <= S <= 256, 1 <= nf <= 256)");
-    int e = sahs_resample_launch(N, S, nf, 1, z, weights, u, z_samples, z_out, (long long *)inds, (hipStream_t)stream);
+    int e = sahs_resample_launch(N, S, nf, 1, z, weights, u, z_samples, z_out, (long long *)inds, nullptr, (hipStream_t)stream);
     return e ? hip_fail("sahs_resample", e) : 0;
+}
+
+int sahs_resample_merge(long N, int S, int nf, const float *z, const float *weights, const float *u, float *z_samples, float *z_out,
+                        int32_t *src, void *stream)
+{
+    if (N == 0) return 0;
+    REQUIRE(z && weights && z_out && z_samples && src, "sahs_resample_merge");
+    REQUIRE(N >= 0 && S >= 3 && S <= 256 && nf >= 1 && nf <= 256, "sahs_resample_merge(shape: 3 <= S <= 256, 1 <= nf <= 256)");
+    int e = sahs_resample_launch(N, S, nf, 1, z, weights, u, z_samples, z_out, nullptr, src, (hipStream_t)stream);
+    return e ? hip_fail("sahs_resample_merge", e) : 0;
 }
 
 int sahs_sample_pdf(long N, int nb, int ns, const float *bins, const float *weights, const float *u, float *samples, int64_t *inds,
@@ -186,7 +199,7 @@ int sahs_sample_pdf(long N, int nb, int ns, const float *bins, const float *weig
     if (N == 0) return 0;
     REQUIRE(bins && weights && samples, "sahs_sample_pdf");
     REQUIRE(N >= 0 && nb >= 2 && nb < 256 && ns >= 1 && ns <= 256, "sahs_sample_pdf(shape: 2 <= nb < 256, 1 <= ns <= 256)");
-    int e = sahs_resample_launch(N, nb + 1, ns, 0, bins, weights, u, samples, nullptr, (long long *)inds, (hipStream_t)stream);
+    int e = sahs_resample_launch(N, nb + 1, ns, 0, bins, weights, u, samples, nullptr, (long long *)inds, nullptr, (hipStream_t)stream);
     return e ? hip_fail("sahs_sample_pdf", e) : 0;
 }
 
@@ -309,11 +322,13 @@ long sahs_model_packed_words(int model, int precision)
     if (model == SAHS_MODEL_AUDIO) return sahs_packed_words(precision);
     return precision == SAHS_F32 ? kModels[model].packed_words_f32() : -1;
 }
-long sahs_model_executed_macs_per_sample(int model, int precision)
+long sahs_model_executed_macs_part(int model, int precision, int part)
 {
-    if (model < 0 || model > 2 || (precision != SAHS_F32 && precision != SAHS_BF16)) return -1;
-    return model == 0 ? sahs_layout_executed_macs(precision) : (model == 1 ? sahs_layout_executed_macs_nf(precision) : sahs_layout_executed_macs_ns(precision));
+    if (model < 0 || model > 2 || precision < SAHS_F32 || precision > SAHS_BF16_2W || part < 0 || part > 2) return -1;
+    return model == 0 ? sahs_layout_executed_macs(precision, part)
+                      : (model == 1 ? sahs_layout_executed_macs_nf(precision, part) : sahs_layout_executed_macs_ns(precision, part));
 }
+long sahs_model_executed_macs_per_sample(int model, int precision) { return sahs_model_executed_macs_part(model, precision, 0); }
 long sahs_model_frame_words(int model) { return (model < 0 || model > 2) ? -1 : kModels[model].frame_words(); }
 
 int sahs_model_pack_weights(int model, const float *flat_params, void *packed, int precision, void *stream)
@@ -397,6 +412,27 @@ int sahs_model_render_rays(int model, const void *packed, const float *frame, in
                              t_rand, noise_c, u, noise_f, z_c, z_f, raw, weights, rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_bg, depth_f, stream);
 }
 
+/* The split evaluation of the field (csrc/field_f32.hip, MODE): 0 whole network + x', w written to xw; 1 deformation nets only;
+ * 2 radiance net only, x', w fetched from xw through src. */
+int sahs_model_field_forward_split(int model, const void *packed, const float *frame, int level, int mode, long N, int S, const float *rays,
+                                   int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src, void *stream)
+{
+    REQUIRE_MODEL(model, "sahs_model_field_forward_split");
+    if (N == 0) return 0;
+    if (model == SAHS_MODEL_NERFACE_STATIC) return fail(4, "sahs_model_field_forward_split: this model has no deformation nets%s%ld", "", 0L);
+    REQUIRE(packed && frame && rays && xw && (level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8 && mode >= 0 && mode <= 2,
+            "sahs_model_field_forward_split");
+    REQUIRE((mode == 1 || raw) && (mode == 2 || z) && (mode != 2 || src), "sahs_model_field_forward_split(buffers of the mode)");
+    REQUIRE(xw_col0 >= 0 && xw_row >= xw_col0 + (mode == 2 ? 0 : S) && ALIGNED16(xw) && ALIGNED16(packed) && ALIGNED16(frame) && (!raw || ALIGNED16(raw)),
+            "sahs_model_field_forward_split(xw layout / alignment)");
+    int e = model == SAHS_MODEL_AUDIO
+                ? sahs_field_forward_f32_split_launch((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0, src,
+                                                      num_cus(), (hipStream_t)stream)
+                : sahs_field_forward_f32_split_launch_nf((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0,
+                                                         src, num_cus(), (hipStream_t)stream);
+    return e ? hip_fail("sahs_model_field_forward_split", e) : 0;
+}
+
 int sahs_composite_forward_rows(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
                                 const float *bg, int white_background, float *weights, float *rows, int row_ld, int fine_pass, void *stream)
 {
@@ -415,11 +451,30 @@ int sahs_composite_forward_rows(long N, int S, const float *raw, const float *z,
 int sahs_model_render_rays_rows(int model, const void *packed, const float *frame, int precision, long N, const float *rays,
                                 int ray_stride, int Sc, int nf, int lindisp, int white_background, const float *bg, const float *t_rand,
                                 const float *noise_c, const float *u, const float *noise_f, float *z_c, float *z_f, float *raw,
-                                float *weights, float *rows, int row_ld, void *stream)
+                                float *weights, float *rows, int row_ld, float *xw, int32_t *src, float *z_new, void *stream)
 {
     REQUIRE_MODEL(model, "sahs_model_render_rays_rows");
     if (N == 0) return 0;
     REQUIRE(rows && row_ld >= SAHS_ROW_COLUMNS, "sahs_model_render_rays_rows(rows)");
+    if (xw && src && z_new && nf > 0 && precision == SAHS_F32 && model != SAHS_MODEL_NERFACE_STATIC) {
+        // the deformation nets are shared by the two levels and the fine depths contain the coarse ones: evaluate them once per depth
+        const char *who = "sahs_model_render_rays_rows";
+        REQUIRE(packed && frame && rays && z_c && z_f && raw && weights && Sc + nf <= 256, who);
+        const int Sf = Sc + nf;
+        hipStream_t st = (hipStream_t)stream;
+        int e;
+        if ((e = sahs_stratified_depths(N, Sc, rays, ray_stride, lindisp, t_rand, z_c, stream))) return e;
+        if ((e = sahs_model_field_forward_split(model, packed, frame, 0, 0, N, Sc, rays, ray_stride, z_c, raw, xw, Sf, 0, nullptr, stream))) return e;
+        e = sahs_composite_forward_launch(N, Sc, raw, z_c, rays, ray_stride, noise_c, bg, white_background, rows + SAHS_ROW_RGB_C, rows + SAHS_ROW_DISP_C,
+                                          rows + SAHS_ROW_ACC_C, weights, nullptr, nullptr, row_ld, row_ld, st);
+        if (e) return hip_fail(who, e);
+        if ((e = sahs_resample_merge(N, Sc, nf, z_c, weights, u, z_new, z_f, src, stream))) return e;
+        if ((e = sahs_model_field_forward_split(model, packed, frame, 1, 1, N, nf, rays, ray_stride, z_new, nullptr, xw, Sf, Sc, nullptr, stream))) return e;
+        if ((e = sahs_model_field_forward_split(model, packed, frame, 1, 2, N, Sf, rays, ray_stride, nullptr, raw, xw, Sf, 0, src, stream))) return e;
+        e = sahs_composite_forward_launch(N, Sf, raw, z_f, rays, ray_stride, noise_f, bg, white_background, rows + SAHS_ROW_RGB_F, rows + SAHS_ROW_DISP_F,
+                                          rows + SAHS_ROW_ACC_F, weights, rows + SAHS_ROW_DEPTH_F, rows + SAHS_ROW_W_BG, row_ld, row_ld, st);
+        return e ? hip_fail(who, e) : 0;
+    }
     field_fn_t f = model == SAHS_MODEL_AUDIO ? sahs_field_forward : (model == SAHS_MODEL_NERFACE ? field_nf : field_ns);
     return render_rays_chain(f, "sahs_model_render_rays_rows", packed, frame, precision, N, rays, ray_stride, Sc, nf, lindisp, white_background,
                              bg, t_rand, noise_c, u, noise_f, z_c, z_f, raw, weights, rows + SAHS_ROW_RGB_C, rows + SAHS_ROW_DISP_C,

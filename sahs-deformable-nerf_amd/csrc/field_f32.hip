@@ -56,12 +56,13 @@ struct Ctx {
     // Next chunk's LDS-DMA.  The chunk sequence is static, so its offset is tracked arithmetically (no table load on the
     // critical path) and its size -- hence its number of 8-KB pieces -- is a compile-time constant at every call site.
     uint32_t off;             // float offset of the next chunk to prefetch (uniform)
+    uint32_t wrap_at, wrap_to; // the part of the stream this launch walks: [wrap_to, wrap_at) (whole stream, deformation nets only, or radiance net only)
     const f32x4 *nx_src; f32x4 *nx_dst;
     lds_cfloat bias_lane;     // LDS address of this lane's bias rows (refreshed opaquely per sample tile: see refresh())
 
     __device__ __forceinline__ void begin_chunk(int next_floats)
     {
-        if (off >= (uint32_t)STREAM_FLOATS) off = 0;
+        if (off >= wrap_at) off = wrap_to;
         nx_src = reinterpret_cast<const f32x4 *>(stream + off) + lane;
         nx_dst = reinterpret_cast<f32x4 *>(lds + (buf ^ 1) * LDS_BUF_FLOATS);
         off += (uint32_t)next_floats;
@@ -253,12 +254,26 @@ __device__ __forceinline__ void grid_blocks(const float *__restrict__ grid, floa
 #define CHF(id) (kProg.layer[id].G * kProg.layer[id].KB * 256)   /* floats in one chunk of layer id */
 
 // SAVE: also store every layer's activations (sahs::act layout, 19 KB/sample) for field_bwd.hip
-template <bool SAVE>
+// MODE: which part of the per-sample network a launch evaluates.  The deformation nets (warp field, hyper sheet) are shared by the
+// coarse and the fine level, and the fine pass's depths are sort(cat(coarse depths, new depths)) (train_utils.py:166): the reference
+// evaluates the deformation of the coarse samples a second time in its fine pass.  Here the coarse launch (FIELD_ALL) also writes every
+// sample's deformed point x' and ambient coordinate w to `xw`, a FIELD_DEFORM launch computes them for the new depths only, and the
+// fine launch (FIELD_RADIANCE) reads them through the merge permutation `src` and runs only the radiance net: the same arithmetic on
+// the same operands, hence bit-identical results, for 6 % fewer matrix instructions per frame.
+//   xw: (rays, xw_row, 8) floats [x'0 x'1 x'2 w0 w1 . . .]; a launch over (N, S) depths owns columns xw_col0 .. xw_col0 + S - 1
+//   src: (N, S) int32, FIELD_RADIANCE only: column of xw holding sample s of the ray
+enum { FIELD_ALL = 0, FIELD_DEFORM = 1, FIELD_RADIANCE = 2 };
+template <bool SAVE, int MODE>
 __global__ void __launch_bounds__(F32_THREADS, 2)
 field_forward_f32_kernel(const float *__restrict__ packed, const float *__restrict__ frame, int level, long P, int S,
                          const float *__restrict__ rays, int ray_stride, const float *__restrict__ zvals,
-                         float *__restrict__ raw, float *__restrict__ dbg, float *__restrict__ actbuf)
+                         float *__restrict__ raw, float *__restrict__ dbg, float *__restrict__ actbuf,
+                         float *__restrict__ xw, int xw_row, int xw_col0, const int *__restrict__ src)
 {
+    static_assert(!(SAVE && MODE != FIELD_ALL), "activations are saved by whole-network launches only");
+#if SAHS_MODEL == 2
+    static_assert(MODE == FIELD_ALL, "this model has no deformation nets to split off");
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Ctx cx;
     cx.stream = packed + PACK_STREAM_OFF + (long)level * STREAM_FLOATS;
@@ -267,19 +282,22 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
     cx.lane = threadIdx.x & 63;
     cx.q = cx.lane >> 4;
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    cx.off = 0;
+    constexpr const Layer *Ly = kProg.layer;
+    constexpr int L_START = (MODE == FIELD_RADIANCE) ? L_T0 : L_FIRST;      // first layer of this launch's walk through the stream
+    cx.wrap_to = (MODE == FIELD_RADIANCE) ? (uint32_t)Ly[L_T0].stream_off : 0u;
+    cx.wrap_at = (MODE == FIELD_DEFORM) ? (uint32_t)Ly[L_T0].stream_off : (uint32_t)STREAM_FLOATS;
+    cx.off = cx.wrap_to;
     const float *grid = packed + PACK_GRID_OFF;
     const int q = cx.q;
 
     {   // per-level biases (static + folded conditioning) -> LDS, first weight chunk -> buffer 0
         const float *bsrc = frame + FRAME_BIAS_OFF + level * BIAS_FLOATS;
         for (int i = threadIdx.x; i < BIAS_FLOATS; i += F32_THREADS) lds[LDS_BIAS_OFF + i] = bsrc[i];
-        cx.begin_chunk(CHF(L_FIRST));
+        cx.begin_chunk(CHF(L_START));
 #pragma unroll
-        for (int pc = 0; pc < (CHF(L_FIRST) + PIECE_FLOATS - 1) / PIECE_FLOATS; ++pc) cx.issue_piece(pc);
+        for (int pc = 0; pc < (CHF(L_START) + PIECE_FLOATS - 1) / PIECE_FLOATS; ++pc) cx.issue_piece(pc);
         cx.end_chunk();
     }
-    constexpr const Layer *Ly = kProg.layer;
 
     const long ntiles = (P + F32_PTS_PER_WG - 1) / F32_PTS_PER_WG;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -289,20 +307,25 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         // x' (3) and w (2) are parked in LDS between their uses; the ray direction is re-read where needed: values that stay
         // live across the 256-wide layers get spilled to scratch, and a scratch reload drains the LDS-DMA prefetch (vmcnt).
         float *stash = lds + LDS_STASH_OFF + (cx.wave * F32_PTS_PER_WAVE + (cx.lane & 15)) * STASH_FLOATS;
-        const bool dump = dbg != nullptr && q == 0 && p_raw < P;   // lanes holding feature 0 of tile 0
+        const bool dump = MODE == FIELD_ALL && dbg != nullptr && q == 0 && p_raw < P;   // lanes holding feature 0 of tile 0
         float *dsl = dbg + p * DBG_STRIDE;
         // saved activations are one dense [P x width] array per layer (array at column c of the act:: table starts at c * P):
         // this lane's slot in its sample's row of array (c, w)
         const bool sv_on = SAVE && p_raw < P;
 #define SVP(c, w) (actbuf + (long)(c) * P + p * (long)(w) + 4 * q)
 #define SV(c, w) (sv_on ? SVP(c, w) : nullptr)
-        float x[3];
-        {
+        float x[3] = {0.0f, 0.0f, 0.0f};
+        if constexpr (MODE != FIELD_RADIANCE) {
             const float *rp = rays + (p / S) * ray_stride;
             const float z = zvals[p];
 #pragma unroll
             for (int i = 0; i < 3; ++i) x[i] = rp[i] + rp[3 + i] * z;          // train_utils.py:115
+        } else if (q == 0) {     // x', w of this sample were computed by the coarse or the deformation launch: fetch through the merge permutation
+            const float *row = xw + ((p / S) * (long)xw_row + src[p]) * 8;
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(row);
+            stash[0] = a[0]; stash[1] = a[1]; stash[2] = a[2]; stash[3] = a[3]; stash[4] = row[4];
         }
+        if constexpr (MODE != FIELD_RADIANCE) {
 #if SAHS_MODEL == 2
         // no deformation nets (use_warp False, use_ambient False): the template is queried at the raw point (models.py:316-327)
         if (q == 0) {
@@ -369,13 +392,20 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
             dense<4, 0, 4, CHF(L_H5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::HH + 4 * 64, 64));
             dense<4, 0, 4, CHF(L_HF)>(cx, hn, nullptr, h, Ly[L_H5].bias_off, false, 0.0f, SV(act::HH + 5 * 64, 64));
             f32x4 o[1];
-            dense<4, 0, 1, CHF(L_T0)>(cx, h, nullptr, o, Ly[L_HF].bias_off, false, 1.0f);
+            dense<4, 0, 1, (MODE == FIELD_DEFORM ? CHF(L_FIRST) : CHF(L_T0))>(cx, h, nullptr, o, Ly[L_HF].bias_off, false, 1.0f);
             if (q == 0) {      // rows 0..AMB_DIM-1 of the one output tile
                 stash[3] = o[0][0]; stash[4] = (AMB_DIM > 1) ? o[0][1] : 0.0f;
                 if (sv_on) { SVP(act::AW, 16)[0] = o[0][0]; SVP(act::AW, 16)[1] = stash[4]; }
             }
         }
 #endif
+        if (xw != nullptr && q == 0 && p_raw < P) {   // hand x', w to the fine pass (the lane that wrote the stash reads it back: no barrier needed)
+            float *row = xw + ((p / S) * (long)xw_row + xw_col0 + (p % S)) * 8;
+            *reinterpret_cast<f32x4 *>(row) = f32x4{stash[0], stash[1], stash[2], stash[3]};
+            row[4] = stash[4];
+        }
+        }   // MODE != FIELD_RADIANCE
+        if constexpr (MODE == FIELD_DEFORM) continue;      // the stream has wrapped to the warp field's first layer
         __builtin_amdgcn_wave_barrier();
         if (dump) { dsl[0] = stash[0] - x[0]; dsl[1] = stash[1] - x[1]; dsl[2] = stash[2] - x[2]; dsl[3] = stash[3]; dsl[4] = stash[4]; }
 
@@ -488,7 +518,7 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
             }
             dense<8, 0, 8, CHF(L_SEG)>(cx, s, nullptr, sn, Ly[L_S3].bias_off, false, 0.01f, SV(act::S + 384, 128));
             if (dump) dsl[17] = sn[0][0];
-            dense<8, 0, 1, CHF(L_FIRST)>(cx, sn, nullptr, fin, 0, true, 1.0f);
+            dense<8, 0, 1, CHF(L_START)>(cx, sn, nullptr, fin, 0, true, 1.0f);
         }
         if (p_raw < P) *reinterpret_cast<f32x4 *>(raw + p * D_RAW + 4 * q) = fin[0];   // cat((rgb, seg, alpha)) modules.py:295
     }
@@ -499,27 +529,50 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
 using namespace SAHS_NS;
 
 // dbg (optional, may be null): [P x 24: see DBG_STRIDE][P x 32: grid features]
+template <bool SAVE, int MODE>
+static int launch_field(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride, const float *zvals,
+                        float *raw, float *dbg, float *actbuf, float *xw, int xw_row, int xw_col0, const int *src, int num_cu, hipStream_t stream)
+{
+    const long ntiles = (P + F32_PTS_PER_WG - 1) / F32_PTS_PER_WG;
+    const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
+    const size_t lds_bytes = (size_t)LDS_TOTAL_FLOATS * sizeof(float);
+    static sahs_once::Flags attr_set;       // the large-LDS attribute is per device (and per instantiation)
+    hipError_t ae = sahs_once::per_device(attr_set, [&]() {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_f32_kernel<SAVE, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_bytes);
+    });
+    if (ae != hipSuccess) return (int)ae;
+    field_forward_f32_kernel<SAVE, MODE><<<grid, F32_THREADS, lds_bytes, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, actbuf,
+                                                                                   xw, xw_row, xw_col0, src);
+    return (int)hipGetLastError();
+}
+
 extern "C" int SAHS_SYM(sahs_field_forward_f32_launch)(const float *packed, const float *frame, int level, long P, int S, const float *rays,
                                              int ray_stride, const float *zvals, float *raw, float *dbg, float *actbuf, int num_cu,
                                              hipStream_t stream)
 {
     if (P <= 0) return 0;
-    const long ntiles = (P + F32_PTS_PER_WG - 1) / F32_PTS_PER_WG;
-    const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
-    const size_t lds_bytes = (size_t)LDS_TOTAL_FLOATS * sizeof(float);
-    static sahs_once::Flags attr_set;       // the large-LDS attribute is per device
-    hipError_t ae = sahs_once::per_device(attr_set, [&]() {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_f32_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_f32_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        return e;
-    });
-    if (ae != hipSuccess) return (int)ae;
     if (actbuf != nullptr)
-        field_forward_f32_kernel<true><<<grid, F32_THREADS, lds_bytes, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, actbuf);
-    else
-        field_forward_f32_kernel<false><<<grid, F32_THREADS, lds_bytes, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, nullptr);
-    return (int)hipGetLastError();
+        return launch_field<true, FIELD_ALL>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, actbuf, nullptr, 0, 0, nullptr, num_cu, stream);
+    return launch_field<false, FIELD_ALL>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, nullptr, nullptr, 0, 0, nullptr, num_cu, stream);
+}
+
+// The split evaluation (see the kernel's MODE): mode 0 = whole network, additionally writing x', w of every sample to xw; mode 1 =
+// deformation nets only (raw unused); mode 2 = radiance net only on x', w fetched through src (zvals unused).
+extern "C" int SAHS_SYM(sahs_field_forward_f32_split_launch)(const float *packed, const float *frame, int level, int mode, long P, int S,
+                                                   const float *rays, int ray_stride, const float *zvals, float *raw, float *xw, int xw_row,
+                                                   int xw_col0, const int *src, int num_cu, hipStream_t stream)
+{
+    if (P <= 0) return 0;
+#if SAHS_MODEL == 2
+    return -3;      // no deformation nets in this model
+#else
+    if (mode == FIELD_ALL)
+        return launch_field<false, FIELD_ALL>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, nullptr, nullptr, xw, xw_row, xw_col0, nullptr, num_cu, stream);
+    if (mode == FIELD_DEFORM)
+        return launch_field<false, FIELD_DEFORM>(packed, frame, level, P, S, rays, ray_stride, zvals, nullptr, nullptr, nullptr, xw, xw_row, xw_col0, nullptr, num_cu, stream);
+    if (mode == FIELD_RADIANCE)
+        return launch_field<false, FIELD_RADIANCE>(packed, frame, level, P, S, rays, ray_stride, nullptr, raw, nullptr, nullptr, xw, xw_row, 0, src, num_cu, stream);
+    return -2;
+#endif
 }

@@ -258,13 +258,16 @@ extern "C" long SAHS_SYM(sahs_layout_frame_words)(void) { return FRAME_FLOATS; }
 extern "C" long SAHS_SYM(sahs_layout_act_words)(void) { return act::STRIDE; }
 // multiply-accumulates per sample evaluation that the field kernel ISSUES (padded tiles and k-blocks of the layer program; the
 // per-frame constant columns are folded into biases and not multiplied): the denominator of an executed-MFMA utilisation
-extern "C" long SAHS_SYM(sahs_layout_executed_macs)(int precision)
+// part: 0 whole network, 1 deformation nets (the layers in front of the radiance trunk), 2 radiance net
+extern "C" long SAHS_SYM(sahs_layout_executed_macs)(int precision, int part)
 {
     long m = 0;
     if (precision == 0) {
-        for (int i = 0; i < NUM_LAYERS; ++i) m += (long)kProg.layer[i].NT * 16 * kProg.layer[i].KB * 16;
+        for (int i = 0; i < NUM_LAYERS; ++i)
+            if (part == 0 || (part == 1) == (i < L_T0)) m += (long)kProg.layer[i].NT * 16 * kProg.layer[i].KB * 16;
     } else {
-        for (int i = 0; i < hb::NUM_LAYERS_H; ++i) m += (long)hb::kProgH.layer[i].NT32 * 32 * hb::kProgH.layer[i].KB32 * 32;
+        for (int i = 0; i < hb::NUM_LAYERS_H; ++i)
+            if (part == 0 || (part == 1) == (i < hb::H_T0)) m += (long)hb::kProgH.layer[i].NT32 * 32 * hb::kProgH.layer[i].KB32 * 32;
     }
     return m;
 }

@@ -214,8 +214,8 @@ constexpr int RS_WAVES = 4;
 __global__ void __launch_bounds__(RS_WAVES * 64) resample_kernel(long N, int S, int nf, int from_z, const float *__restrict__ z,
                                                                  const float *__restrict__ weights, const float *__restrict__ u_in,
                                                                  float *__restrict__ z_samples, float *__restrict__ z_out,
-                                                                 long long *__restrict__ inds_out)
-{
+                                                                 long long *__restrict__ inds_out, int *__restrict__ src_out)
+{   // src_out (N, S+nf), optional: the merge permutation -- position `rank` of the sorted row holds element src of cat(z, samples)
     __shared__ float s_cdf[RS_WAVES][RS_MAX], s_bins[RS_WAVES][RS_MAX], s_val[RS_WAVES][2 * RS_MAX];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float *cdf = s_cdf[wv], *bins = s_bins[wv], *val = s_val[wv];
@@ -275,6 +275,7 @@ __global__ void __launch_bounds__(RS_WAVES * 64) resample_kernel(long N, int S, 
                 rank += (o < v || (o == v && b < a)) ? 1 : 0;
             }
             z_out[ray * M + rank] = v;
+            if (src_out != nullptr) src_out[ray * M + rank] = a;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -318,12 +319,12 @@ extern "C" int sahs_composite_forward_launch(long N, int S, const float *raw, co
 }
 
 extern "C" int sahs_resample_launch(long N, int S, int nf, int from_z, const float *z, const float *weights, const float *u,
-                                    float *z_samples, float *z_out, long long *inds, hipStream_t stream)
+                                    float *z_samples, float *z_out, long long *inds, int *src, hipStream_t stream)
 {
     if (N <= 0) return 0;
     if (S < 3 || S > RS_MAX || nf < 1 || nf > RS_MAX) return -2;
     resample_kernel<<<blocks_for(N, RS_WAVES, 8192), RS_WAVES * 64, 0, stream>>>(N, S, nf, from_z, z, weights, u, z_samples, z_out,
-                                                                                 inds);
+                                                                                 inds, src);
     return (int)hipGetLastError();
 }
 

@@ -60,9 +60,10 @@ def param_count(arch="audio"):
     return int(_fn("param_count", arch)[0]())
 
 
-def executed_macs_per_sample(arch="audio", precision=SAHS_F32):
-    """MACs per sample evaluation the field kernel issues to the matrix pipe (padded tiles, constants folded away)."""
-    return int(_fn("executed_macs_per_sample", arch)[0](precision))
+def executed_macs_per_sample(arch="audio", precision=SAHS_F32, part=0):
+    """MACs per sample evaluation the field kernel issues to the matrix pipe (padded tiles, constants folded away); part 1 / 2: the
+    deformation nets / the radiance net alone (the split evaluation)."""
+    return int(_fn("executed_macs_part", arch)[0](precision, part))
 
 
 def pack_weights(flat, precision=SAHS_F32, arch="audio"):
@@ -161,6 +162,40 @@ def resample(z, weights, num_fine, u=None, want_aux=False):
     return (z_out, zs, inds) if want_aux else z_out
 
 
+def resample_merge(z, weights, num_fine, u=None):
+    """resample that also returns the new samples and the merge permutation: (z_sorted (N,S+nf), z_new (N,nf), src (N,S+nf) int32)."""
+    z, weights, u = _req(z, "z_vals"), _req(weights, "weights"), _req(u, "u")
+    N, S = z.shape
+    z_out = torch.empty(N, S + num_fine, dtype=torch.float32, device=z.device)
+    z_new = torch.empty(N, num_fine, dtype=torch.float32, device=z.device)
+    src = torch.empty(N, S + num_fine, dtype=torch.int32, device=z.device)
+    check(_lib.lib().sahs_resample_merge(N, S, int(num_fine), _p(z), _p(weights), _p(u), _p(z_new), _p(z_out), _p(src), _stream()), "sahs_resample_merge")
+    return z_out, z_new, src
+
+
+FIELD_ALL, FIELD_DEFORM, FIELD_RADIANCE = 0, 1, 2
+
+
+def field_forward_split(packed, frame, level, mode, rays, xw, z=None, src=None, xw_col0=0, out=None, arch="audio"):
+    """The field in parts (include/sahs_nerf.h: sahs_model_field_forward_split).  xw: (N, row, 8) fp32 buffer of deformed points.
+    FIELD_ALL: raw (N,S,16) for depths z, x'/w of its samples written to xw[:, xw_col0:xw_col0+S]; FIELD_DEFORM: only x'/w for depths z;
+    FIELD_RADIANCE: raw for the samples xw[ray, src[ray, s]] (src (N,S) int32)."""
+    packed, frame, rays, z = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays"), _req(z, "z")
+    src = _req(src, "src", torch.int32)
+    xw = _req(xw, "xw")
+    N = rays.shape[0]
+    S = src.shape[1] if mode == FIELD_RADIANCE else z.shape[1]
+    if xw.dim() != 3 or xw.shape[0] != N or xw.shape[2] != 8:
+        raise _lib.SahsError("xw must be (N, row, 8)")
+    raw = None
+    if mode != FIELD_DEFORM:
+        raw = out if out is not None else torch.empty(N, S, 16, dtype=torch.float32, device=rays.device)
+    f, name = _fn("field_forward_split", arch)
+    check(f(_p(packed), _p(frame), int(level), int(mode), N, int(S), _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(xw), int(xw.shape[1]), int(xw_col0),
+            _p(src), _stream()), name)
+    return raw
+
+
 def sample_pdf(bins, weights, num_samples, u=None, want_inds=False):
     bins, weights, u = _req(bins, "bins"), _req(weights, "weights"), _req(u, "u")
     N, nb = bins.shape
@@ -222,10 +257,11 @@ def composite_forward_rows(raw, z, rays, rows, fine_pass, noise=None, bg=None, w
 
 
 def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=SAHS_F32, lindisp=False, white_background=False, bg=None,
-                     t_rand=None, noise_c=None, u=None, noise_f=None, workspace=None, arch="audio"):
+                     t_rand=None, noise_c=None, u=None, noise_f=None, workspace=None, arch="audio", share_deformation=True):
     """predict_and_render_radiance for one ray chunk, written IN PLACE into ``rows`` (N, 36): the 8-tuple of every ray side by
     side (a row block of the frame's (R, 36) buffer, which is also what the multi-GPU all-gather moves), so a chunk loop needs
-    no per-chunk concatenation.  Returns ``rows``."""
+    no per-chunk concatenation.  Returns ``rows``.  share_deformation (fp32): evaluate the deformation nets once per depth -- the fine
+    pass reuses the coarse samples' deformed points instead of recomputing them as the reference does; identical results."""
     packed, frame, rays = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays")
     bg, t_rand, noise_c, u, noise_f = (_req(t, n) for t, n in ((bg, "background_prior"), (t_rand, "t_rand"), (noise_c, "noise_c"),
                                                                (u, "u"), (noise_f, "noise_f")))
@@ -246,10 +282,17 @@ def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=
 
     z_c, z_f = buf("z_c", N, num_coarse), buf("z_f", N, Sf)
     raw, weights = buf("raw", N, Sf, 16), buf("weights", N, Sf)
+    xw = src = z_new = None
+    if share_deformation and num_fine > 0 and precision == SAHS_F32 and arch != "nerface_static":
+        # extra workspace of the split evaluation: deformed points of every depth, the merge permutation, the new depths
+        xw, z_new = buf("xw", N, Sf, 8), buf("z_new", N, num_fine)
+        src = ws.get("src")
+        if src is None or tuple(src.shape) != (N, Sf) or src.device != dev:
+            src = ws["src"] = torch.empty(N, Sf, dtype=torch.int32, device=dev)
     f, name = _fn("render_rays_rows", arch)
     check(f(_p(packed), _p(frame), precision, N, _p(rays), int(rays.shape[1]), int(num_coarse), int(num_fine),
             int(bool(lindisp)), int(bool(white_background)), _p(bg), _p(t_rand), _p(noise_c), _p(u), _p(noise_f),
-            _p(z_c), _p(z_f), _p(raw), _p(weights), _p(rows), int(rows.stride(0)), _stream()), name)
+            _p(z_c), _p(z_f), _p(raw), _p(weights), _p(rows), int(rows.stride(0)), _p(xw), _p(src), _p(z_new), _stream()), name)
     return rows
 
 

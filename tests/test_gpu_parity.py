@@ -415,3 +415,42 @@ def test_partition_invariant_render(flat_weights):
         assert torch.equal(a, chunked[i].reshape(144, -1)), i
         assert torch.equal(a, torch.cat([p[i].reshape(p[i].shape[0] if p[i].dim() else 1, -1) for p in parts], 0).reshape(144, -1)), i
     assert not torch.equal(full[3], other[3])
+
+
+@pytest.mark.parametrize("arch,N,nf", [("audio", 300, 64), ("audio", 77, 128), ("nerface", 130, 64)])
+def test_shared_deformation_is_bit_identical(arch, N, nf, weights_mod):
+    """The split evaluation (deformation nets once per depth: the fine pass reuses the coarse samples' deformed points through the
+    merge permutation) against the plain chain that evaluates the whole network for every fine sample, as the reference does:
+    all 36 outputs per ray bit for bit, ragged ray counts, both fine-pass lengths, both deforming architectures."""
+    sahs, ops = pkg(), pkg("ops")
+    d = dev()
+    model_name = "audio" if arch == "audio" else "nerface"
+    fw = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 2.0, 30.0, model=model_name, hdr=(arch == "audio")), model=model_name)
+    flat = T(fw)
+    packed = ops.pack_weights(flat, arch=arch)
+    g = torch.Generator(device=d).manual_seed(N + nf)
+    drv = torch.randn(16, 29, device=d, generator=g) if arch == "audio" else torch.randn(76, device=d, generator=g) * 0.5
+    cam = 0.8 if arch == "audio" else 0.5
+    pose = T(np.concatenate([np.eye(3), [[0.0], [0.0], [cam]]], 1).astype(np.float32))
+    frame = ops.fold_conditioning(flat, drv, pose, arch=arch)
+    near, far = (0.483771, 1.083771) if arch == "audio" else (0.2, 0.8)
+    rays = torch.zeros(N, 8, device=d)
+    rays[:, 2] = cam
+    rays[:, 3:6] = torch.randn(N, 3, device=d, generator=g) * 0.15 + torch.tensor([0, 0, -1.0], device=d)
+    rays[:, 6], rays[:, 7] = near, far
+    bg = torch.cat([torch.rand(N, 3, device=d, generator=g), torch.ones(N, 1, device=d), torch.zeros(N, 11, device=d)], 1)
+    t_rand, u = torch.rand(N, 64, device=d, generator=g), torch.rand(N, nf, device=d, generator=g)
+    u[0, :4] = 0.0          # samples landing exactly on coarse depths / in flat bins: ties in the merge
+    out = {}
+    for share in (False, True):
+        rows = torch.full((N, 36), float("nan"), device=d)
+        ws = {}
+        ops.render_rays_rows(packed, frame, rays, 64, nf, rows, bg=bg, t_rand=t_rand, u=u, workspace=ws, arch=arch, share_deformation=share)
+        out[share] = (rows, ws["z_f"].clone(), ws["raw"].clone())
+        assert ("xw" in ws) == share
+    for a, b, nm in zip(out[False], out[True], ("rows", "z_fine", "raw_fine")):
+        assert bool(torch.isfinite(a).all()), nm
+        assert torch.equal(a, b), "%s differs between the plain and the shared-deformation chain (max %.3e)" % (nm, float((a - b).abs().max()))
+    # and the 8-tuple entry point (plain chain) agrees with the row block
+    tup = ops.render_rays(packed, frame, rays, 64, nf, bg=bg, t_rand=t_rand, u=u, arch=arch)
+    assert torch.equal(pkg("distributed").pack_outputs(tup), out[True][0])
