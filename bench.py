@@ -46,11 +46,21 @@ FLOP_PER_SAMPLE = {"audio": 1_855_744,            # BASELINE.md section 3 (GEMM 
                    "nerface": 2 * 719_168}        # the same count for NeRFaceModel (config/expression/person_2.yml)
 PEAK_TFLOPS = {"fp32": 157.3,        # MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
                "bf16": 2500.0}       # dense BF16 MFMA peak (never the 2:1-sparse figure)
-KERNEL = {"fp32": "field_forward_f32_kernel", "bf16": "field_forward_bf16_kernel"}
+KERNEL = {"fp32": "field_forward_f32_kernel", "bf16": "field_forward_bf16w_kernel"}
 HDR = dict(seed=0, density_bias=2.0, density_gain=30.0, hdr=True)      # = VARIANTS["hdr"] of tests/golden/make_golden.py
-# HBM-side bytes of the dominant dispatch (a fine launch, 16.8 M samples) from the committed rocprofv3 PMC passes (WRITE_SIZE +
-# 2 x FETCH_SIZE, the gfx950 correction for 16 B/lane streaming reads).  STATIC: bench.py cannot collect PMCs itself.
-TRAFFIC = {"fp32": (1.074e9 + 2.19e9, "profiles/r1_final_pmc_summary.csv"), "bf16": (1.074e9 + 0.09e9, "profiles/r1_final_pmc_summary.csv")}
+# HBM-side bytes of the dominant dispatch (the launch over the 16.8 M fine samples of a ray chunk) from the committed rocprofv3 PMC passes
+# (WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction for 16 B/lane streaming reads).  STATIC: bench.py cannot collect PMCs itself; the
+# numbers are read from the summary that tools/profile_r2.sh wrote under profiles/.
+def _static_traffic():
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "r2_pmc_summary.json")))
+        return {"fp32": (d["f32_radiance"]["traffic_bytes"], "profiles/r2_pmc_summary.json:f32_radiance"),
+                "bf16": (d["bf16"]["traffic_bytes"], "profiles/r2_pmc_summary.json:bf16")}
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
+TRAFFIC = _static_traffic()
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -144,6 +154,7 @@ class HipRenderer:
         self.ws = {}
         self.record = False
         self.field_events = []
+        self.radiance_events = []     # fp32 split chain: the radiance-net launches alone (the dominant dispatch)
 
     def render(self, lo, hi):
         """Rays [lo, hi) of the frame -> (hi-lo, 36) rows; the same launches, in the same order, as sahs_model_render_rays_rows."""
@@ -183,7 +194,11 @@ class HipRenderer:
                     z_f, z_new, src = ops.resample_merge(z_c, wts, nf, u=u)
                     e2.record()
                     ops.field_forward_split(self.packed, frame, 1, ops.FIELD_DEFORM, rb, xw, z=z_new, xw_col0=nc, arch=self.arch)
+                    em = ev()
+                    em.record()
                     raw_f = ops.field_forward_split(self.packed, frame, 1, ops.FIELD_RADIANCE, rb, xw, src=src, out=self.ws.get(("raw", N, nc + nf)), arch=self.arch)
+                    if self.record:
+                        self.radiance_events.append((em, e3, N * (nc + nf)))
                 else:
                     z_f = ops.resample(z_c, wts, nf, u=u)
                     e2.record()
@@ -203,12 +218,26 @@ class HipRenderer:
         achieved = samples * self.flop_per_sample / (field_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[self.precision_name]
         traffic, src = TRAFFIC.get(self.precision_name, (None, None))
+        dominant = None
+        if self.radiance_events:      # the one kernel that is 59 % of the frame, priced on ITS OWN algorithmic FLOPs (the radiance net's 757,760 MAC)
+            rms = sum(a.elapsed_time(b) for a, b, _ in self.radiance_events)
+            rfl = sum(p for _, _, p in self.radiance_events) * 2 * self.ops.executed_macs_per_sample(self.arch, self.prec, 2)
+            alg = {"audio": 2 * 757_760}.get(self.arch)
+            dominant = {"kernel": "field_forward_f32_kernel<false, 2> (radiance net over the fine samples of a ray chunk)",
+                        "avg_launch_ms": rms / len(self.radiance_events), "executed_tflops": rfl / (rms * 1e-3) / 1e12,
+                        "frac_executed": rfl / (rms * 1e-3) / 1e12 / peak}
+            if alg is not None:
+                dominant["achieved"] = sum(p for _, _, p in self.radiance_events) * alg / (rms * 1e-3) / 1e12
+                dominant["frac"] = dominant["achieved"] / peak
         return {"bound": "mfma", "kernel": KERNEL[self.precision_name], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic, "traffic_source": None if src is None else src + " (static: rocprofv3 --pmc "
                 "passes of this command, per fine launch; bench.py cannot collect PMCs)", "launches": len(self.field_events),
                 "avg_launch_ms": field_ms / max(1, len(self.field_events)), "flop_per_sample": self.flop_per_sample,
                 "flop_per_sample_executed": self.exec_flop_per_sample,
-                "shared_deformation": self.split,
+                "shared_deformation": self.split, "dominant_kernel": dominant,
+                "note": ("achieved counts the reference's algorithmic FLOPs (1,855,744 per sample evaluation) of the field launches over their time; with "
+                         "shared_deformation the fine pass skips the reference's redundant second evaluation of the deformation nets at the coarse "
+                         "depths, so frac can exceed frac_executed (the instructions actually issued) by more than the constant folding alone") if self.split else None,
                 "frac_executed": (samples / (2 * self.nc + self.nf)) * self.exec_flop_per_ray / (field_ms * 1e-3) / 1e12 / peak,
                 "field_time_share": field_ms * 1e-3 / dt}
 
@@ -239,6 +268,7 @@ def measure(pkg, dev, size, precision, steps, warmup, arch="audio", num_fine=Non
     def roofline(dt):
         per_step = len(r.field_events) // (steps + warmup)
         r.field_events = r.field_events[-steps * per_step:]        # the timed region's launches only
+        r.radiance_events = r.radiance_events[-steps * (len(r.radiance_events) // (steps + warmup)):] if r.radiance_events else []
         return r.roofline(dt)
 
     with torch.no_grad():
