@@ -145,8 +145,8 @@ class HipRenderer:
         self.prec = self.model.precision
         self.packed, _ = self.model.packed()
         self.flop_per_sample = FLOP_PER_SAMPLE[arch]
-        # fp32: the deformation nets are evaluated once per depth (sahs_model_field_forward_split), as the drop-in driver does
-        self.split = precision == "fp32" and share_deformation
+        # the deformation nets are evaluated once per depth (sahs_model_field_forward_split), as the drop-in driver does
+        self.split = share_deformation and (precision == "fp32" or (precision == "bf16" and arch == "audio")) and arch != "nerface_static"
         ex = lambda part: 2 * self.ops.executed_macs_per_sample(arch, self.prec, part)
         self.exec_flop_per_sample = ex(0)
         # executed FLOPs per RAY: coarse = nc whole-network evaluations; fine = nf deformation + (nc + nf) radiance evaluations when split
@@ -181,7 +181,7 @@ class HipRenderer:
                     xw = self.ws[key] = torch.empty(N, nc + nf, 8, dtype=torch.float32, device=dev)
             e0.record()
             if split:
-                raw = ops.field_forward_split(self.packed, frame, 0, ops.FIELD_ALL, rb, xw, z=z_c, out=self.ws.get(("raw", N, nc)), arch=self.arch)
+                raw = ops.field_forward_split(self.packed, frame, 0, ops.FIELD_ALL, rb, xw, z=z_c, out=self.ws.get(("raw", N, nc)), arch=self.arch, precision=self.prec)
             else:
                 raw = ops.field_forward(self.packed, frame, 0, rb, z_c, precision=self.prec, out=self.ws.get(("raw", N, nc)), arch=self.arch)
             e1.record()
@@ -193,10 +193,10 @@ class HipRenderer:
                 if split:
                     z_f, z_new, src = ops.resample_merge(z_c, wts, nf, u=u)
                     e2.record()
-                    ops.field_forward_split(self.packed, frame, 1, ops.FIELD_DEFORM, rb, xw, z=z_new, xw_col0=nc, arch=self.arch)
+                    ops.field_forward_split(self.packed, frame, 1, ops.FIELD_DEFORM, rb, xw, z=z_new, xw_col0=nc, arch=self.arch, precision=self.prec)
                     em = ev()
                     em.record()
-                    raw_f = ops.field_forward_split(self.packed, frame, 1, ops.FIELD_RADIANCE, rb, xw, src=src, out=self.ws.get(("raw", N, nc + nf)), arch=self.arch)
+                    raw_f = ops.field_forward_split(self.packed, frame, 1, ops.FIELD_RADIANCE, rb, xw, src=src, out=self.ws.get(("raw", N, nc + nf)), arch=self.arch, precision=self.prec)
                     if self.record:
                         self.radiance_events.append((em, e3, N * (nc + nf)))
                 else:
@@ -223,7 +223,7 @@ class HipRenderer:
             rms = sum(a.elapsed_time(b) for a, b, _ in self.radiance_events)
             rfl = sum(p for _, _, p in self.radiance_events) * 2 * self.ops.executed_macs_per_sample(self.arch, self.prec, 2)
             alg = {"audio": 2 * 757_760}.get(self.arch)
-            dominant = {"kernel": "field_forward_f32_kernel<false, 2> (radiance net over the fine samples of a ray chunk)",
+            dominant = {"kernel": ("field_forward_f32_kernel<false, 2>" if self.precision_name == "fp32" else "field_forward_bf16w_kernel<2>") + " (radiance net over the fine samples of a ray chunk)",
                         "avg_launch_ms": rms / len(self.radiance_events), "executed_tflops": rfl / (rms * 1e-3) / 1e12,
                         "frac_executed": rfl / (rms * 1e-3) / 1e12 / peak}
             if alg is not None:

@@ -196,14 +196,15 @@ int sahs_resample_merge(long N, int S, int nf, const float *z, const float *weig
  * repeats the deformation of every coarse sample.  mode 0: the whole network for (N,S) depths z, also writing [x'0 x'1 x'2 w0 w1 . . .]
  * of every sample to xw[ray][xw_col0 + s] (xw: (N, xw_row, 8) floats); mode 1: the deformation nets only (raw unused); mode 2: the
  * radiance net of `level` only, for S samples per ray whose (x', w) are xw[ray][src[ray][s]] (z unused).  Same arithmetic on the same
- * operands as sahs_model_field_forward: bit-identical raw.  fp32; not for SAHS_MODEL_NERFACE_STATIC (no deformation nets). */
-int sahs_model_field_forward_split(int model, const void *packed, const float *frame, int level, int mode, long N, int S, const float *rays,
+ * operands as sahs_model_field_forward: bit-identical raw.  SAHS_F32 for the models with deformation nets (not SAHS_MODEL_NERFACE_STATIC);
+ * SAHS_BF16 for SAHS_MODEL_AUDIO (packed from sahs_pack_weights(..., SAHS_BF16, ...)). */
+int sahs_model_field_forward_split(int model, const void *packed, const float *frame, int precision, int level, int mode, long N, int S, const float *rays,
                                    int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src,
                                    void *stream);
 
 /* sahs_model_render_rays writing rows[r * row_ld + column] instead of eight dense arrays (row_ld >= 36; columns 17..33 are
  * left untouched when nf == 0).  Workspace and draws as sahs_render_rays.  Optional extra workspace xw (N,Sc+nf,8) floats, src
- * (N,Sc+nf) int32, z_new (N,nf) floats: when all three are given (fp32, nf > 0) the chain evaluates the deformation nets once per
+ * (N,Sc+nf) int32, z_new (N,nf) floats: when all three are given (nf > 0; SAHS_F32, or SAHS_BF16 with SAHS_MODEL_AUDIO) the chain evaluates the deformation nets once per
  * depth (sahs_model_field_forward_split) -- 6 % less matrix work per frame, identical results. */
 int sahs_model_render_rays_rows(int model, const void *packed, const float *frame, int precision, long N, const float *rays,
                                 int ray_stride, int Sc, int nf, int lindisp, int white_background, const float *bg, const float *t_rand,

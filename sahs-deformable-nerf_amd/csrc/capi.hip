@@ -24,6 +24,9 @@ int sahs_field_forward_bf16w_launch(const float *packed, const float *frame, int
                                     const float *zvals, float *raw, float *dbg, int num_cu, hipStream_t stream);
 int sahs_field_forward_bf16_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                    const float *zvals, float *raw, float *dbg, int num_cu, hipStream_t stream);
+int sahs_field_forward_bf16w_split_launch(const float *packed, const float *frame, int level, int mode, long P, int S, const float *rays,
+                                          int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
+                                          int num_cu, hipStream_t stream);
 int sahs_fold_conditioning_launch(const float *flat, const float *audio, const float *pose, int pose_ld, float *frame, hipStream_t stream);
 int sahs_field_forward_f32_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                   const float *zvals, float *raw, float *dbg, float *actbuf, int num_cu, hipStream_t stream);
@@ -414,8 +417,9 @@ int sahs_model_render_rays(int model, const void *packed, const float *frame, in
 
 /* The split evaluation of the field (csrc/field_f32.hip, MODE): 0 whole network + x', w written to xw; 1 deformation nets only;
  * 2 radiance net only, x', w fetched from xw through src. */
-int sahs_model_field_forward_split(int model, const void *packed, const float *frame, int level, int mode, long N, int S, const float *rays,
-                                   int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src, void *stream)
+int sahs_model_field_forward_split(int model, const void *packed, const float *frame, int precision, int level, int mode, long N, int S,
+                                   const float *rays, int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0,
+                                   const int32_t *src, void *stream)
 {
     REQUIRE_MODEL(model, "sahs_model_field_forward_split");
     if (N == 0) return 0;
@@ -425,7 +429,12 @@ int sahs_model_field_forward_split(int model, const void *packed, const float *f
     REQUIRE((mode == 1 || raw) && (mode == 2 || z) && (mode != 2 || src), "sahs_model_field_forward_split(buffers of the mode)");
     REQUIRE(xw_col0 >= 0 && xw_row >= xw_col0 + (mode == 2 ? 0 : S) && ALIGNED16(xw) && ALIGNED16(packed) && ALIGNED16(frame) && (!raw || ALIGNED16(raw)),
             "sahs_model_field_forward_split(xw layout / alignment)");
-    int e = model == SAHS_MODEL_AUDIO
+    if (precision != SAHS_F32 && !(precision == SAHS_BF16 && model == SAHS_MODEL_AUDIO))
+        return fail(4, "sahs_model_field_forward_split: precision %s%ld is not built for this model", "", (long)precision);
+    int e = precision == SAHS_BF16
+                ? sahs_field_forward_bf16w_split_launch((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0,
+                                                        src, num_cus(), (hipStream_t)stream)
+            : model == SAHS_MODEL_AUDIO
                 ? sahs_field_forward_f32_split_launch((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0, src,
                                                       num_cus(), (hipStream_t)stream)
                 : sahs_field_forward_f32_split_launch_nf((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0,
@@ -456,7 +465,7 @@ int sahs_model_render_rays_rows(int model, const void *packed, const float *fram
     REQUIRE_MODEL(model, "sahs_model_render_rays_rows");
     if (N == 0) return 0;
     REQUIRE(rows && row_ld >= SAHS_ROW_COLUMNS, "sahs_model_render_rays_rows(rows)");
-    if (xw && src && z_new && nf > 0 && precision == SAHS_F32 && model != SAHS_MODEL_NERFACE_STATIC) {
+    if (xw && src && z_new && nf > 0 && ((precision == SAHS_F32 && model != SAHS_MODEL_NERFACE_STATIC) || (precision == SAHS_BF16 && model == SAHS_MODEL_AUDIO))) {
         // the deformation nets are shared by the two levels and the fine depths contain the coarse ones: evaluate them once per depth
         const char *who = "sahs_model_render_rays_rows";
         REQUIRE(packed && frame && rays && z_c && z_f && raw && weights && Sc + nf <= 256, who);
@@ -464,13 +473,13 @@ int sahs_model_render_rays_rows(int model, const void *packed, const float *fram
         hipStream_t st = (hipStream_t)stream;
         int e;
         if ((e = sahs_stratified_depths(N, Sc, rays, ray_stride, lindisp, t_rand, z_c, stream))) return e;
-        if ((e = sahs_model_field_forward_split(model, packed, frame, 0, 0, N, Sc, rays, ray_stride, z_c, raw, xw, Sf, 0, nullptr, stream))) return e;
+        if ((e = sahs_model_field_forward_split(model, packed, frame, precision, 0, 0, N, Sc, rays, ray_stride, z_c, raw, xw, Sf, 0, nullptr, stream))) return e;
         e = sahs_composite_forward_launch(N, Sc, raw, z_c, rays, ray_stride, noise_c, bg, white_background, rows + SAHS_ROW_RGB_C, rows + SAHS_ROW_DISP_C,
                                           rows + SAHS_ROW_ACC_C, weights, nullptr, nullptr, row_ld, row_ld, st);
         if (e) return hip_fail(who, e);
         if ((e = sahs_resample_merge(N, Sc, nf, z_c, weights, u, z_new, z_f, src, stream))) return e;
-        if ((e = sahs_model_field_forward_split(model, packed, frame, 1, 1, N, nf, rays, ray_stride, z_new, nullptr, xw, Sf, Sc, nullptr, stream))) return e;
-        if ((e = sahs_model_field_forward_split(model, packed, frame, 1, 2, N, Sf, rays, ray_stride, nullptr, raw, xw, Sf, 0, src, stream))) return e;
+        if ((e = sahs_model_field_forward_split(model, packed, frame, precision, 1, 1, N, nf, rays, ray_stride, z_new, nullptr, xw, Sf, Sc, nullptr, stream))) return e;
+        if ((e = sahs_model_field_forward_split(model, packed, frame, precision, 1, 2, N, Sf, rays, ray_stride, nullptr, raw, xw, Sf, 0, src, stream))) return e;
         e = sahs_composite_forward_launch(N, Sf, raw, z_f, rays, ray_stride, noise_f, bg, white_background, rows + SAHS_ROW_RGB_F, rows + SAHS_ROW_DISP_F,
                                           rows + SAHS_ROW_ACC_F, weights, rows + SAHS_ROW_DEPTH_F, rows + SAHS_ROW_W_BG, row_ld, row_ld, st);
         return e ? hip_fail(who, e) : 0;

@@ -30,6 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+enum { FIELD_ALL = 0, FIELD_DEFORM = 1, FIELD_RADIANCE = 2 };      // the kernel's MODE (same values as field_f32.hip / SAHS_FIELD_*)
 constexpr int NH = 2;                              // 32-sample halves per wave
 struct Blk { u32x4 s[NH][2]; };                    // 32 features of this lane's two samples: [half][k-step] bf16x8 fragments (as dwords)
 
@@ -85,11 +86,13 @@ struct Ctx {
     int lane, h, wave;
     const f32x4 *nx_src; f32x4 *nx_dst;   // the chunk being prefetched: this lane's first source granule, the LDS buffer
     uint32_t off;                   // halfword offset of the NEXT chunk to prefetch (uniform)
+    uint32_t wrap_at, wrap_to;      // the stream wraps for the next sample tile: whole network [0, STREAM_HW), deformation nets
+                                    // [0, T0), radiance nets [T0, STREAM_HW) (the kernel's MODE)
     uint32_t bias_addr;             // LDS byte address of this lane's first bias row (+4h rows)
 
     __device__ __forceinline__ void prepare(int hw, int b)
     {
-        if (off >= (uint32_t)STREAM_HW) off = 0;                   // the stream wraps for the next sample tile
+        if (off >= wrap_at) off = wrap_to;
         nx_src = reinterpret_cast<const f32x4 *>(stream + off) + lane;
         nx_dst = reinterpret_cast<f32x4 *>(lds + b * LDS_BUF_BYTES);
         off += (uint32_t)hw;
@@ -147,12 +150,18 @@ __device__ __forceinline__ f32x16 bias_as_c(const f32x4 (&t)[4])
 // v_max -> v_cvt_pk issued back to back stalls the wave's in-order issue on every result, and the next MFMA with it (tools/micro/
 // mfma_valu_overlap2.hip: one such unit per MFMA costs 15 %, two 74 %).  The 32 values of a tile (half U&1 .. see unit_of) therefore go
 // through a three-stage pipeline, one "tick" at a time, so that the instructions of one tick never depend on each other:
-//   tick T:   A(T)    m = v_T * slope                       (leaky only)
+//   tick T:   A(T)    m = v_{T,T+1} * slope                 (leaky only; T even, one packed multiply per pair)
 //             B(T-1)  r = max(v_{T-1}, m)    | max(v, 0) for relu | v for no activation
 //             C(T-2)  dword = cvt_pk_bf16(r_{T-3}, r_{T-2})   when T-2 is odd
-// 34 ticks convert a tile; they are dealt out over the MFMA slots of the following tile.
-struct PackState { float m[2]; float r[4]; };
+// 36 ticks convert a tile; they are dealt out over the MFMA slots of the following tile.
+struct PackState { f32x2 m2[2]; float r[4]; uint32_t d[2]; };
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 // value U (0..31): pair P = U>>1 (half P&1, accumulator registers 2(P>>1) + (U&1)) -> dword (P>>1)&3 of fragment [half][(P>>1)>>2]
+// ReLU layers (slope 0) take a shorter route: round first, clamp after -- bf16(max(v,0)) == max(bf16(v),0), and on bf16 BIT PATTERNS
+// max(.,0) is a signed 16-bit integer max (negative floats are negative integers), so one v_pk_max_i16 clamps a converted PAIR:
+// 1 instruction per value instead of 1.5 (two v_max_f32 + one v_cvt_pk per pair).
+//   tick T:   C'(T-2)  d = cvt_pk_bf16(v_{T-3}, v_{T-2})        when T-2 is odd
+//             D'(T-4)  dword = pk_max_i16(d, 0)                 when T-4 is odd
 template <int T>
 __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float slope, PackState &ps)
 {
@@ -160,21 +169,41 @@ __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float
     if (T == 0) asm volatile("" :: "v"(acc[0]), "v"(acc[1]));     // keep the chains alive, convert nothing
     return;
 #endif
-    if constexpr (T >= 0 && T < 32) {                       // A(T)
-        constexpr int P = T >> 1, hh = P & 1, q = P >> 1, e = T & 1;
-        if (slope != 0.0f && slope != 1.0f) ps.m[T & 1] = acc[hh][2 * q + e] * slope;
+#ifndef SAHS_BF16W_FP32_RELU
+    if (slope == 0.0f) {
+        if constexpr (T - 2 >= 1 && T - 2 < 32 && ((T - 2) & 1)) {
+            constexpr int U = T - 2, P = U >> 1, hh = P & 1, q = P >> 1;
+            ps.d[P & 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{acc[hh][2 * q], acc[hh][2 * q + 1]}, bf16x2));
+        }
+        if constexpr (T - 4 >= 1 && T - 4 < 32 && ((T - 4) & 1)) {
+            constexpr int U = T - 4, P = U >> 1, hh = P & 1, q = P >> 1, s = q >> 2, jp = q & 3;
+            o.s[hh][s][jp] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ps.d[P & 1]), s16x2{0, 0}));
+        }
+        return;
+    }
+#endif
+    if constexpr (T >= 0 && T < 32 && !(T & 1)) {           // A(T), T even: both values of the pair in one v_pk_mul_f32
+        constexpr int P = T >> 1, hh = P & 1, q = P >> 1;
+        if (slope != 0.0f && slope != 1.0f) {
+            const f32x2 pr = f32x2{acc[hh][2 * q], acc[hh][2 * q + 1]}, sl = f32x2{slope, slope};
+#ifdef SAHS_BF16W_PKMUL     // measured SLOWER (23.6 vs 22.3 ms per fine launch) although it halves the multiplies: kept as an experiment
+            asm("v_pk_mul_f32 %0, %1, %2" : "=v"(ps.m2[P & 1]) : "v"(pr), "v"(sl));
+#else
+            ps.m2[P & 1] = pr * sl;      // the compiler scalarises this into two v_mul_f32
+#endif
+        }
     }
     if constexpr (T - 1 >= 0 && T - 1 < 32) {               // B(T-1)
         constexpr int U = T - 1, P = U >> 1, hh = P & 1, q = P >> 1, e = U & 1;
         const float v = acc[hh][2 * q + e];
-        ps.r[U & 3] = slope == 1.0f ? v : (slope == 0.0f ? fmaxf(v, 0.0f) : fmaxf(v, ps.m[U & 1]));
+        ps.r[U & 3] = slope == 1.0f ? v : (slope == 0.0f ? fmaxf(v, 0.0f) : fmaxf(v, ps.m2[P & 1][e]));
     }
     if constexpr (T - 2 >= 1 && T - 2 < 32 && ((T - 2) & 1)) {    // C(T-2): the pair (T-3, T-2) is complete
         constexpr int U = T - 2, P = U >> 1, hh = P & 1, q = P >> 1, s = q >> 2, jp = q & 3;
         o.s[hh][s][jp] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ps.r[(U - 1) & 3], ps.r[U & 3]}, bf16x2));
     }
 }
-constexpr int PACK_TICKS = 34;
+constexpr int PACK_TICKS = 36;
 template <int LO, int HI>
 __device__ __forceinline__ void pack_ticks(const f32x16 (&acc)[NH], Blk &o, float slope, PackState &ps)
 {
@@ -424,11 +453,20 @@ __device__ __forceinline__ void grid_block_w(const float *__restrict__ grid, flo
 
 #define CH(id) (kProgH.layer[id].G32 * kProgH.layer[id].KB32 * 1024)   /* halfwords in one chunk of layer id */
 
+// MODE (the split evaluation of field_f32.hip, same contract): FIELD_ALL = whole network, additionally writing x', w of every sample
+// to xw when xw != nullptr; FIELD_DEFORM = warp + hyper nets only, on the depths zvals, results to xw columns xw_col0..; FIELD_RADIANCE =
+// radiance nets only, (x', w) of sample p read from xw column src[p].  xw: (rays, xw_row, 8) floats [x'0 x'1 x'2 w0 w1 . . .].
+template <int MODE>
 __global__ void __launch_bounds__(W_THREADS, 1)
 field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__restrict__ frame, int level, long P, int S,
                            const float *__restrict__ rays, int ray_stride, const float *__restrict__ zvals,
-                           float *__restrict__ raw, float *__restrict__ dbg)
+                           float *__restrict__ raw, float *__restrict__ dbg, float *__restrict__ xw, int xw_row, int xw_col0,
+                           const int *__restrict__ src)
 {
+    constexpr uint32_t RAD_OFF = (uint32_t)kProgH.layer[H_T0].stream_off;      // first radiance-net chunk
+    constexpr int L_FIRST = MODE == FIELD_RADIANCE ? H_T0 : H_W0;               // the launch's first layer
+    constexpr int AFTER_DEFORM = MODE == FIELD_DEFORM ? H_W0 : H_T0;            // the chunk prefetched under the last deformation layer
+    constexpr int AFTER_RADIANCE = MODE == FIELD_RADIANCE ? H_T0 : H_W0;        // ... under the last radiance layer
     extern __shared__ __attribute__((aligned(16))) char lds_w[];
     Ctx cx;
     cx.stream = reinterpret_cast<const unsigned short *>(packed + PACKH_STREAM_OFF) + (long)level * STREAM_HW;
@@ -443,10 +481,12 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
         const float *bsrc = frame + FRAME_BIAS_OFF + level * BIAS_FLOATS;
         float *bl = reinterpret_cast<float *>(lds_w + LDS_BIAS_BYTE_OFF);
         for (int i = threadIdx.x; i < BIAS_FLOATS; i += W_THREADS) bl[i] = bsrc[i];
-        cx.off = 0;
-        cx.prepare(CH(H_W0), 0);
+        cx.wrap_at = MODE == FIELD_DEFORM ? RAD_OFF : (uint32_t)STREAM_HW;
+        cx.wrap_to = MODE == FIELD_RADIANCE ? RAD_OFF : 0u;
+        cx.off = cx.wrap_to;
+        cx.prepare(CH(L_FIRST), 0);
 #pragma unroll
-        for (int pc = 0; pc < (CH(H_W0) + PIECE_HW - 1) / PIECE_HW; ++pc) cx.issue_piece(pc);
+        for (int pc = 0; pc < (CH(L_FIRST) + PIECE_HW - 1) / PIECE_HW; ++pc) cx.issue_piece(pc);
         __syncthreads();
     }
     constexpr const LayerH *Ly = kProgH.layer;
@@ -466,11 +506,24 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
             constexpr int hh = decltype(Q)::value;
             p_raw[hh] = tile * W_PTS_PER_WG + cx.wave * W_PTS_PER_WAVE + hh * 32 + col;
             p[hh] = p_raw[hh] < P ? p_raw[hh] : P - 1;
-            const float *rp = rays + (p[hh] / S) * ray_stride;
-            const float z = zvals[p[hh]];
+            if constexpr (MODE != FIELD_RADIANCE) {
+                const float *rp = rays + (p[hh] / S) * ray_stride;
+                const float z = zvals[p[hh]];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) x[hh][i] = rp[i] + rp[3 + i] * z;
+                for (int i = 0; i < 3; ++i) x[hh][i] = rp[i] + rp[3 + i] * z;
+            }
         });
+        if constexpr (MODE == FIELD_RADIANCE) {     // x', w come from the launches that deformed these samples
+            if (h == 0) {
+                for_halves([&](auto Q) {
+                    constexpr int q = decltype(Q)::value;
+                    const float *row = xw + ((p[q] / S) * (long)xw_row + src[p[q]]) * 8;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(row);
+                    stash(q)[0] = v[0]; stash(q)[1] = v[1]; stash(q)[2] = v[2]; stash(q)[3] = v[3];
+                    stash(q)[4] = row[4];
+                });
+            }
+        } else {
         Blk pe_x[2];
         pe_blocks_w<3, 10, 2>(x, h, pe_x);
         {   // warp field (layers alternate between two register sets: no activation copies)
@@ -501,7 +554,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
             dense_w<2, 2, 0, 2, CH(H_H5), true>(cx, st, B, pe_x, nullptr, A, Ly[H_H4].bias_off, 0.0f, 0.0f);
             dense_w<2, 0, 0, 2, CH(H_HF), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H5].bias_off, 0.0f, 0.0f);
             f32x16 o[NH];
-            dense_w_out<2, CH(H_T0)>(cx, st, B, o, Ly[H_HF].bias_off, true, 0.0f);
+            dense_w_out<2, CH(AFTER_DEFORM)>(cx, st, B, o, Ly[H_HF].bias_off, true, 0.0f);
             if (h == 0) {
                 for_halves([&](auto Q) {
                     constexpr int q = decltype(Q)::value;
@@ -510,8 +563,19 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                 });
             }
         }
+        if (xw != nullptr && h == 0) {      // hand x', w to the fine pass (the lane that wrote the stash reads it back: no barrier needed)
+            for_halves([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                if (p_raw[q] < P) {
+                    float *row = xw + ((p[q] / S) * (long)xw_row + xw_col0 + (p[q] % S)) * 8;
+                    *reinterpret_cast<f32x4 *>(row) = f32x4{stash(q)[0], stash(q)[1], stash(q)[2], stash(q)[3]};
+                    *reinterpret_cast<f32x4 *>(row + 4) = f32x4{stash(q)[4], 0.0f, 0.0f, 0.0f};
+                }
+            });
+        }
+        }
         __builtin_amdgcn_wave_barrier();
-        if (dbg != nullptr && h == 0) {
+        if (dbg != nullptr && h == 0 && MODE != FIELD_RADIANCE) {
             for_halves([&](auto Q) {
                 constexpr int q = decltype(Q)::value;
                 if (p_raw[q] < P) {
@@ -521,6 +585,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                 }
             });
         }
+        if constexpr (MODE == FIELD_DEFORM) continue;
         // radiance trunk (two 256-wide register sets A, B alternate; feat ends up in A)
         Blk A[8];
         f32x16 fin[NH];
@@ -589,7 +654,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
             dense_w<4, 0, 0, 4, CH(H_S1), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S1].bias_off, 0.01f, 0.01f);
             dense_w<4, 0, 0, 4, CH(H_S1), true>(cx, st, sn, nullptr, nullptr, s, Ly[H_S1].bias_off + 128, 0.01f, 0.01f);
             dense_w<4, 0, 0, 4, CH(H_SEG), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S3].bias_off, 0.01f, 0.01f);
-            dense_w_out<4, CH(H_W0)>(cx, st, sn, fin, 0, false, 0.01f);
+            dense_w_out<4, CH(AFTER_RADIANCE)>(cx, st, sn, fin, 0, false, 0.01f);
         }
         for_halves([&](auto Q) {
             constexpr int q = decltype(Q)::value;
@@ -607,18 +672,41 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
 using namespace sahs;
 using namespace sahs::hw;
 
-extern "C" int sahs_field_forward_bf16w_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays,
-                                               int ray_stride, const float *zvals, float *raw, float *dbg, int num_cu,
-                                               hipStream_t stream)
+template <int MODE>
+static int launch_w(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride, const float *zvals,
+                    float *raw, float *dbg, float *xw, int xw_row, int xw_col0, const int *src, int num_cu, hipStream_t stream)
 {
     if (P <= 0) return 0;
     const long ntiles = (P + W_PTS_PER_WG - 1) / W_PTS_PER_WG;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
-    static sahs_once::Flags attr_set;       // the large-LDS attribute is per device
+    static sahs_once::Flags attr_set;       // the large-LDS attribute is per device (and per kernel instance)
     hipError_t ae = sahs_once::per_device(attr_set, [&]() {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_bf16w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_bf16w_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     });
     if (ae != hipSuccess) return (int)ae;
-    field_forward_bf16w_kernel<<<grid, W_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg);
+    field_forward_bf16w_kernel<MODE><<<grid, W_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, xw, xw_row,
+                                                                            xw_col0, src);
     return (int)hipGetLastError();
+}
+
+extern "C" int sahs_field_forward_bf16w_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays,
+                                               int ray_stride, const float *zvals, float *raw, float *dbg, int num_cu,
+                                               hipStream_t stream)
+{
+    return launch_w<FIELD_ALL>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, nullptr, 0, 0, nullptr, num_cu, stream);
+}
+
+// the split evaluation (field_f32.hip: sahs_field_forward_f32_split_launch, same arguments)
+extern "C" int sahs_field_forward_bf16w_split_launch(const float *packed, const float *frame, int level, int mode, long P, int S,
+                                                     const float *rays, int ray_stride, const float *zvals, float *raw, float *xw, int xw_row,
+                                                     int xw_col0, const int *src, int num_cu, hipStream_t stream)
+{
+    switch (mode) {
+    case FIELD_ALL:
+        return launch_w<FIELD_ALL>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, nullptr, xw, xw_row, xw_col0, nullptr, num_cu, stream);
+    case FIELD_DEFORM:
+        return launch_w<FIELD_DEFORM>(packed, frame, level, P, S, rays, ray_stride, zvals, nullptr, nullptr, xw, xw_row, xw_col0, nullptr, num_cu, stream);
+    default:
+        return launch_w<FIELD_RADIANCE>(packed, frame, level, P, S, rays, ray_stride, nullptr, raw, nullptr, xw, xw_row, 0, src, num_cu, stream);
+    }
 }

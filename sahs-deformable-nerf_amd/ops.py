@@ -176,7 +176,7 @@ def resample_merge(z, weights, num_fine, u=None):
 FIELD_ALL, FIELD_DEFORM, FIELD_RADIANCE = 0, 1, 2
 
 
-def field_forward_split(packed, frame, level, mode, rays, xw, z=None, src=None, xw_col0=0, out=None, arch="audio"):
+def field_forward_split(packed, frame, level, mode, rays, xw, z=None, src=None, xw_col0=0, out=None, arch="audio", precision=SAHS_F32):
     """The field in parts (include/sahs_nerf.h: sahs_model_field_forward_split).  xw: (N, row, 8) fp32 buffer of deformed points.
     FIELD_ALL: raw (N,S,16) for depths z, x'/w of its samples written to xw[:, xw_col0:xw_col0+S]; FIELD_DEFORM: only x'/w for depths z;
     FIELD_RADIANCE: raw for the samples xw[ray, src[ray, s]] (src (N,S) int32)."""
@@ -191,7 +191,7 @@ def field_forward_split(packed, frame, level, mode, rays, xw, z=None, src=None, 
     if mode != FIELD_DEFORM:
         raw = out if out is not None else torch.empty(N, S, 16, dtype=torch.float32, device=rays.device)
     f, name = _fn("field_forward_split", arch)
-    check(f(_p(packed), _p(frame), int(level), int(mode), N, int(S), _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(xw), int(xw.shape[1]), int(xw_col0),
+    check(f(_p(packed), _p(frame), int(precision), int(level), int(mode), N, int(S), _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(xw), int(xw.shape[1]), int(xw_col0),
             _p(src), _stream()), name)
     return raw
 
@@ -260,7 +260,7 @@ def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=
                      t_rand=None, noise_c=None, u=None, noise_f=None, workspace=None, arch="audio", share_deformation=True):
     """predict_and_render_radiance for one ray chunk, written IN PLACE into ``rows`` (N, 36): the 8-tuple of every ray side by
     side (a row block of the frame's (R, 36) buffer, which is also what the multi-GPU all-gather moves), so a chunk loop needs
-    no per-chunk concatenation.  Returns ``rows``.  share_deformation (fp32): evaluate the deformation nets once per depth -- the fine
+    no per-chunk concatenation.  Returns ``rows``.  share_deformation (fp32; bf16 for the audio model): evaluate the deformation nets once per depth -- the fine
     pass reuses the coarse samples' deformed points instead of recomputing them as the reference does; identical results."""
     packed, frame, rays = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays")
     bg, t_rand, noise_c, u, noise_f = (_req(t, n) for t, n in ((bg, "background_prior"), (t_rand, "t_rand"), (noise_c, "noise_c"),
@@ -283,7 +283,7 @@ def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=
     z_c, z_f = buf("z_c", N, num_coarse), buf("z_f", N, Sf)
     raw, weights = buf("raw", N, Sf, 16), buf("weights", N, Sf)
     xw = src = z_new = None
-    if share_deformation and num_fine > 0 and precision == SAHS_F32 and arch != "nerface_static":
+    if share_deformation and num_fine > 0 and ((precision == SAHS_F32 and arch != "nerface_static") or (precision == SAHS_BF16 and arch == "audio")):
         # extra workspace of the split evaluation: deformed points of every depth, the merge permutation, the new depths
         xw, z_new = buf("xw", N, Sf, 8), buf("z_new", N, num_fine)
         src = ws.get("src")

@@ -417,17 +417,20 @@ def test_partition_invariant_render(flat_weights):
     assert not torch.equal(full[3], other[3])
 
 
-@pytest.mark.parametrize("arch,N,nf", [("audio", 300, 64), ("audio", 77, 128), ("nerface", 130, 64)])
-def test_shared_deformation_is_bit_identical(arch, N, nf, weights_mod):
+@pytest.mark.parametrize("arch,N,nf,precision", [("audio", 300, 64, "fp32"), ("audio", 77, 128, "fp32"), ("nerface", 130, 64, "fp32"),
+                                                  ("audio", 300, 64, "bf16"), ("audio", 5, 128, "bf16")])
+def test_shared_deformation_is_bit_identical(arch, N, nf, precision, weights_mod):
     """The split evaluation (deformation nets once per depth: the fine pass reuses the coarse samples' deformed points through the
     merge permutation) against the plain chain that evaluates the whole network for every fine sample, as the reference does:
-    all 36 outputs per ray bit for bit, ragged ray counts, both fine-pass lengths, both deforming architectures."""
+    all 36 outputs per ray bit for bit, ragged ray counts, both fine-pass lengths, both deforming architectures, and the bf16 kernel
+    (same three-launch chain, field_bf16w.hip)."""
     sahs, ops = pkg(), pkg("ops")
+    prec = ops.PRECISIONS[precision]
     d = dev()
     model_name = "audio" if arch == "audio" else "nerface"
     fw = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 2.0, 30.0, model=model_name, hdr=(arch == "audio")), model=model_name)
     flat = T(fw)
-    packed = ops.pack_weights(flat, arch=arch)
+    packed = ops.pack_weights(flat, prec, arch=arch)
     g = torch.Generator(device=d).manual_seed(N + nf)
     drv = torch.randn(16, 29, device=d, generator=g) if arch == "audio" else torch.randn(76, device=d, generator=g) * 0.5
     cam = 0.8 if arch == "audio" else 0.5
@@ -445,12 +448,12 @@ def test_shared_deformation_is_bit_identical(arch, N, nf, weights_mod):
     for share in (False, True):
         rows = torch.full((N, 36), float("nan"), device=d)
         ws = {}
-        ops.render_rays_rows(packed, frame, rays, 64, nf, rows, bg=bg, t_rand=t_rand, u=u, workspace=ws, arch=arch, share_deformation=share)
+        ops.render_rays_rows(packed, frame, rays, 64, nf, rows, precision=prec, bg=bg, t_rand=t_rand, u=u, workspace=ws, arch=arch, share_deformation=share)
         out[share] = (rows, ws["z_f"].clone(), ws["raw"].clone())
         assert ("xw" in ws) == share
     for a, b, nm in zip(out[False], out[True], ("rows", "z_fine", "raw_fine")):
         assert bool(torch.isfinite(a).all()), nm
         assert torch.equal(a, b), "%s differs between the plain and the shared-deformation chain (max %.3e)" % (nm, float((a - b).abs().max()))
     # and the 8-tuple entry point (plain chain) agrees with the row block
-    tup = ops.render_rays(packed, frame, rays, 64, nf, bg=bg, t_rand=t_rand, u=u, arch=arch)
+    tup = ops.render_rays(packed, frame, rays, 64, nf, precision=prec, bg=bg, t_rand=t_rand, u=u, arch=arch)
     assert torch.equal(pkg("distributed").pack_outputs(tup), out[True][0])
