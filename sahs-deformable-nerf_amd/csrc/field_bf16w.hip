@@ -89,6 +89,17 @@ struct Ctx {
     uint32_t wrap_at, wrap_to;      // the stream wraps for the next sample tile: whole network [0, STREAM_HW), deformation nets
                                     // [0, T0), radiance nets [T0, STREAM_HW) (the kernel's MODE)
     uint32_t bias_addr;             // LDS byte address of this lane's first bias row (+4h rows)
+#ifdef SAHS_STAMP_W
+    // diagnostic build only (tools/stamp_bf16w.py): s_memtime stamps of wave 0 of workgroup 0 for one sample tile, written to the dbg
+    // buffer (which the normal dbg writes then leave alone); no output value is computed from them
+    unsigned long long *stamps; int sidx; bool stamp_on;
+    __device__ __forceinline__ void stamp()
+    {
+        if (stamp_on) { if (lane == 0) stamps[sidx] = __builtin_amdgcn_s_memtime(); ++sidx; }
+    }
+#else
+    __device__ __forceinline__ void stamp() {}
+#endif
 
     __device__ __forceinline__ void prepare(int hw, int b)
     {
@@ -109,7 +120,11 @@ struct Ctx {
     __device__ __forceinline__ void begin_chunk(int next_hw) { prepare(next_hw, buf ^ 1); }
     __device__ __forceinline__ void end_chunk()
     {
+#ifdef SAHS_X_NOBARRIER             // timing-only experiment (results wrong by construction)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         __syncthreads();            // vmcnt(0) (the next chunk has landed) + barrier (every wave is done with this one)
+#endif
         buf ^= 1;
     }
     __device__ __forceinline__ uint32_t cur_addr() const { return lds_addr_of(lds + buf * LDS_BUF_BYTES) + 16 * lane; }
@@ -169,6 +184,12 @@ __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float
     if (T == 0) asm volatile("" :: "v"(acc[0]), "v"(acc[1]));     // keep the chains alive, convert nothing
     return;
 #endif
+#ifdef SAHS_X_SLOPE1                // timing-only experiments (results wrong by construction)
+    slope = 1.0f;
+#endif
+#ifdef SAHS_X_EXTRAVALU
+    if constexpr (T >= 0 && T < 32) { float dmy; asm volatile("v_max_f32 %0, %1, %1" : "=v"(dmy) : "v"(acc[0][T & 15])); }
+#endif
 #ifndef SAHS_BF16W_FP32_RELU
     if (slope == 0.0f) {
         if constexpr (T - 2 >= 1 && T - 2 < 32 && ((T - 2) & 1)) {
@@ -193,13 +214,14 @@ __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float
 #endif
         }
     }
-    if constexpr (T - 1 >= 0 && T - 1 < 32) {               // B(T-1)
-        constexpr int U = T - 1, P = U >> 1, hh = P & 1, q = P >> 1, e = U & 1;
+    constexpr int DB = 1, DC = 2;       // stage distances in ticks (2 and 4 measured: no change, 46.1-48.2 vs 46.9-48.0 cycles per MFMA)
+    if constexpr (T - DB >= 0 && T - DB < 32) {             // B(T-1)
+        constexpr int U = T - DB, P = U >> 1, hh = P & 1, q = P >> 1, e = U & 1;
         const float v = acc[hh][2 * q + e];
         ps.r[U & 3] = slope == 1.0f ? v : (slope == 0.0f ? fmaxf(v, 0.0f) : fmaxf(v, ps.m2[P & 1][e]));
     }
-    if constexpr (T - 2 >= 1 && T - 2 < 32 && ((T - 2) & 1)) {    // C(T-2): the pair (T-3, T-2) is complete
-        constexpr int U = T - 2, P = U >> 1, hh = P & 1, q = P >> 1, s = q >> 2, jp = q & 3;
+    if constexpr (T - DC >= 1 && T - DC < 32 && ((T - DC) & 1)) {    // C(T-2): the pair (T-3, T-2) is complete
+        constexpr int U = T - DC, P = U >> 1, hh = P & 1, q = P >> 1, s = q >> 2, jp = q & 3;
         o.s[hh][s][jp] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ps.r[(U - 1) & 3], ps.r[U & 3]}, bf16x2));
     }
 }
@@ -286,7 +308,9 @@ __device__ __forceinline__ void dense_w(Ctx &cx, St &st, Blk *in0, const Blk *in
                 if constexpr (hh == 0) {
                     if constexpr (S::bias_at(I)) bias_read<128 * (t + 1)>(braw[set ^ 1], baddr);
                 } else {
+#ifndef SAHS_X_NOAREAD              // timing-only experiment: the A fragments of the prologue are reused (results wrong by construction)
                     if constexpr (S::aread_at(I)) lds_read16<(I + AP) * 1024>(a[I % AP], abase);
+#endif
                     if constexpr (I % PSTEP == 0 && I / PSTEP < npieces) cx.issue_piece(I / PSTEP);
                 }
                 if constexpr (t > 0 && k >= 1) {              // the finished tile t-1 -> out[t-1]: this slot's share of its conversion ticks
@@ -492,7 +516,19 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
     constexpr const LayerH *Ly = kProgH.layer;
 
     const long ntiles = (P + W_PTS_PER_WG - 1) / W_PTS_PER_WG;
+#ifdef SAHS_STAMP_W
+    unsigned long long *stamp_base = reinterpret_cast<unsigned long long *>(dbg);
+    dbg = nullptr;
+    int tile_no = 0;
+#endif
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef SAHS_STAMP_W
+        cx.stamp_on = stamp_base != nullptr && blockIdx.x == 0 && tile_no == 3 && cx.wave == 0;
+        cx.stamps = stamp_base;
+        cx.sidx = 0;
+        ++tile_no;
+#endif
+        cx.stamp();                                   // 0 tile start
         cx.refresh_bias_base();
         St st;
         // this lane's two samples: halves hh = 0, 1 -> sample (wave*64 + hh*32 + col) of the workgroup tile
@@ -526,6 +562,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
         } else {
         Blk pe_x[2];
         pe_blocks_w<3, 10, 2>(x, h, pe_x);
+        cx.stamp();                                   // 1 sample points + PE(x)
         {   // warp field (layers alternate between two register sets: no activation copies)
             Blk A[4], B[4];
             dense_w<2, 0, 0, 4, CH(H_W1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_W0].bias_off, 0.0f, 0.0f);
@@ -545,6 +582,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                 });
             }
         }
+        cx.stamp();                                   // 2 warp net
         {   // hyper sheet
             Blk A[2], B[2];
             dense_w<2, 0, 0, 2, CH(H_H1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_H0].bias_off, 0.0f, 0.0f);
@@ -575,6 +613,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
         }
         }
         __builtin_amdgcn_wave_barrier();
+        cx.stamp();                                   // 3 hyper net (RADIANCE: x', w fetched)
         if (dbg != nullptr && h == 0 && MODE != FIELD_RADIANCE) {
             for_halves([&](auto Q) {
                 constexpr int q = decltype(Q)::value;
@@ -601,10 +640,14 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                 });
                 pe_blocks_w<3, 10, 2>(xw, h, in_tr);
                 pe_blocks_w<2, 4, 1>(amb, h, in_tr + 2);
+                cx.stamp();                           // 4 PE(x'), PE(w)
                 dense_w<2, 1, 0, 8, CH(H_T1), false>(cx, st, in_tr, in_tr + 2, nullptr, A, Ly[H_T0].bias_off, 0.01f, 0.0f);
+                cx.stamp();                           // 5 T0
             }
             dense_w<8, 0, 0, 8, CH(H_T2), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T1].bias_off, 0.01f, 0.01f);
+            cx.stamp();                               // 6 T1
             dense_w<8, 0, 0, 8, CH(H_T3), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T2].bias_off, 0.01f, 0.01f);
+            cx.stamp();                               // 7 T2
             {   // the re-injected encoding [PE(x') | PE(w)] is rebuilt at the skip layer instead of staying live
                 Blk in_tr[3];
                 float xw[NH][3], amb[NH][3];
@@ -615,16 +658,24 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                 });
                 pe_blocks_w<3, 10, 2>(xw, h, in_tr);
                 pe_blocks_w<2, 4, 1>(amb, h, in_tr + 2);
+                cx.stamp();                           // 8 PE again
                 dense_w<8, 2, 1, 8, CH(H_T4), true>(cx, st, A, in_tr, in_tr + 2, B, Ly[H_T3].bias_off, 0.01f, 0.01f);
+                cx.stamp();                           // 9 T3 (skip)
             }
 #pragma unroll 1
             for (int j = 0; j < 2; ++j) {     // T4, T5 | T6, T7 (identical shapes: one copy of the code, run twice)
                 dense_w<8, 0, 0, 8, CH(H_T5), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T4].bias_off + 512 * j, 0.01f, 0.01f);
                 dense_w<8, 0, 0, 8, CH(H_T5), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T4].bias_off + 512 * j + 256, 0.01f, 0.01f);
+#ifdef SAHS_STAMP_W
+                if (j == 0) cx.stamp();               // (diagnostic only) first pass through the loop body: instruction-cache cold
+#endif
             }
+            cx.stamp();                               // 10 T4..T7
             dense_w<8, 0, 0, 8, CH(H_ALPHA), true>(cx, st, B, nullptr, nullptr, A, Ly[H_FEAT].bias_off, 1.0f, 0.01f);
+            cx.stamp();                               // 11 feat
         }
         dense_w_out<8, CH(H_D0)>(cx, st, A, fin, Ly[H_ALPHA].bias_off, true, 1.0f);
+        cx.stamp();                                   // 12 sigma
         {   // colour branch
             Blk in_d[2];
             {
@@ -641,6 +692,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                                  (dbg != nullptr && p_raw[q] < P) ? dbg + P * DBG_STRIDE_H + p[q] * 32 : nullptr);
                 });
             }
+            cx.stamp();                               // 13 PE(dir) + grid lookup
             Blk c[4], cn[4];
             dense_w<8, 1, 1, 4, CH(H_D1), false>(cx, st, A, in_d, in_d + 1, c, Ly[H_D0].bias_off, 0.01f, 0.0f);
             dense_w<4, 0, 0, 4, CH(H_D1), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D1].bias_off, 0.01f, 0.01f);
@@ -648,6 +700,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
             dense_w<4, 0, 0, 4, CH(H_RGB), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D3].bias_off, 0.01f, 0.01f);
             dense_w_out<4, CH(H_S0)>(cx, st, cn, fin, 0, false, 0.01f);
         }
+        cx.stamp();                                   // 14 colour branch
         {   // seg branch
             Blk s[4], sn[4];
             dense_w<8, 0, 0, 4, CH(H_S1), false>(cx, st, A, nullptr, nullptr, s, Ly[H_S0].bias_off, 0.01f, 0.0f);
@@ -656,6 +709,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
             dense_w<4, 0, 0, 4, CH(H_SEG), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S3].bias_off, 0.01f, 0.01f);
             dense_w_out<4, CH(AFTER_RADIANCE)>(cx, st, sn, fin, 0, false, 0.01f);
         }
+        cx.stamp();                                   // 15 seg branch
         for_halves([&](auto Q) {
             constexpr int q = decltype(Q)::value;
             if (p_raw[q] < P) {   // rows 4h..4h+3 and 8+4h..8+4h+3 of [rgb3 | seg12 | sigma]
@@ -663,6 +717,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                 *reinterpret_cast<f32x4 *>(raw + p_raw[q] * D_RAW + 8 + 4 * h) = f32x4{fin[q][4], fin[q][5], fin[q][6], fin[q][7]};
             }
         });
+        cx.stamp();                                   // 16 store
     }
 }
 
