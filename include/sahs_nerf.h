@@ -120,6 +120,22 @@ int sahs_field_backward(const float *flat_params, const float *frame, int level,
 int sahs_composite_backward(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
                             const float *bg, int white_background, const float *d_rgb, const float *d_disp, const float *d_acc,
                             const float *d_depth, const float *d_wlast, const float *d_weights, float *d_raw, void *stream);
+/* The Stage-I objective of train_stage_rays_auto.py:455-468 over one ray batch, with the loss modules of nerf_helpers.py:14-62
+ * (MaskMSELoss, MaskCrossEntropyLoss built with class_weights, :268-271):
+ *   loss = sum over the given levels of  mean l2 + 0.02 mean ce + 0.005 sum_{c in 7,8} (masked mean_c l2 + masked mean_c ce)
+ * map_coarse / map_fine (N,15) = the rendered [rgb3 | seg12] of a level (either may be NULL), target (N,target_ld >= 3), mask (N,12)
+ * one-hot.  stats (64 floats): [0] loss, [1] mean l2 of the last level given (the script's psnr input), [2:14] the new sample_prob
+ * (:466-468), [14:26] per-class ray counts (>= 1), [26] N.  One workgroup, fixed summation order. */
+#define SAHS_LOSS_STATS_WORDS 64
+int sahs_stage1_loss_forward(long N, const float *map_coarse, const float *map_fine, const float *target, int target_ld, const float *mask,
+                             const float *class_weights, float *stats, void *stream);
+/* sahs_composite_backward for a level whose rendered map enters that objective: the kernel forms d loss / d [rgb3 | seg12] of each ray
+ * itself from (loss_map = the level's forward output, target, mask, stats of sahs_stage1_loss_forward, *loss_gscale = d objective /
+ * d loss or NULL for 1) and adds it to d_rgb (may be NULL), so the (N,15) gradient never exists in memory. */
+int sahs_composite_backward_loss(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
+                                 const float *bg, int white_background, const float *d_rgb, const float *d_disp, const float *d_acc,
+                                 const float *d_depth, const float *d_wlast, const float *loss_map, const float *loss_target, int target_ld,
+                                 const float *loss_mask, const float *loss_stats, const float *loss_gscale, float *d_raw, void *stream);
 /* grad_cond[0:76] -> AudioNet parameter gradients in grad_flat (+=) and, optionally, grad_audio (16,29) (+=). */
 int sahs_conditioning_backward(const float *flat_params, const float *audio, const float *grad_cond, float *grad_flat,
                                float *grad_audio, void *stream);

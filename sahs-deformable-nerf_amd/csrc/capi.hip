@@ -15,9 +15,13 @@ int sahs_pack_weights_bf16_launch(const float *flat, float *packed, hipStream_t 
 long sahs_field_backward_ws_words(long P);
 int sahs_field_backward_launch(const float *flat, const float *frame, int level, long P, const float *actbuf, const float *d_raw,
                                float *grad_flat, float *grad_cond, float *ws, hipStream_t stream);
+int sahs_stage1_loss_forward_launch(long N, const float *map_c, const float *map_f, const float *target, int target_ld, const float *mask,
+                                    const float *class_w, float *stats, hipStream_t stream);
 int sahs_composite_backward_launch(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
                                    const float *bg, int white_bkgd, const float *d_rgb, const float *d_disp, const float *d_acc,
-                                   const float *d_depth, const float *d_wlast, const float *d_weights, float *d_raw, hipStream_t stream);
+                                   const float *d_depth, const float *d_wlast, const float *d_weights, float *d_raw, const float *loss_map,
+                                   const float *loss_target, int target_ld, const float *loss_mask, const float *loss_stats,
+                                   const float *loss_gscale, hipStream_t stream);
 int sahs_conditioning_backward_launch(const float *flat, const float *audio, const float *grad_cond, float *grad_flat, float *grad_audio,
                                       hipStream_t stream);
 int sahs_field_forward_bf16w_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
@@ -237,8 +241,31 @@ int sahs_composite_backward(long N, int S, const float *raw, const float *z, con
     REQUIRE(N >= 0 && S >= 1 && S <= 256, "sahs_composite_backward(shape: 1 <= S <= 256)");
     if (N == 0) return 0;
     int e = sahs_composite_backward_launch(N, S, raw, z, rays, ray_stride, noise, bg, white_background, d_rgb, d_disp, d_acc, d_depth, d_wlast,
-                                           d_weights, d_raw, (hipStream_t)stream);
+                                           d_weights, d_raw, nullptr, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream);
     return e ? hip_fail("sahs_composite_backward", e) : 0;
+}
+
+int sahs_stage1_loss_forward(long N, const float *map_coarse, const float *map_fine, const float *target, int target_ld, const float *mask,
+                             const float *class_weights, float *stats, void *stream)
+{
+    REQUIRE((map_coarse || map_fine) && target && mask && class_weights && stats && target_ld >= 3 && N >= 1, "sahs_stage1_loss_forward");
+    int e = sahs_stage1_loss_forward_launch(N, map_coarse, map_fine, target, target_ld, mask, class_weights, stats, (hipStream_t)stream);
+    return e ? hip_fail("sahs_stage1_loss_forward", e) : 0;
+}
+
+int sahs_composite_backward_loss(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,
+                                 const float *bg, int white_background, const float *d_rgb, const float *d_disp, const float *d_acc,
+                                 const float *d_depth, const float *d_wlast, const float *loss_map, const float *loss_target, int target_ld,
+                                 const float *loss_mask, const float *loss_stats, const float *loss_gscale, float *d_raw, void *stream)
+{
+    REQUIRE(raw && z && rays && d_raw && ray_stride >= 6 && ALIGNED16(raw) && ALIGNED16(d_raw), "sahs_composite_backward_loss");
+    REQUIRE(loss_map && loss_target && loss_mask && loss_stats && target_ld >= 3, "sahs_composite_backward_loss(loss operands)");
+    REQUIRE(N >= 0 && S >= 1 && S <= 256, "sahs_composite_backward_loss(shape: 1 <= S <= 256)");
+    if (N == 0) return 0;
+    int e = sahs_composite_backward_launch(N, S, raw, z, rays, ray_stride, noise, bg, white_background, d_rgb, d_disp, d_acc, d_depth, d_wlast,
+                                           nullptr, d_raw, loss_map, loss_target, target_ld, loss_mask, loss_stats, loss_gscale,
+                                           (hipStream_t)stream);
+    return e ? hip_fail("sahs_composite_backward_loss", e) : 0;
 }
 
 int sahs_conditioning_backward(const float *flat_params, const float *audio, const float *grad_cond, float *grad_flat, float *grad_audio,

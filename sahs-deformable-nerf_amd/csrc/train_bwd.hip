@@ -18,6 +18,88 @@ __device__ __forceinline__ float wsum(float v)
 
 struct Smp { float col[15]; float alpha, f, pre, dist, zs; };
 
+// ---- Stage-I loss (train_stage_rays_auto.py:455-468 with nerf_helpers.py:14-62) fused around the compositing -----------------
+//   loss = sum over levels {coarse, fine} of  mean_r l2_r + 0.02 mean_r ce_r + 0.005 sum_{c in 7,8} (M_c[l2] + M_c[ce])
+//   l2_r = sum_ch (rgb_r,ch - target_r,ch)^2,  ce_r = -sum_c mask_r,c log(seg_r,c + 1e-10),  M_c[x] = sum_r x_r mask_r,c / max(1, #{r: mask_r,c != 0})
+//   new sample_prob_c ~ sum over levels of w_c (M_c[l2] + M_c[ce])        (w = the loss modules' class weights, ones(12) with [7:9] = 2)
+// stats (64 floats): [0] loss, [1] mse of the last level (the script's psnr), [2..13] new sample_prob, [14..25] class counts (>= 1), [26] rays
+enum { STAT_LOSS = 0, STAT_MSE = 1, STAT_PROB = 2, STAT_CNT = 14, STAT_RAYS = 26, STAT_WORDS = 64 };
+struct LossGrad {        // composite_backward_kernel adds d loss / d [rgb3 | seg12] of its level itself when map != nullptr
+    const float *map;    // (N,15) the level's rendered [rgb3 | seg12] (the forward's output)
+    const float *target; int target_ld;    // (N, >=3)
+    const float *mask;   // (N,12)
+    const float *stats;  // STAT_* above, of the whole batch
+    const float *gscale; // device scalar: d (final objective) / d loss, or nullptr for 1
+};
+
+// one workgroup, fixed summation order (deterministic): thread t takes rays t, t+1024, ...; wave butterfly; waves summed in order
+__global__ void __launch_bounds__(1024) stage1_loss_forward_kernel(long N, const float *__restrict__ map_c, const float *__restrict__ map_f,
+                                                                   const float *__restrict__ target, int target_ld,
+                                                                   const float *__restrict__ mask, const float *__restrict__ class_w,
+                                                                   float *__restrict__ stats)
+{
+    constexpr int NV = 12 + 2 * 26;        // counts | per level: total l2, total ce, l2 per class, ce per class
+    __shared__ float part[16][NV];
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
+    for (long r = threadIdx.x; r < N; r += 1024) {
+        const float *mk = mask + r * 12, *tg = target + r * target_ld;
+        float m[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) { m[c] = mk[c]; acc[c] += (m[c] != 0.0f) ? 1.0f : 0.0f; }
+#pragma unroll
+        for (int L = 0; L < 2; ++L) {
+            const float *mp = L == 0 ? map_c : map_f;
+            if (mp == nullptr) continue;
+            mp += r * 15;
+            float l2 = 0.0f, ce = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const float d = mp[c] - tg[c]; l2 += d * d; }
+#pragma unroll
+            for (int c = 0; c < 12; ++c) ce += m[c] * logf(mp[3 + c] + 1e-10f);
+            ce = -ce;
+            float *a = acc + 12 + 26 * L;
+            a[0] += l2; a[1] += ce;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) { a[2 + c] += l2 * m[c]; a[14 + c] += ce * m[c]; }
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const float v = wsum(acc[i]); if (lane == 0) part[wave][i] = v; }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float v = 0.0f;
+        for (int w = 0; w < 16; ++w) v += part[w][threadIdx.x];
+        part[0][threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float *t = part[0];
+        float cnt[12], loss = 0.0f, mse = 0.0f, wsumv = 0.0f, wc[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) { cnt[c] = t[c] > 0.0f ? t[c] : 1.0f; wc[c] = 0.0f; }
+        for (int L = 0; L < 2; ++L) {
+            if ((L == 0 ? map_c : map_f) == nullptr) continue;
+            const float *a = t + 12 + 26 * L;
+            mse = a[0] / (float)N;
+            float mouth = 0.0f;
+            for (int c = 0; c < 12; ++c) {
+                const float pl2 = a[2 + c] / cnt[c], pce = a[14 + c] / cnt[c];
+                if (c == 7 || c == 8) mouth += pl2 + pce;
+                wc[c] += class_w[c] * pl2 + class_w[c] * pce;
+            }
+            loss += mse + 0.02f * (a[1] / (float)N) + 0.005f * mouth;
+        }
+        for (int c = 0; c < 12; ++c) wsumv += wc[c];
+        stats[STAT_LOSS] = loss;
+        stats[STAT_MSE] = mse;
+        for (int c = 0; c < 12; ++c) { stats[STAT_PROB + c] = wc[c] / wsumv; stats[STAT_CNT + c] = cnt[c]; }
+        stats[STAT_RAYS] = (float)N;
+    }
+}
+
 __device__ __forceinline__ void sample_fwd(const float *__restrict__ raw, const float *__restrict__ z, const float *__restrict__ noise,
                                            const float *__restrict__ bg, long ray, int S, int sc, float nrm, Smp &o)
 {
@@ -60,7 +142,7 @@ __global__ void __launch_bounds__(256) composite_backward_kernel(long N, int S, 
                                                                  int white_bkgd, const float *__restrict__ d_rgb,
                                                                  const float *__restrict__ d_disp, const float *__restrict__ d_acc,
                                                                  const float *__restrict__ d_depth, const float *__restrict__ d_wlast,
-                                                                 const float *__restrict__ d_weights, float *__restrict__ d_raw)
+                                                                 const float *__restrict__ d_weights, float *__restrict__ d_raw, LossGrad lg)
 {
     const int lane = threadIdx.x & 63;
     const long stride = (long)gridDim.x * (blockDim.x >> 6);
@@ -87,7 +169,20 @@ __global__ void __launch_bounds__(256) composite_backward_kernel(long N, int S, 
         dsum = wsum(dsum); asum = wsum(asum);
         float g[15], gsum = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 15; ++c) { g[c] = d_rgb ? d_rgb[ray * 15 + c] : 0.0f; gsum += g[c]; }
+        for (int c = 0; c < 15; ++c) g[c] = d_rgb ? d_rgb[ray * 15 + c] : 0.0f;
+        if (lg.map != nullptr) {      // the Stage-I loss's own gradient w.r.t. this ray's rendered [rgb3 | seg12] (see stage1_loss_forward_kernel)
+            const float *mp = lg.map + ray * 15, *tg = lg.target + ray * lg.target_ld, *mk = lg.mask + ray * 12;
+            const float gs = lg.gscale ? lg.gscale[0] : 1.0f;
+            const float mouth = 0.005f * (mk[7] / lg.stats[STAT_CNT + 7] + mk[8] / lg.stats[STAT_CNT + 8]);
+            const float inv = 1.0f / lg.stats[STAT_RAYS];
+            const float a = gs * (inv + mouth), b = gs * (0.02f * inv + mouth);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] += a * 2.0f * (mp[c] - tg[c]);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) g[3 + c] -= b * mk[c] / (mp[3 + c] + 1e-10f);
+        }
+#pragma unroll
+        for (int c = 0; c < 15; ++c) gsum += g[c];
         float gd = d_depth ? d_depth[ray] : 0.0f, ga = d_acc ? d_acc[ray] : 0.0f;
         const float gdisp = d_disp ? d_disp[ray] : 0.0f, gwl = d_wlast ? d_wlast[ray] : 0.0f;
         const float mq = dsum / asum;
@@ -255,14 +350,23 @@ using namespace sahs;
 extern "C" int sahs_composite_backward_launch(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride,
                                               const float *noise, const float *bg, int white_bkgd, const float *d_rgb, const float *d_disp,
                                               const float *d_acc, const float *d_depth, const float *d_wlast, const float *d_weights,
-                                              float *d_raw, hipStream_t stream)
+                                              float *d_raw, const float *loss_map, const float *loss_target, int target_ld,
+                                              const float *loss_mask, const float *loss_stats, const float *loss_gscale, hipStream_t stream)
 {
     if (N <= 0) return 0;
     if (S < 1 || S > 256) return -2;
     long blocks = (N + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     composite_backward_kernel<<<(int)blocks, 256, 0, stream>>>(N, S, raw, z, rays, ray_stride, noise, bg, white_bkgd, d_rgb, d_disp, d_acc,
-                                                               d_depth, d_wlast, d_weights, d_raw);
+                                                               d_depth, d_wlast, d_weights, d_raw,
+                                                               LossGrad{loss_map, loss_target, target_ld, loss_mask, loss_stats, loss_gscale});
+    return (int)hipGetLastError();
+}
+
+extern "C" int sahs_stage1_loss_forward_launch(long N, const float *map_c, const float *map_f, const float *target, int target_ld,
+                                               const float *mask, const float *class_w, float *stats, hipStream_t stream)
+{
+    stage1_loss_forward_kernel<<<1, 1024, 0, stream>>>(N, map_c, map_f, target, target_ld, mask, class_w, stats);
     return (int)hipGetLastError();
 }
 

@@ -320,10 +320,41 @@ def field_backward(flat, frame, level, act, d_raw, grad_flat, grad_cond, arch="a
     check(f(_p(flat), _p(frame), int(level), P, _p(act), _p(d_raw), _p(grad_flat), _p(grad_cond), _p(ws), _stream()), name)
 
 
-def composite_backward(raw, z, rays, noise, bg, white_background, d_rgb, d_disp, d_acc, d_depth, d_wlast, d_weights=None):
+LOSS_STATS_WORDS = 64      # include/sahs_nerf.h: [0] loss, [1] last level's mse, [2:14] new sample_prob, [14:26] class counts, [26] rays
+
+
+def stage1_loss_forward(map_coarse, map_fine, target, mask, class_weights):
+    """The Stage-I objective (train_stage_rays_auto.py:455-468) of one ray batch in one launch -> stats (64,) fp32 (see LOSS_STATS_WORDS).
+    map_*: (N,15) rendered [rgb3 | seg12] (either may be None), target (N, >=3), mask (N,12) one-hot, class_weights (12,)."""
+    mc, mf = _req(map_coarse, "map_coarse"), _req(map_fine, "map_fine")
+    target, mask, cw = _req(target, "target"), _req(mask, "mask"), _req(class_weights, "class_weights")
+    ref = mc if mc is not None else mf
+    N = ref.shape[0]
+    if any(t is not None and tuple(t.shape) != (N, 15) for t in (mc, mf)) or tuple(mask.shape) != (N, 12) or target.shape[0] != N or cw.numel() != 12:
+        raise _lib.SahsError("stage1_loss_forward: maps (N,15), target (N,>=3), mask (N,12), class_weights (12,)")
+    stats = torch.zeros(LOSS_STATS_WORDS, dtype=torch.float32, device=ref.device)
+    check(_lib.lib().sahs_stage1_loss_forward(N, _p(mc), _p(mf), _p(target), int(target.shape[1]), _p(mask), _p(cw), _p(stats), _stream()),
+          "sahs_stage1_loss_forward")
+    return stats
+
+
+def composite_backward(raw, z, rays, noise, bg, white_background, d_rgb, d_disp, d_acc, d_depth, d_wlast, d_weights=None, loss=None):
+    """loss = (map (N,15), target, mask, stats, gscale or None): the level's share of the Stage-I objective's gradient is formed inside
+    the kernel (sahs_composite_backward_loss) and added to d_rgb."""
     raw, z, rays = _req(raw, "raw"), _req(z, "z"), _req(rays, "rays")
     N, S = z.shape
     d_raw = torch.empty(N, S, 16, dtype=torch.float32, device=z.device)
+    if loss is not None:
+        if d_weights is not None:
+            raise _lib.SahsError("composite_backward: d_weights and loss together are not supported")
+        lm, lt, lk, st, gsc = (_req(t, n) for t, n in zip(loss, ("loss_map", "loss_target", "loss_mask", "loss_stats", "loss_gscale")))
+        if tuple(lm.shape) != (N, 15) or tuple(lk.shape) != (N, 12) or lt.shape[0] != N or st.numel() < LOSS_STATS_WORDS:
+            raise _lib.SahsError("composite_backward: loss operands (N,15), (N,>=3), (N,12), stats (64,)")
+        gs = [_req(g, n) for g, n in ((d_rgb, "d_rgb"), (d_disp, "d_disp"), (d_acc, "d_acc"), (d_depth, "d_depth"), (d_wlast, "d_wlast"))]
+        check(_lib.lib().sahs_composite_backward_loss(N, S, _p(raw), _p(z), _p(rays), int(rays.shape[1]), _p(_req(noise, "noise")), _p(_req(bg, "bg")),
+                                                       int(bool(white_background)), *[_p(g) for g in gs], _p(lm), _p(lt), int(lt.shape[1]), _p(lk),
+                                                       _p(st), _p(gsc), _p(d_raw), _stream()), "sahs_composite_backward_loss")
+        return d_raw
     gs = [_req(g, n) for g, n in ((d_rgb, "d_rgb"), (d_disp, "d_disp"), (d_acc, "d_acc"), (d_depth, "d_depth"), (d_wlast, "d_wlast"),
                                   (d_weights, "d_weights"))]
     check(_lib.lib().sahs_composite_backward(N, S, _p(raw), _p(z), _p(rays), int(rays.shape[1]), _p(_req(noise, "noise")), _p(_req(bg, "bg")),
@@ -411,9 +442,25 @@ class RenderRaysFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, flat, audio, pose, rays, bg, t_rand, noise_c, u, noise_f, packed, num_coarse, num_fine, lindisp, white_background,
-                arch="audio"):
+                arch="audio", loss_target=None, loss_mask=None, loss_weights=None):
+        """With loss_target (N,>=3), loss_mask (N,12), loss_weights (12,) the op also returns (loss, stats) of the Stage-I objective
+        (stage1_loss_forward) and its backward forms that loss's gradient inside the composite backward kernels."""
         frame = fold_conditioning(flat.detach(), audio.detach(), pose, arch=arch)
         ctx.arch = arch
+        ctx.has_loss = loss_target is not None
+
+        def with_loss(outs, saved):
+            if not ctx.has_loss:
+                ctx.save_for_backward(*saved)
+                return outs
+            tgt, msk = loss_target.detach().float().contiguous(), loss_mask.detach().float().contiguous()
+            rgb_f = outs[3] if num_fine > 0 else None
+            stats = stage1_loss_forward(outs[0], rgb_f, tgt, msk, loss_weights.detach().float().contiguous())
+            ctx.n_base = len(saved)
+            ctx.save_for_backward(*saved, outs[0], rgb_f if rgb_f is not None else torch.empty(0, device=rays.device), tgt, msk, stats)
+            ctx.mark_non_differentiable(stats)
+            return tuple(outs) + (stats[0].clone(), stats)
+
         none = torch.empty(0, device=rays.device)
         ctx.cfg = (num_coarse, num_fine, bool(white_background), bg is not None, noise_c is not None, noise_f is not None)
         ctx.kept = rays.shape[0] <= RenderRaysFn.BLOCK_RAYS and num_fine > 0
@@ -425,19 +472,22 @@ class RenderRaysFn(torch.autograd.Function):
             raw_f, act_f = field_forward_save(packed, frame, 1, rays, z_f, arch)
             rgb_f, disp_f, acc_f, w_f, depth_f = composite_forward(raw_f, z_f, rays, noise_f, bg, white_background)
             outs = (rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_f[:, -1].contiguous(), depth_f)
-            ctx.save_for_backward(flat.detach(), audio.detach(), rays, z_c, z_f, frame, packed,
-                                  *[t if t is not None else none for t in (bg, noise_c, noise_f)], raw_c, act_c, raw_f, act_f)
-            return outs
+            return with_loss(outs, (flat.detach(), audio.detach(), rays, z_c, z_f, frame, packed,
+                                    *[t if t is not None else none for t in (bg, noise_c, noise_f)], raw_c, act_c, raw_f, act_f))
         ws = {}
         outs = render_rays(packed, frame, rays, num_coarse, num_fine, precision=SAHS_F32, lindisp=lindisp, white_background=white_background,
                            bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f, workspace=ws, arch=arch)
-        ctx.save_for_backward(flat.detach(), audio.detach(), rays, ws["z_c"].clone(), ws["z_f"].clone() if num_fine > 0 else none, frame, packed,
-                              *[t if t is not None else none for t in (bg, noise_c, noise_f)])
-        return outs
+        return with_loss(outs, (flat.detach(), audio.detach(), rays, ws["z_c"].clone(), ws["z_f"].clone() if num_fine > 0 else none, frame, packed,
+                                *[t if t is not None else none for t in (bg, noise_c, noise_f)]))
 
     @staticmethod
-    def backward(ctx, g_rgb_c, g_disp_c, g_acc_c, g_rgb_f, g_disp_f, g_acc_f, g_wbg, g_depth_f):
+    def backward(ctx, g_rgb_c, g_disp_c, g_acc_c, g_rgb_f, g_disp_f, g_acc_f, g_wbg, g_depth_f, g_loss=None, g_stats=None):
         flat, audio, rays, z_c, z_f, frame, packed, bg, noise_c, noise_f = ctx.saved_tensors[:10]
+        loss_ops = None
+        if ctx.has_loss and g_loss is not None:
+            map_c, map_f, l_tgt, l_msk, l_stats = ctx.saved_tensors[ctx.n_base:ctx.n_base + 5]
+            loss_ops = {0: map_c, 1: map_f}
+            gscale = g_loss.detach().float().reshape(1).contiguous()
         kept = dict(zip((0, 1), (ctx.saved_tensors[10:12], ctx.saved_tensors[12:14]))) if ctx.kept else None
         nc, nf, white, has_bg, has_nc, has_nf = ctx.cfg
         bg = bg if has_bg else None
@@ -460,13 +510,16 @@ class RenderRaysFn(torch.autograd.Function):
             else:     # coarse only (train_utils.py:148-149): depth and weights[:, -1] of the 8-tuple are the COARSE pass's
                 passes = ((0, z_c, noise_c, (g_rgb_c, g_disp_c, g_acc_c, g_depth_f, g_wbg)),)
             for level, z, noise, grads in passes:
-                if all(g is None for g in grads):
+                lvl_loss = None
+                if loss_ops is not None:      # with nf == 0 the only pass is level 0 and its map is the coarse one
+                    lvl_loss = (loss_ops[level][sl].contiguous(), l_tgt[sl].contiguous(), l_msk[sl].contiguous(), l_stats, gscale)
+                if lvl_loss is None and all(g is None for g in grads):
                     continue
                 zb = z[sl].contiguous()
                 raw, act = kept[level] if kept is not None else field_forward_save(packed, frame, level, rb, zb, ctx.arch)
                 nb = None if noise is None else noise[sl].contiguous()
                 gb = [None if g is None else c(g[sl]) for g in grads]
-                d_raw = composite_backward(raw, zb, rb, nb, bgb, white, *gb)
+                d_raw = composite_backward(raw, zb, rb, nb, bgb, white, *gb, loss=lvl_loss)
                 field_backward(flat, frame, level, act, d_raw.view(-1, 16), grad_flat, grad_cond, ctx.arch)
                 del raw, act, d_raw
         if ctx.arch == "audio":
@@ -474,4 +527,4 @@ class RenderRaysFn(torch.autograd.Function):
                   "sahs_conditioning_backward")
         else:       # NeRFaceModel: the driving vector is the expression itself
             grad_audio = grad_cond[:76].clone()
-        return (grad_flat, grad_audio) + (None,) * 13
+        return (grad_flat, grad_audio) + (None,) * 16

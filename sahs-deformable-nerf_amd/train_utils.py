@@ -51,7 +51,7 @@ def run_network(level, network_fn, pts, ray_batch, chunksize, use_viewdirs, driv
 
 def predict_and_render_radiance(ray_batch, model, options, mode="train", driving=None, pose=None, pose_c=None,
                                 background_prior=None, latent_code=None, spatial_embeddings=None, ray_dirs_fake=None,
-                                _frame=None, _workspace=None, _ray0=0, _rows=None):
+                                _frame=None, _workspace=None, _ray0=0, _rows=None, _loss=None):
     """train_utils.py:72-206 for one ray chunk -> the 8-tuple
     (rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine, weights_fine[:, -1], depth_fine).
     _rows (driver-internal): an (N, 36) row block to fill in place instead (ops.render_rays_rows); returns None then."""
@@ -87,8 +87,10 @@ def predict_and_render_radiance(ray_batch, model, options, mode="train", driving
         if model.precision != ops.SAHS_F32:
             raise NotImplementedError("training runs the fp32 path; build the model with precision='fp32'")
         flat = model.flat_params(differentiable=True)
+        # _loss = (target (N,>=3), mask (N,12), class weights (12,)): the op also returns (loss, stats) of the Stage-I objective and
+        # forms that loss's gradient inside its composite backward (ops.RenderRaysFn)
         return ops.RenderRaysFn.apply(flat, driving.to(torch.float32), pose.to(torch.float32), rays.detach(), bg, t_rand, noise_c, u, noise_f,
-                                      packed, nc, nf, bool(opt.lindisp), bool(opt.white_background), arch)
+                                      packed, nc, nf, bool(opt.lindisp), bool(opt.white_background), arch, *(_loss or ()))
     if _rows is not None:
         ops.render_rays_rows(packed, frame, rays, nc, nf, _rows, precision=model.precision, lindisp=bool(opt.lindisp),
                              white_background=bool(opt.white_background), bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f,
@@ -101,8 +103,11 @@ def predict_and_render_radiance(ray_batch, model, options, mode="train", driving
 
 def run_one_iter_of_nerf(height, width, focal_length, model, ray_origins, ray_directions, options, mode="train", driving=None,
                          pose=None, pose_c=None, background_prior=None, latent_code=None, ray_directions_ablation=None,
-                         spatial_embeddings=None, inHead=None):
-    """train_utils.py:209-321.  height/width/focal_length are unused when dataset.no_ndc is True (as there)."""
+                         spatial_embeddings=None, inHead=None, _loss=None):
+    """train_utils.py:209-321.  height/width/focal_length are unused when dataset.no_ndc is True (as there).
+    _loss (not in the reference): (target, mask, class_weights) of the Stage-I objective for a training batch that fits one ray
+    chunk -> the 8-tuple is followed by (loss, stats), and the loss's gradient is formed inside the HIP backward
+    (training.train_step uses it; stats layout: ops.LOSS_STATS_WORDS)."""
     if options.dataset.no_ndc is False:
         raise NotImplementedError("NDC rays: the reference's own no_ndc=False branch is dead (NameError at train_utils.py:263)")
     ro = ray_origins.reshape((-1, 3))
@@ -120,6 +125,12 @@ def run_one_iter_of_nerf(height, width, focal_length, model, ray_origins, ray_di
     # once per call (the reference recomputes it per point-chunk); the differentiable op folds the conditioning itself
     frame = None if needs_grad else model.frame(driving, pose)
     workspace = {}
+    if _loss is not None:
+        if not needs_grad or len(batches) != 1:
+            raise ValueError("_loss needs a differentiable call whose rays fit one chunk (nerf.%s.chunksize)" % mode)
+        return tuple(predict_and_render_radiance(batches[0], model, options, mode, driving=driving, pose=pose, pose_c=pose_c,
+                                                 background_prior=bgs[0] if bgs is not None else None, latent_code=latent_code,
+                                                 _workspace=workspace, _loss=_loss))
     if needs_grad:
         pred = [predict_and_render_radiance(b, model, options, mode, driving=driving, pose=pose, pose_c=pose_c,
                                             background_prior=bgs[i] if bgs is not None else None, latent_code=latent_code,

@@ -63,14 +63,18 @@ def learning_rate(cfg, step):
 
 
 def train_step(model, optimizer, cfg, step, image, mask, pose, intrinsics, audio, background, sample_prob, generator=None,
-               regularize_spatial_embedding=False, group=None):
+               regularize_spatial_embedding=False, group=None, fused_loss=True):
     """One optimisation step on one frame.  image (H,W,3), mask (H,W,12) one-hot float, background (H,W,15).
     Returns dict(loss, psnr, sample_prob).
 
     Under torch.distributed (one process per GPU) the step is data-parallel over rays: every rank draws the same batch
     (``generator`` seeded identically), renders and back-propagates its contiguous slice, and the gradients -- and the
     per-class sampling feedback -- are averaged with one all-reduce each before the optimiser step, so the replicas stay
-    identical."""
+    identical.
+
+    fused_loss: the objective is evaluated by one HIP launch on the rendered maps and its gradient is formed inside the composite
+    backward kernels (ops.RenderRaysFn with loss operands) instead of ~40 small torch kernels and an (R,15) gradient round trip;
+    same recipe, same class weights (stage1_loss is the unfused statement, kept for the seams and the tests)."""
     import torch.distributed as dist
     from . import distributed as D
     H, W = image.shape[:2]
@@ -82,8 +86,14 @@ def train_step(model, optimizer, cfg, step, image, mask, pose, intrinsics, audio
     target = image.reshape(-1, image.shape[-1])[sel]
     bg = background.reshape(-1, 15)[sel] if background is not None else None
     m = mask.reshape(-1, 12)[sel].float()
-    outs = run_one_iter_of_nerf(H, W, intrinsics, model, ro, rd, cfg, mode="train", driving=audio, pose=pose, background_prior=bg, inHead=m)
-    loss, new_prob, fine_mse = stage1_loss(outs[0], outs[3], target, m)
+    if fused_loss and m.is_cuda and sel.shape[0] <= int(cfg.nerf.train.chunksize):
+        outs = run_one_iter_of_nerf(H, W, intrinsics, model, ro, rd, cfg, mode="train", driving=audio, pose=pose, background_prior=bg, inHead=m,
+                                    _loss=(target[..., :3].float(), m, sample_prob_weights(m.device)))
+        loss, stats = outs[8], outs[9]
+        new_prob, fine_mse = stats[2:14].clone(), stats[1].clone()
+    else:
+        outs = run_one_iter_of_nerf(H, W, intrinsics, model, ro, rd, cfg, mode="train", driving=audio, pose=pose, background_prior=bg, inHead=m)
+        loss, new_prob, fine_mse = stage1_loss(outs[0], outs[3], target, m)
     if regularize_spatial_embedding:
         loss = loss + torch.norm(model.spatial_embeddings) * 0.0005 * 10
     optimizer.zero_grad(set_to_none=True)

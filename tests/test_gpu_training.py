@@ -84,8 +84,11 @@ def test_train_step_2048_rays_vs_eager_autograd(weights_mod):
     print(json.dumps(res))
 
 
-def test_train_step_vs_reference_fixture(flat_weights):
-    """f-2 pinned: one training step (train_stage_rays_auto.py:437-468) on the high-dynamic-range network -- train-mode render
+@pytest.mark.parametrize("fused", [False, True])
+def test_train_step_vs_reference_fixture(flat_weights, fused):
+    """fused: the objective evaluated by sahs_stage1_loss_forward and its gradient formed inside composite_backward_kernel
+    (run_one_iter_of_nerf(..., _loss=...)); otherwise the torch statement of the loss modules + autograd.  Same bounds.
+    f-2 pinned: one training step (train_stage_rays_auto.py:437-468) on the high-dynamic-range network -- train-mode render
     with the reference's captured draws, the loss recipe, the sample_prob feedback and backward through the HIP kernels --
     against what the REFERENCE computed on the same 32 rays (tests/golden/train_step_hdr.npz: its own MaskMSELoss /
     MaskCrossEntropyLoss with the script's weights, its own autograd), with the float64 run of the reference as yardstick.
@@ -110,14 +113,22 @@ def test_train_step_vs_reference_fixture(flat_weights):
 
     torch.rand, torch.randn = feed("rand"), feed("randn")
     try:
+        extra = dict(_loss=(T(g["target"])[:, :3], T(g["mask"]), Tr.sample_prob_weights(dev))) if fused else {}
         outs = sahs.run_one_iter_of_nerf(12, 12, None, model, T(g["ro"]), T(g["rd"]), cfg, mode="train", driving=audio, pose=T(g["pose"]),
-                                         background_prior=T(g["bg"]), inHead=T(g["mask"]))
+                                         background_prior=T(g["bg"]), inHead=T(g["mask"]), **extra)
     finally:
         torch.rand, torch.randn = o_rand, o_randn
     assert not log, "the driver must consume exactly the reference's random draws"
     for nm, o in zip(["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"], outs):
         yardstick(o, g["out_" + nm], g["f64_" + nm], "hip train_step_hdr:" + nm, outlier_rays=0.0 if nm.endswith("_c") else 0.04, scale_floor=1.0)
     loss, prob, fine_mse = Tr.stage1_loss(outs[0], outs[3], T(g["target"]), T(g["mask"]))
+    if fused:       # the kernel's value against the torch statement on the same maps, then use the kernel's
+        assert len(outs) == 10
+        st = outs[9]
+        assert abs(float(outs[8]) - float(loss)) <= 2e-6 * abs(float(loss)), (float(outs[8]), float(loss))
+        assert float((st[2:14] - prob.detach()).abs().max()) <= 2e-6
+        assert abs(float(st[1]) - float(fine_mse)) <= 2e-6 * float(fine_mse)
+        loss, prob = outs[8], st[2:14]
     l64, l32 = float(g["loss_f64"]), float(g["loss"])
     assert abs(float(loss) - l64) <= 3.0 * abs(l32 - l64) + 1e-5 * abs(l64), (float(loss), l32, l64)
     p64, p32 = g["sample_prob_f64"], g["sample_prob"].astype(np.float64)
@@ -148,10 +159,50 @@ def test_train_step_vs_reference_fixture(flat_weights):
                grad_audio_err=e_audio, grad_audio_err_ref=ref_audio)
     print(json.dumps(res))
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-    json.dump(res, open(os.path.join(REPO, "gpurun_out", "train_step_vs_reference.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(REPO, "gpurun_out", "train_step_vs_reference%s.json" % ("_fused" if fused else "")), "w"), indent=1)
     assert worst_norm <= 2.0 * ref_norm_err + 1e-4, res
     assert worst_entry <= 2.0 * ref_entry + 1e-4, res
     assert e_audio <= 2.0 * ref_audio + 1e-4, res
+
+
+def test_stage1_loss_kernel_vs_loss_modules():
+    """sahs_stage1_loss_forward against the torch statement of the reference's loss modules (pinned to the reference's own classes by
+    tests/golden/losses.npz on CPU): ragged ray count, an empty class, a one-ray class, coarse-only; and its gradient, formed inside
+    composite_backward_kernel, against autograd of that statement through ops.CompositeFn."""
+    ops, Tr, sahs = pkg("ops"), pkg("training"), pkg()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(5)
+    N, S = 777, 40
+    cls = torch.randint(0, 12, (N,), device=dev, generator=gen)
+    cls[cls == 5] = 4
+    cls[cls == 11] = 10
+    cls[3] = 11
+    mask = torch.nn.functional.one_hot(cls, 12).float()
+    target = torch.rand(N, 3, device=dev, generator=gen)
+    w = Tr.sample_prob_weights(dev)
+    maps = []
+    for _ in range(2):
+        m = torch.cat([torch.rand(N, 3, device=dev, generator=gen), torch.softmax(torch.randn(N, 12, device=dev, generator=gen) * 2, -1)], 1)
+        maps.append(m)
+    for mc, mf in ((maps[0], maps[1]), (maps[0], None)):
+        st = ops.stage1_loss_forward(mc, mf, target, mask, w)
+        loss, prob, mse = Tr.stage1_loss(mc, mf, target, mask)
+        assert abs(float(st[0]) - float(loss)) <= 2e-6 * abs(float(loss))
+        assert float((st[2:14] - prob).abs().max()) <= 1e-6 and abs(float(st[1]) - float(mse)) <= 2e-6 * float(mse)
+        assert float(st[14 + 5]) == 1.0 and float(st[14 + 11]) == 1.0 and float(st[26]) == N        # empty class counts as 1
+    # gradient: d loss / d raw through one compositing level, fused against autograd of the statement
+    raw = (torch.randn(N, S, 16, device=dev, generator=gen) * 1.5).requires_grad_(True)
+    z = torch.sort(torch.rand(N, S, device=dev, generator=gen) * 0.6 + 0.48, dim=1).values
+    rays = torch.zeros(N, 8, device=dev)
+    rays[:, 3:6] = torch.randn(N, 3, device=dev, generator=gen) * 0.2 + torch.tensor([0, 0, -1.0], device=dev)
+    rgb = sahs.volume_render_radiance_field(raw, z, rays[:, 3:6], radiance_field_noise_std=0.0)[0]      # no prior: 15 sigmoid channels
+    loss, _, _ = Tr.stage1_loss(rgb, None, target, mask)
+    (3.0 * loss).backward()
+    st = ops.stage1_loss_forward(rgb.detach(), None, target, mask, w)
+    d_raw = ops.composite_backward(raw.detach(), z, rays, None, None, False, None, None, None, None, None,
+                                   loss=(rgb.detach().contiguous(), target, mask, st, torch.tensor([3.0], device=dev)))
+    scale = float(raw.grad.abs().max())
+    assert float((d_raw - raw.grad).abs().max()) <= 2e-5 * scale, (float((d_raw - raw.grad).abs().max()), scale)
 
 
 def test_training_loop_reduces_loss(weights_mod):
