@@ -352,9 +352,13 @@ def train_leg(pkg, dev, rays=2048, steps=5, warmup=2):
     target = torch.rand(rays, 3, device=dev, generator=g)
     bg = torch.cat([torch.rand(rays, 3, device=dev, generator=g), torch.ones(rays, 1, device=dev), torch.zeros(rays, 11, device=dev)], 1)
 
+    cw = Tr.sample_prob_weights(dev)
+
     def step():
-        outs = pkg.run_one_iter_of_nerf(H, Wd, intr, model, ro, rd, cfg, mode="train", driving=audio, pose=pose, background_prior=bg, inHead=m)
-        loss, _, _ = Tr.stage1_loss(outs[0], outs[3], target, m)
+        # as training.train_step: the objective and its gradient inside the HIP launches (sahs_stage1_loss_forward, composite backward)
+        outs = pkg.run_one_iter_of_nerf(H, Wd, intr, model, ro, rd, cfg, mode="train", driving=audio, pose=pose, background_prior=bg, inHead=m,
+                                        _loss=(target, m, cw))
+        loss = outs[8]
         model.zero_grad(set_to_none=True)
         loss.backward()
         return loss

@@ -218,6 +218,23 @@ int sahs_model_field_forward_split(int model, const void *packed, const float *f
                                    int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src,
                                    void *stream);
 
+/* Training through the split evaluation (autograd of the same graph, train_stage_rays_auto.py:493, with the deformation nets
+ * evaluated once per depth).  sahs_model_field_forward_split_save = sahs_model_field_forward_split (fp32) that also stores the
+ * activations of the layers it runs into act_out: N*S*sahs_model_act_words_part(model, mode) floats (part/mode 0: whole network, 1:
+ * deformation nets, 2: radiance nets).  sahs_model_field_backward_split walks `part` of the network backwards over activations saved by
+ * the forward of the same part: the seam is the gradient w.r.t. (x', w), (P,8) rows [dx'0 dx'1 dx'2 . dw0 dw1 . .]: part 2 (radiance
+ * alone) takes d_raw (P,16) and writes xw_grad_out; part 1 (deformation alone) starts from xw_grad_in; part 3 (everything) takes d_raw
+ * and ADDS xw_grad_in (may be NULL) at the seam.  sahs_route_xw_grad scatters the fine pass's (N,Sc+nf,8) seam gradient through the merge
+ * permutation src (sahs_resample_merge) into g_coarse (N,Sc,8) -- the xw_grad_in of the coarse pass -- and g_new (N,nf,8). */
+long sahs_model_act_words_part(int model, int part);
+int sahs_model_field_forward_split_save(int model, const void *packed, const float *frame, int level, int mode, long N, int S, const float *rays,
+                                        int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src,
+                                        float *act_out, void *stream);
+int sahs_model_field_backward_split(int model, const float *flat_params, const float *frame, int level, int part, long P, const float *act_in,
+                                    const float *d_raw, const float *xw_grad_in, float *xw_grad_out, float *grad_flat, float *grad_cond,
+                                    float *workspace, void *stream);
+int sahs_route_xw_grad(long N, int Sc, int nf, const int32_t *src, const float *g_fine, float *g_coarse, float *g_new, void *stream);
+
 /* sahs_model_render_rays writing rows[r * row_ld + column] instead of eight dense arrays (row_ld >= 36; columns 17..33 are
  * left untouched when nf == 0).  Workspace and draws as sahs_render_rays.  Optional extra workspace xw (N,Sc+nf,8) floats, src
  * (N,Sc+nf) int32, z_new (N,nf) floats: when all three are given (nf > 0; SAHS_F32, or SAHS_BF16 with SAHS_MODEL_AUDIO) the chain evaluates the deformation nets once per

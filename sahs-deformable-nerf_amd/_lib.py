@@ -51,6 +51,10 @@ SIGNATURES = {
     "sahs_model_executed_macs_part": (_L, [_I, _I, _I]),
     "sahs_model_render_rays_rows": (_I, [_I, _P, _P, _I, _L, _P, _I, _I, _I, _I, _I] + [_P] * 10 + [_I, _P, _P, _P, _P]),
     "sahs_resample_merge": (_I, [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "sahs_model_act_words_part": (_L, [_I, _I]),
+    "sahs_model_field_forward_split_save": (_I, [_I, _P, _P, _I, _I, _L, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "sahs_model_field_backward_split": (_I, [_I, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sahs_route_xw_grad": (_I, [_L, _I, _I, _P, _P, _P, _P, _P]),
     "sahs_stage1_loss_forward": (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _P]),
     "sahs_composite_backward_loss": (_I, [_L, _I, _P, _P, _P, _I, _P, _P, _I] + [_P] * 5 + [_P, _P, _I, _P, _P, _P, _P, _P]),
     "sahs_model_field_forward_split": (_I, [_I, _P, _P, _I, _I, _I, _L, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P]),

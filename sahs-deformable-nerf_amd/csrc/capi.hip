@@ -44,6 +44,7 @@ int sahs_composite_forward_launch(long N, int S, const float *raw, const float *
 int sahs_resample_launch(long N, int S, int nf, int from_z, const float *z, const float *weights, const float *u, float *z_samples,
                          float *z_out, long long *inds, int *src, hipStream_t stream);
 int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, long N, int S, float *out, hipStream_t stream);
+int sahs_route_xw_grad_launch(long N, int Sc, int nf, const int *src, const float *g_fine, float *g_coarse, float *g_new, hipStream_t stream);
 // the NeRFaceModel builds of pack.hip / field_f32.hip (sahs_model.hpp: SAHS_MODEL=1 suffix _nf, SAHS_MODEL=2 suffix _ns)
 #define SAHS_DECLARE_MODEL(sfx)                                                                                                      \
     long sahs_layout_param_count##sfx(void);                                                                                        \
@@ -52,6 +53,11 @@ int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, 
     long sahs_layout_act_words##sfx(void);                                                                                          \
     long sahs_layout_executed_macs##sfx(int precision, int part);                                                                             \
     long sahs_field_backward_ws_words##sfx(long P);                                                                                 \
+    int sahs_layout_act_part_words##sfx(int part);                                                                                  \
+    int sahs_layout_act_part_col0##sfx(int part);                                                                                   \
+    int sahs_field_backward_split_launch##sfx(const float *flat, const float *frame, int level, int part, long P, const float *actbuf, \
+                                              const float *d_raw, const float *xwg_in, float *xwg_out, float *grad_flat,            \
+                                              float *grad_cond, float *ws, hipStream_t stream);                                     \
     int sahs_field_backward_launch##sfx(const float *flat, const float *frame, int level, long P, const float *actbuf,              \
                                         const float *d_raw, float *grad_flat, float *grad_cond, float *ws, hipStream_t stream);     \
     int sahs_pack_weights_f32_launch##sfx(const float *flat, float *packed, hipStream_t stream);                                   \
@@ -62,7 +68,8 @@ int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, 
                                            hipStream_t stream);                                                                     \
     int sahs_field_forward_f32_split_launch##sfx(const float *packed, const float *frame, int level, int mode, long P, int S,      \
                                                  const float *rays, int ray_stride, const float *zvals, float *raw, float *xw,      \
-                                                 int xw_row, int xw_col0, const int *src, int num_cu, hipStream_t stream);
+                                                 int xw_row, int xw_col0, const int *src, float *actbuf, int num_cu,                \
+                                                 hipStream_t stream);
 SAHS_DECLARE_MODEL()
 SAHS_DECLARE_MODEL(_nf)
 SAHS_DECLARE_MODEL(_ns)
@@ -463,10 +470,77 @@ int sahs_model_field_forward_split(int model, const void *packed, const float *f
                                                         src, num_cus(), (hipStream_t)stream)
             : model == SAHS_MODEL_AUDIO
                 ? sahs_field_forward_f32_split_launch((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0, src,
-                                                      num_cus(), (hipStream_t)stream)
+                                                      nullptr, num_cus(), (hipStream_t)stream)
                 : sahs_field_forward_f32_split_launch_nf((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0,
-                                                         src, num_cus(), (hipStream_t)stream);
+                                                         src, nullptr, num_cus(), (hipStream_t)stream);
     return e ? hip_fail("sahs_model_field_forward_split", e) : 0;
+}
+
+// ---- training with the deformation nets evaluated once per depth: the split launches with saved activations, the backward cut at
+// the (x', w) seam, and the routing of the fine pass's seam gradient through the merge permutation ----
+long sahs_model_act_words_part(int model, int part)
+{
+    if (model < 0 || model > 2 || part < 0 || part > 3) return -1;
+    const int p = part == 3 ? 0 : part;
+    return model == SAHS_MODEL_AUDIO ? sahs_layout_act_part_words(p) : (model == SAHS_MODEL_NERFACE ? sahs_layout_act_part_words_nf(p) : sahs_layout_act_part_words_ns(p));
+}
+static long act_col0(int model, int part)
+{
+    const int p = part == 3 ? 0 : part;
+    return model == SAHS_MODEL_AUDIO ? sahs_layout_act_part_col0(p) : (model == SAHS_MODEL_NERFACE ? sahs_layout_act_part_col0_nf(p) : sahs_layout_act_part_col0_ns(p));
+}
+
+int sahs_model_field_forward_split_save(int model, const void *packed, const float *frame, int level, int mode, long N, int S, const float *rays,
+                                        int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src,
+                                        float *act_out, void *stream)
+{
+    const char *who = "sahs_model_field_forward_split_save";
+    REQUIRE_MODEL(model, who);
+    if (N == 0) return 0;
+    if (model == SAHS_MODEL_NERFACE_STATIC) return fail(4, "%s: this model has no deformation nets%ld", who, 0L);
+    REQUIRE(packed && frame && rays && xw && act_out && (level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8 && mode >= 0 && mode <= 2, who);
+    REQUIRE((mode == 1 || raw) && (mode == 2 || z) && (mode != 2 || src), "sahs_model_field_forward_split_save(buffers of the mode)");
+    REQUIRE(xw_col0 >= 0 && xw_row >= xw_col0 + (mode == 2 ? 0 : S) && ALIGNED16(xw) && ALIGNED16(packed) && ALIGNED16(frame) && (!raw || ALIGNED16(raw)) &&
+            ALIGNED16(act_out), "sahs_model_field_forward_split_save(xw layout / alignment)");
+    const long P = N * S;
+    float *base = act_out - act_col0(model, mode) * P;       // column c of the act:: table at base + c * P; only the part's columns are touched
+    int e = model == SAHS_MODEL_AUDIO
+                ? sahs_field_forward_f32_split_launch((const float *)packed, frame, level, mode, P, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0, src, base,
+                                                      num_cus(), (hipStream_t)stream)
+                : sahs_field_forward_f32_split_launch_nf((const float *)packed, frame, level, mode, P, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0, src,
+                                                         base, num_cus(), (hipStream_t)stream);
+    return e ? hip_fail(who, e) : 0;
+}
+
+int sahs_model_field_backward_split(int model, const float *flat_params, const float *frame, int level, int part, long P, const float *act_in,
+                                    const float *d_raw, const float *xw_grad_in, float *xw_grad_out, float *grad_flat, float *grad_cond,
+                                    float *workspace, void *stream)
+{
+    const char *who = "sahs_model_field_backward_split";
+    REQUIRE_MODEL(model, who);
+    if (part == 0) part = 3;
+    REQUIRE(flat_params && frame && act_in && grad_flat && grad_cond && workspace && part >= 1 && part <= 3, who);
+    REQUIRE((level == 0 || level == 1) && P >= 0 && P <= 4000000L, "sahs_model_field_backward_split(0 <= P <= 4e6 samples per call)");
+    REQUIRE(((part & 2) ? d_raw != nullptr : xw_grad_in != nullptr) && (part != 2 || xw_grad_out != nullptr),
+            "sahs_model_field_backward_split(d_raw for the radiance part, xw_grad_in for the deformation part alone, xw_grad_out for the radiance part alone)");
+    if (model == SAHS_MODEL_NERFACE_STATIC && part != 3) return fail(4, "%s: this model has no deformation nets%ld", who, 0L);
+    const float *base = act_in - act_col0(model, part) * P;
+    int e = model == SAHS_MODEL_AUDIO ? sahs_field_backward_split_launch(flat_params, frame, level, part, P, base, d_raw, xw_grad_in, xw_grad_out, grad_flat,
+                                                                         grad_cond, workspace, (hipStream_t)stream)
+            : model == SAHS_MODEL_NERFACE ? sahs_field_backward_split_launch_nf(flat_params, frame, level, part, P, base, d_raw, xw_grad_in, xw_grad_out,
+                                                                                grad_flat, grad_cond, workspace, (hipStream_t)stream)
+                                          : sahs_field_backward_split_launch_ns(flat_params, frame, level, part, P, base, d_raw, xw_grad_in, xw_grad_out,
+                                                                                grad_flat, grad_cond, workspace, (hipStream_t)stream);
+    return e ? hip_fail(who, e) : 0;
+}
+
+int sahs_route_xw_grad(long N, int Sc, int nf, const int32_t *src, const float *g_fine, float *g_coarse, float *g_new, void *stream)
+{
+    if (N == 0) return 0;
+    REQUIRE(src && g_fine && g_coarse && g_new && N >= 0 && Sc >= 1 && nf >= 1 && ALIGNED16(g_fine) && ALIGNED16(g_coarse) && ALIGNED16(g_new),
+            "sahs_route_xw_grad");
+    int e = sahs_route_xw_grad_launch(N, Sc, nf, src, g_fine, g_coarse, g_new, (hipStream_t)stream);
+    return e ? hip_fail("sahs_route_xw_grad", e) : 0;
 }
 
 int sahs_composite_forward_rows(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,

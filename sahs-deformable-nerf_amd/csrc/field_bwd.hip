@@ -693,10 +693,28 @@ constexpr long WAL_FLOATS = 2L << 20;   // aligned weight sub-matrix copies of o
 extern "C" long SAHS_SYM(sahs_field_backward_ws_words)(long P) { return P * (256L * 3 + DIN_LD + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS + WAL_FLOATS; }
 
 // grad_cond: [0:76] d_driving, [80:116] d_pose36 (accumulated).  grad_flat: accumulated.  d_raw: (P,16).
+// part (bit 1: deformation nets, bit 2: radiance nets; 0 = 3 = everything) cuts the walk at its seam, the gradient w.r.t. the deformed
+// point and the ambient coordinate, (P,8) rows [dx'0 dx'1 dx'2 . dw0 dw1 . .]: the radiance part alone leaves it in xwg_out, the
+// deformation part alone starts from xwg_in, and the whole walk adds xwg_in (if given) at the seam -- that is how the fine pass's
+// gradient reaches the coarse samples' deformation when the forward evaluated the deformation nets once per depth (field_f32.hip MODE).
+extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, const float *frame, int level, int part, long P, const float *actbuf,
+                                                const float *d_raw, const float *xwg_in, float *xwg_out, float *grad_flat, float *grad_cond,
+                                                float *ws, hipStream_t stream);
 extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const float *frame, int level, long P, const float *actbuf, const float *d_raw,
                                           float *grad_flat, float *grad_cond, float *ws, hipStream_t stream)
 {
+    return SAHS_SYM(sahs_field_backward_split_launch)(flat, frame, level, 3, P, actbuf, d_raw, nullptr, nullptr, grad_flat, grad_cond, ws, stream);
+}
+extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, const float *frame, int level, int part, long P, const float *actbuf,
+                                                const float *d_raw, const float *xwg_in, float *xwg_out, float *grad_flat, float *grad_cond,
+                                                float *ws, hipStream_t stream)
+{
     if (P <= 0) return 0;
+    if (part == 0) part = 3;
+    const bool do_rad = (part & 2) != 0, do_def = (part & 1) != 0;
+#if SAHS_MODEL == 2
+    if (part != 3) return -3;      // no deformation nets: nothing to split
+#endif
     if (P > 4000000L) return -3;   // gridDim.y of the P x N GEMMs; callers chunk larger batches
     Bwd b{stream, P};
     b.zero = ws + P * (256L * 3 + DIN_LD + 32 + 12) + DB_SCRATCH - 64;   // tail of the (zeroed) bias-gradient scratch, never written
@@ -734,8 +752,9 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
         (void)boff; (void)dbl;
     };
 
-    // ================= seg branch: seg = fc_seg(s3), s_i = lrelu(layers_seg[i](.)) (modules.py:289-294) =================
     const float *A = actbuf;
+    if (do_rad) {
+    // ================= seg branch: seg = fc_seg(s3), s_i = lrelu(layers_seg[i](.)) (modules.py:289-294) =================
     {
         const float *dseg = d_raw + 3;   // (P,12), ld 16
         float *dbl = newdb(N_SEG, Lv.segout_b);
@@ -828,6 +847,11 @@ extern "C" int SAHS_SYM(sahs_field_backward_launch)(const float *flat, const flo
         grid_transpose_kernel<<<tb, 256, 0, stream>>>(dgrid_cl, G(F.grid), 1); b.check();
         encode_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, din, dxw, dw); b.check();
     }
+    }   // do_rad
+    // ---- the seam: d x' (P,4) and d w (P,4) ----
+    if (do_rad && !do_def && xwg_out != nullptr) { b.copy(dxw, 4, 4, xwg_out, 8, 0); b.copy(dw, 4, 4, xwg_out + 4, 8, 0); }
+    if (xwg_in != nullptr && do_def) { b.copy(xwg_in, 8, 4, dxw, 4, do_rad ? 1 : 0); b.copy(xwg_in + 4, 8, 4, dw, 4, do_rad ? 1 : 0); }
+    if (!do_def) { if (!b.err && dbo > DB_SCRATCH - 64) b.err = (int)hipErrorOutOfMemory; return b.err; }
 #if SAHS_MODEL != 2
     // ================= hyper sheet (modules.py:444-462): w = fc_ambient(g5) =================
     {

@@ -270,7 +270,6 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                          float *__restrict__ raw, float *__restrict__ dbg, float *__restrict__ actbuf,
                          float *__restrict__ xw, int xw_row, int xw_col0, const int *__restrict__ src)
 {
-    static_assert(!(SAVE && MODE != FIELD_ALL), "activations are saved by whole-network launches only");
 #if SAHS_MODEL == 2
     static_assert(MODE == FIELD_ALL, "this model has no deformation nets to split off");
 #endif
@@ -324,6 +323,7 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
             const float *row = xw + ((p / S) * (long)xw_row + src[p]) * 8;
             const f32x4 a = *reinterpret_cast<const f32x4 *>(row);
             stash[0] = a[0]; stash[1] = a[1]; stash[2] = a[2]; stash[3] = a[3]; stash[4] = row[4];
+            if (sv_on) { float *d = SVP(act::XW, 16); d[0] = a[0]; d[1] = a[1]; d[2] = a[2]; }   // the grid backward reads x'
         }
         if constexpr (MODE != FIELD_RADIANCE) {
 #if SAHS_MODEL == 2
@@ -559,14 +559,26 @@ extern "C" int SAHS_SYM(sahs_field_forward_f32_launch)(const float *packed, cons
 
 // The split evaluation (see the kernel's MODE): mode 0 = whole network, additionally writing x', w of every sample to xw; mode 1 =
 // deformation nets only (raw unused); mode 2 = radiance net only on x', w fetched through src (zvals unused).
+// actbuf != nullptr: also save the activations of the layers the launch runs (training).  A saved array of act:: column c starts at
+// actbuf + c * P as for whole-network launches, so a radiance-only launch touches columns >= act::XW only and a deformation-only launch
+// columns < act::XW + 16: the caller may pass a base such that only that range is backed by memory (sahs_layout_act_part_words).
 extern "C" int SAHS_SYM(sahs_field_forward_f32_split_launch)(const float *packed, const float *frame, int level, int mode, long P, int S,
                                                    const float *rays, int ray_stride, const float *zvals, float *raw, float *xw, int xw_row,
-                                                   int xw_col0, const int *src, int num_cu, hipStream_t stream)
+                                                   int xw_col0, const int *src, float *actbuf, int num_cu, hipStream_t stream)
 {
     if (P <= 0) return 0;
 #if SAHS_MODEL == 2
     return -3;      // no deformation nets in this model
 #else
+    if (actbuf != nullptr) {
+        if (mode == FIELD_ALL)
+            return launch_field<true, FIELD_ALL>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, nullptr, actbuf, xw, xw_row, xw_col0, nullptr, num_cu, stream);
+        if (mode == FIELD_DEFORM)
+            return launch_field<true, FIELD_DEFORM>(packed, frame, level, P, S, rays, ray_stride, zvals, nullptr, nullptr, actbuf, xw, xw_row, xw_col0, nullptr, num_cu, stream);
+        if (mode == FIELD_RADIANCE)
+            return launch_field<true, FIELD_RADIANCE>(packed, frame, level, P, S, rays, ray_stride, nullptr, raw, nullptr, actbuf, xw, xw_row, 0, src, num_cu, stream);
+        return -2;
+    }
     if (mode == FIELD_ALL)
         return launch_field<false, FIELD_ALL>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, nullptr, nullptr, xw, xw_row, xw_col0, nullptr, num_cu, stream);
     if (mode == FIELD_DEFORM)
@@ -576,3 +588,8 @@ extern "C" int SAHS_SYM(sahs_field_forward_f32_split_launch)(const float *packed
     return -2;
 #endif
 }
+
+// words per sample of the saved activations a launch of `part` writes / a backward of `part` reads, and the first act:: column of that
+// range: part 0 whole network [0, STRIDE); 1 deformation nets [0, XW + 16); 2 radiance nets [XW, STRIDE)
+extern "C" int SAHS_SYM(sahs_layout_act_part_words)(int part) { return part == 1 ? act::XW + 16 : (part == 2 ? act::STRIDE - act::XW : act::STRIDE); }
+extern "C" int SAHS_SYM(sahs_layout_act_part_col0)(int part) { return part == 2 ? act::XW : 0; }

@@ -318,6 +318,34 @@ extern "C" int sahs_composite_forward_launch(long N, int S, const float *raw, co
     return (int)hipGetLastError();
 }
 
+// The fine pass's gradient w.r.t. (x', w) of its samples, (N, Sc+nf, 8) rows in sorted-depth order, routed back through the merge
+// permutation to the samples that produced them: slots < Sc are the coarse pass's samples, the others the new depths (training with
+// the deformation nets evaluated once per depth; src is a permutation per ray, so every output row is written exactly once).
+__global__ void __launch_bounds__(256) route_xw_grad_kernel(long N, int Sc, int nf, const int *__restrict__ src, const float *__restrict__ g_fine,
+                                                            float *__restrict__ g_coarse, float *__restrict__ g_new)
+{
+    const int Sf = Sc + nf;
+    const long total = N * Sf * 2;       // two float4 per row
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e >> 1;
+        const int half = (int)(e & 1);
+        const long ray = row / Sf;
+        const int slot = src[row];
+        const f32x4 v = reinterpret_cast<const f32x4 *>(g_fine)[e];
+        float *dst = slot < Sc ? g_coarse + (ray * Sc + slot) * 8 : g_new + (ray * nf + (slot - Sc)) * 8;
+        reinterpret_cast<f32x4 *>(dst)[half] = v;
+    }
+}
+
+extern "C" int sahs_route_xw_grad_launch(long N, int Sc, int nf, const int *src, const float *g_fine, float *g_coarse, float *g_new, hipStream_t stream)
+{
+    const long total = N * (Sc + nf) * 2;
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    route_xw_grad_kernel<<<(int)blocks, 256, 0, stream>>>(N, Sc, nf, src, g_fine, g_coarse, g_new);
+    return (int)hipGetLastError();
+}
+
 extern "C" int sahs_resample_launch(long N, int S, int nf, int from_z, const float *z, const float *weights, const float *u,
                                     float *z_samples, float *z_out, long long *inds, int *src, hipStream_t stream)
 {

@@ -320,6 +320,51 @@ def field_backward(flat, frame, level, act, d_raw, grad_flat, grad_cond, arch="a
     check(f(_p(flat), _p(frame), int(level), P, _p(act), _p(d_raw), _p(grad_flat), _p(grad_cond), _p(ws), _stream()), name)
 
 
+def field_forward_split_save(packed, frame, level, mode, rays, xw, z=None, src=None, xw_col0=0, arch="audio"):
+    """field_forward_split (fp32) that also keeps the activations of the layers it runs -> (raw or None, act).  act is the part's
+    own buffer, (P, act_words_part(mode)) floats as dense per-layer planes; only field_backward_split of the same part reads it."""
+    packed, frame, rays, z = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays"), _req(z, "z")
+    src, xw = _req(src, "src", torch.int32), _req(xw, "xw")
+    N = rays.shape[0]
+    S = src.shape[1] if mode == FIELD_RADIANCE else z.shape[1]
+    if xw.dim() != 3 or xw.shape[0] != N or xw.shape[2] != 8:
+        raise _lib.SahsError("xw must be (N, row, 8)")
+    raw = None if mode == FIELD_DEFORM else torch.empty(N, S, 16, dtype=torch.float32, device=rays.device)
+    act = torch.empty(N * S, _fn("act_words_part", arch)[0](int(mode)), dtype=torch.float32, device=rays.device)
+    f, name = _fn("field_forward_split_save", arch)
+    check(f(_p(packed), _p(frame), int(level), int(mode), N, int(S), _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(xw), int(xw.shape[1]), int(xw_col0),
+            _p(src), _p(act), _stream()), name)
+    return raw, act
+
+
+def field_backward_split(flat, frame, level, part, act, grad_flat, grad_cond, d_raw=None, xw_grad_in=None, want_xw_grad=False, arch="audio"):
+    """Backward of `part` (FIELD_DEFORM, FIELD_RADIANCE, or 3 = everything) of the field over activations saved by the forward of that
+    part.  The seam is d loss / d (x', w), (P,8): FIELD_RADIANCE returns it, FIELD_DEFORM starts from xw_grad_in, 3 adds xw_grad_in."""
+    flat, frame, act = _req(flat, "flat_params"), _req(frame, "frame"), _req(act, "act")
+    d_raw, xw_grad_in = _req(d_raw, "d_raw"), _req(xw_grad_in, "xw_grad_in")
+    P = act.shape[0]
+    if act.shape[1] != _fn("act_words_part", arch)[0](int(part)):
+        raise _lib.SahsError("field_backward_split: the activations were not saved by a forward of part %d" % part)
+    if xw_grad_in is not None and xw_grad_in.numel() != P * 8:
+        raise _lib.SahsError("field_backward_split: xw_grad_in must hold (P,8)")
+    out = torch.empty(P, 8, dtype=torch.float32, device=act.device) if (part == FIELD_RADIANCE or want_xw_grad) else None
+    ws = torch.empty(_fn("field_backward_workspace_words", arch)[0](P), dtype=torch.float32, device=act.device)
+    f, name = _fn("field_backward_split", arch)
+    check(f(_p(flat), _p(frame), int(level), int(part), P, _p(act), _p(d_raw), _p(xw_grad_in), _p(out), _p(grad_flat), _p(grad_cond), _p(ws), _stream()), name)
+    return out
+
+
+def route_xw_grad(src, g_fine, num_coarse):
+    """(N,Sf) merge permutation, (N*Sf,8) seam gradient of the fine samples -> (N*Sc,8) for the coarse samples, (N*nf,8) for the new depths."""
+    src, g_fine = _req(src, "src", torch.int32), _req(g_fine, "g_fine")
+    N, Sf = src.shape
+    nf = Sf - int(num_coarse)
+    g_c = torch.empty(N * int(num_coarse), 8, dtype=torch.float32, device=src.device)
+    g_n = torch.empty(N * nf, 8, dtype=torch.float32, device=src.device)
+    check(_lib.lib().sahs_route_xw_grad(N, int(num_coarse), nf, _p(src), _p(g_fine), _p(g_c), _p(g_n), _stream()), "sahs_route_xw_grad")
+    return g_c, g_n
+
+
 LOSS_STATS_WORDS = 64      # include/sahs_nerf.h: [0] loss, [1] last level's mse, [2:14] new sample_prob, [14:26] class counts, [26] rays
 
 
@@ -439,6 +484,8 @@ class RenderRaysFn(torch.autograd.Function):
     block by block in backward.  backward: per level -- composite backward, field backward -- then the conditioning backward."""
 
     BLOCK_RAYS = 4096
+    SHARE_DEFORMATION = True      # kept path: deformation nets once per depth, forward AND backward (the fine pass's gradient w.r.t. the
+                                  # coarse samples' (x', w) is added at the seam of the coarse pass's backward); False = the plain chain
 
     @staticmethod
     def forward(ctx, flat, audio, pose, rays, bg, t_rand, noise_c, u, noise_f, packed, num_coarse, num_fine, lindisp, white_background,
@@ -464,6 +511,21 @@ class RenderRaysFn(torch.autograd.Function):
         none = torch.empty(0, device=rays.device)
         ctx.cfg = (num_coarse, num_fine, bool(white_background), bg is not None, noise_c is not None, noise_f is not None)
         ctx.kept = rays.shape[0] <= RenderRaysFn.BLOCK_RAYS and num_fine > 0
+        ctx.shared = ctx.kept and RenderRaysFn.SHARE_DEFORMATION and arch != "nerface_static"
+        if ctx.shared:   # the launch chain of sahs_model_render_rays_rows' split evaluation, with the activations of every launch kept
+            N = rays.shape[0]
+            z_c = stratified_depths(rays, num_coarse, lindisp, t_rand)
+            xw = torch.empty(N, num_coarse + num_fine, 8, dtype=torch.float32, device=rays.device)
+            raw_c, act_c = field_forward_split_save(packed, frame, 0, FIELD_ALL, rays, xw, z=z_c, arch=arch)
+            rgb_c, disp_c, acc_c, w_c, _ = composite_forward(raw_c, z_c, rays, noise_c, bg, white_background)
+            z_f, z_new, src = resample_merge(z_c, w_c, num_fine, u=u)
+            _, act_d = field_forward_split_save(packed, frame, 1, FIELD_DEFORM, rays, xw, z=z_new, xw_col0=num_coarse, arch=arch)
+            raw_f, act_r = field_forward_split_save(packed, frame, 1, FIELD_RADIANCE, rays, xw, src=src, arch=arch)
+            del xw
+            rgb_f, disp_f, acc_f, w_f, depth_f = composite_forward(raw_f, z_f, rays, noise_f, bg, white_background)
+            outs = (rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_f[:, -1].contiguous(), depth_f)
+            return with_loss(outs, (flat.detach(), audio.detach(), rays, z_c, z_f, frame, packed,
+                                    *[t if t is not None else none for t in (bg, noise_c, noise_f)], raw_c, act_c, raw_f, act_r, act_d, src))
         if ctx.kept:     # the same launch chain as sahs_render_rays, with the field activations kept
             z_c = stratified_depths(rays, num_coarse, lindisp, t_rand)
             raw_c, act_c = field_forward_save(packed, frame, 0, rays, z_c, arch)
@@ -489,6 +551,8 @@ class RenderRaysFn(torch.autograd.Function):
             loss_ops = {0: map_c, 1: map_f}
             gscale = g_loss.detach().float().reshape(1).contiguous()
         kept = dict(zip((0, 1), (ctx.saved_tensors[10:12], ctx.saved_tensors[12:14]))) if ctx.kept else None
+        act_d, src = (ctx.saved_tensors[14], ctx.saved_tensors[15]) if ctx.shared else (None, None)
+        xwg_coarse = None      # shared deformation: the fine pass's seam gradient that belongs to the coarse samples
         nc, nf, white, has_bg, has_nc, has_nf = ctx.cfg
         bg = bg if has_bg else None
         noise_c = noise_c if has_nc else None
@@ -513,14 +577,23 @@ class RenderRaysFn(torch.autograd.Function):
                 lvl_loss = None
                 if loss_ops is not None:      # with nf == 0 the only pass is level 0 and its map is the coarse one
                     lvl_loss = (loss_ops[level][sl].contiguous(), l_tgt[sl].contiguous(), l_msk[sl].contiguous(), l_stats, gscale)
-                if lvl_loss is None and all(g is None for g in grads):
+                if lvl_loss is None and all(g is None for g in grads) and not (level == 0 and xwg_coarse is not None):
                     continue
                 zb = z[sl].contiguous()
                 raw, act = kept[level] if kept is not None else field_forward_save(packed, frame, level, rb, zb, ctx.arch)
                 nb = None if noise is None else noise[sl].contiguous()
                 gb = [None if g is None else c(g[sl]) for g in grads]
                 d_raw = composite_backward(raw, zb, rb, nb, bgb, white, *gb, loss=lvl_loss)
-                field_backward(flat, frame, level, act, d_raw.view(-1, 16), grad_flat, grad_cond, ctx.arch)
+                if ctx.shared:      # (kept path: one block, sl covers every ray)
+                    if level == 1:
+                        g_f = field_backward_split(flat, frame, 1, FIELD_RADIANCE, act, grad_flat, grad_cond, d_raw=d_raw.view(-1, 16), arch=ctx.arch)
+                        xwg_coarse, g_new = route_xw_grad(src, g_f, nc)
+                        field_backward_split(flat, frame, 1, FIELD_DEFORM, act_d, grad_flat, grad_cond, xw_grad_in=g_new, arch=ctx.arch)
+                        del g_f, g_new
+                    else:
+                        field_backward_split(flat, frame, 0, 3, act, grad_flat, grad_cond, d_raw=d_raw.view(-1, 16), xw_grad_in=xwg_coarse, arch=ctx.arch)
+                else:
+                    field_backward(flat, frame, level, act, d_raw.view(-1, 16), grad_flat, grad_cond, ctx.arch)
                 del raw, act, d_raw
         if ctx.arch == "audio":
             check(_lib.lib().sahs_conditioning_backward(_p(flat), _p(audio), _p(grad_cond), _p(grad_flat), _p(grad_audio), _stream()),

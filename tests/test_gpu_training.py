@@ -165,6 +165,59 @@ def test_train_step_vs_reference_fixture(flat_weights, fused):
     assert e_audio <= 2.0 * ref_audio + 1e-4, res
 
 
+@pytest.mark.parametrize("arch", ["audio", "nerface"])
+def test_shared_deformation_training_matches_plain_chain(arch, weights_mod):
+    """Training with the deformation nets evaluated once per depth (forward launches FIELD_ALL / FIELD_DEFORM / FIELD_RADIANCE with saved
+    activations; backward cut at the (x', w) seam, the fine pass's seam gradient routed through the merge permutation into the coarse
+    pass's backward) against the plain chain (whole network per level): identical outputs bit for bit, gradients equal up to the
+    summation order of the float atomics."""
+    sahs, ops = pkg(), pkg("ops")
+    dev = torch.device("cuda:0")
+    model_name = "audio" if arch == "audio" else "nerface"
+    fw = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 2.0, 30.0, model=model_name, hdr=(arch == "audio")), model=model_name)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    N, nc, nf = 193, 64, 128 if arch == "audio" else 64
+    drv = torch.randn(16, 29, device=dev, generator=gen) if arch == "audio" else torch.randn(76, device=dev, generator=gen) * 0.5
+    cam = 0.8 if arch == "audio" else 0.5
+    pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [cam]]], 1).astype(np.float32)).to(dev)
+    near, far = (0.483771, 1.083771) if arch == "audio" else (0.2, 0.8)
+    rays = torch.zeros(N, 8, device=dev)
+    rays[:, 2] = cam
+    rays[:, 3:6] = torch.randn(N, 3, device=dev, generator=gen) * 0.15 + torch.tensor([0, 0, -1.0], device=dev)
+    rays[:, 6], rays[:, 7] = near, far
+    bg = torch.cat([torch.rand(N, 3, device=dev, generator=gen), torch.ones(N, 1, device=dev), torch.zeros(N, 11, device=dev)], 1)
+    t_rand, u = torch.rand(N, nc, device=dev, generator=gen), torch.rand(N, nf, device=dev, generator=gen)
+    noise_c, noise_f = torch.randn(N, nc, device=dev, generator=gen) * 0.1, torch.randn(N, nc + nf, device=dev, generator=gen) * 0.1
+    A = [torch.randn(N, 15, device=dev, generator=gen) for _ in range(2)]
+    res = {}
+    try:
+        for share in (False, True):
+            ops.RenderRaysFn.SHARE_DEFORMATION = share
+            flat = torch.from_numpy(fw).to(dev).requires_grad_(True)
+            d = drv.clone().requires_grad_(True)
+            packed = ops.pack_weights(flat.detach(), arch=arch)
+            outs = ops.RenderRaysFn.apply(flat, d, pose, rays, bg, t_rand, noise_c, u, noise_f, packed, nc, nf, False, False, arch)
+            loss = (outs[0] * A[0]).sum() + (outs[3] * A[1]).sum() + 0.3 * outs[7].sum() + 0.2 * outs[6].sum() + 0.1 * outs[1].sum()
+            loss.backward()
+            res[share] = ([o.detach().clone() for o in outs], flat.grad.clone(), d.grad.clone())
+    finally:
+        ops.RenderRaysFn.SHARE_DEFORMATION = True
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b)
+    for k, nm in ((1, "parameters"), (2, "driving input")):
+        a, b = res[False][k], res[True][k]
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-4 * scale, (nm, float((a - b).abs().max()), scale)
+    # per parameter tensor too (a small tensor must not hide behind the global scale): norms within 1e-3
+    off = 0
+    for name, shape in weights_mod.canonical_spec(model_name):
+        n = int(np.prod(shape))
+        ga, gb = res[False][1][off:off + n], res[True][1][off:off + n]
+        na = float(ga.norm())
+        assert abs(na - float(gb.norm())) <= 1e-3 * na + 1e-12, (name, na, float(gb.norm()))
+        off += n
+
+
 def test_stage1_loss_kernel_vs_loss_modules():
     """sahs_stage1_loss_forward against the torch statement of the reference's loss modules (pinned to the reference's own classes by
     tests/golden/losses.npz on CPU): ragged ray count, an empty class, a one-ray class, coarse-only; and its gradient, formed inside
