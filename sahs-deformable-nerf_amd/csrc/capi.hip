@@ -73,6 +73,12 @@ int sahs_route_xw_grad_launch(long N, int Sc, int nf, const int *src, const floa
 SAHS_DECLARE_MODEL()
 SAHS_DECLARE_MODEL(_nf)
 SAHS_DECLARE_MODEL(_ns)
+// NeRFaceModel (with deformation) in mixed precision: bf16 radiance nets (field_bf16w.hip built with SAHS_MODEL=1), fp32 deformation nets
+long sahs_layout_packed_words_bf16_nf(void);
+int sahs_pack_weights_bf16_launch_nf(const float *flat, float *packed, hipStream_t stream);
+int sahs_field_forward_bf16w_split_launch_nf(const float *packed, const float *frame, int level, int mode, long P, int S, const float *rays,
+                                             int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
+                                             int num_cu, hipStream_t stream);
 }
 
 static thread_local char g_err[512] = "";
@@ -357,11 +363,15 @@ long sahs_model_packed_words(int model, int precision)
 {
     if (model < 0 || model > 2) return -1;
     if (model == SAHS_MODEL_AUDIO) return sahs_packed_words(precision);
+    if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)     // mixed precision: [bf16 radiance pack | fp32 pack (deformation nets)]
+        return sahs_layout_packed_words_bf16_nf() + kModels[model].packed_words_f32();
     return precision == SAHS_F32 ? kModels[model].packed_words_f32() : -1;
 }
 long sahs_model_executed_macs_part(int model, int precision, int part)
 {
     if (model < 0 || model > 2 || precision < SAHS_F32 || precision > SAHS_BF16_2W || part < 0 || part > 2) return -1;
+    if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)      // mixed: fp32 deformation nets + bf16 radiance nets
+        return (part != 2 ? sahs_layout_executed_macs_nf(SAHS_F32, 1) : 0) + (part != 1 ? sahs_layout_executed_macs_nf(SAHS_BF16, 2) : 0);
     return model == 0 ? sahs_layout_executed_macs(precision, part)
                       : (model == 1 ? sahs_layout_executed_macs_nf(precision, part) : sahs_layout_executed_macs_ns(precision, part));
 }
@@ -373,6 +383,11 @@ int sahs_model_pack_weights(int model, const float *flat_params, void *packed, i
     REQUIRE_MODEL(model, "sahs_model_pack_weights");
     if (model == SAHS_MODEL_AUDIO) return sahs_pack_weights(flat_params, packed, precision, stream);
     REQUIRE(flat_params && packed && ALIGNED16(packed), "sahs_model_pack_weights");
+    if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16) {
+        int e = sahs_pack_weights_bf16_launch_nf(flat_params, (float *)packed, (hipStream_t)stream);
+        if (!e) e = kModels[model].pack_f32(flat_params, (float *)packed + sahs_layout_packed_words_bf16_nf(), (hipStream_t)stream);
+        return e ? hip_fail("sahs_model_pack_weights", e) : 0;
+    }
     if (precision != SAHS_F32) return fail(2, "sahs_model_pack_weights: only SAHS_F32 is built for this model %s%ld", "", precision);
     int e = kModels[model].pack_f32(flat_params, (float *)packed, (hipStream_t)stream);
     return e ? hip_fail("sahs_model_pack_weights", e) : 0;
@@ -395,6 +410,9 @@ static int field_forward_model(int model, const void *packed, const float *frame
     REQUIRE(packed && frame && rays && z && raw, "sahs_model_field_forward");
     REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_model_field_forward(shape)");
     REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_model_field_forward(alignment)");
+    if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)
+        return fail(2, "sahs_model_field_forward: the mixed-precision NeRFaceModel runs through sahs_model_field_forward_split / "
+                       "sahs_model_render_rays_rows (it needs the xw workspace)%s%ld", "", 0L);
     if (precision != SAHS_F32) return fail(2, "sahs_model_field_forward: only SAHS_F32 is built for this model %s%ld", "", precision);
     int e = kModels[model].field_f32((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, nullptr, num_cus(),
                                      (hipStream_t)stream);
@@ -460,9 +478,22 @@ int sahs_model_field_forward_split(int model, const void *packed, const float *f
     if (model == SAHS_MODEL_NERFACE_STATIC) return fail(4, "sahs_model_field_forward_split: this model has no deformation nets%s%ld", "", 0L);
     REQUIRE(packed && frame && rays && xw && (level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8 && mode >= 0 && mode <= 2,
             "sahs_model_field_forward_split");
-    REQUIRE((mode == 1 || raw) && (mode == 2 || z) && (mode != 2 || src), "sahs_model_field_forward_split(buffers of the mode)");
+    const bool mixed = precision == SAHS_BF16 && model == SAHS_MODEL_NERFACE;
+    REQUIRE((mode == 1 || raw) && (mode == 2 || z) && (mode != 2 || src || mixed), "sahs_model_field_forward_split(buffers of the mode)");
     REQUIRE(xw_col0 >= 0 && xw_row >= xw_col0 + (mode == 2 ? 0 : S) && ALIGNED16(xw) && ALIGNED16(packed) && ALIGNED16(frame) && (!raw || ALIGNED16(raw)),
             "sahs_model_field_forward_split(xw layout / alignment)");
+    if (mixed) {      // deformation nets by the fp32 kernel, radiance nets by the bf16 kernel; mode 0 = both, one after the other
+        const float *pk16 = (const float *)packed, *pk32 = pk16 + sahs_layout_packed_words_bf16_nf();
+        REQUIRE(mode != 0 || xw_col0 == 0, "sahs_model_field_forward_split(mixed precision, mode 0: xw_col0 must be 0)");
+        int e = 0;
+        if (mode != 2)
+            e = sahs_field_forward_f32_split_launch_nf(pk32, frame, level, 1, N * S, S, rays, ray_stride, z, nullptr, xw, xw_row, xw_col0, nullptr, nullptr,
+                                                       num_cus(), (hipStream_t)stream);
+        if (!e && mode != 1)
+            e = sahs_field_forward_bf16w_split_launch_nf(pk16, frame, level, 2, N * S, S, rays, ray_stride, nullptr, raw, xw, xw_row, 0, mode == 2 ? src : nullptr,
+                                                         num_cus(), (hipStream_t)stream);
+        return e ? hip_fail("sahs_model_field_forward_split", e) : 0;
+    }
     if (precision != SAHS_F32 && !(precision == SAHS_BF16 && model == SAHS_MODEL_AUDIO))
         return fail(4, "sahs_model_field_forward_split: precision %s%ld is not built for this model", "", (long)precision);
     int e = precision == SAHS_BF16
@@ -566,7 +597,9 @@ int sahs_model_render_rays_rows(int model, const void *packed, const float *fram
     REQUIRE_MODEL(model, "sahs_model_render_rays_rows");
     if (N == 0) return 0;
     REQUIRE(rows && row_ld >= SAHS_ROW_COLUMNS, "sahs_model_render_rays_rows(rows)");
-    if (xw && src && z_new && nf > 0 && ((precision == SAHS_F32 && model != SAHS_MODEL_NERFACE_STATIC) || (precision == SAHS_BF16 && model == SAHS_MODEL_AUDIO))) {
+    if (precision == SAHS_BF16 && model == SAHS_MODEL_NERFACE)
+        REQUIRE(xw && src && z_new && nf > 0, "sahs_model_render_rays_rows(the mixed-precision NeRFaceModel needs the xw / src / z_new workspace and nf > 0)");
+    if (xw && src && z_new && nf > 0 && ((precision == SAHS_F32 && model != SAHS_MODEL_NERFACE_STATIC) || (precision == SAHS_BF16 && model != SAHS_MODEL_NERFACE_STATIC))) {
         // the deformation nets are shared by the two levels and the fine depths contain the coarse ones: evaluate them once per depth
         const char *who = "sahs_model_render_rays_rows";
         REQUIRE(packed && frame && rays && z_c && z_f && raw && weights && Sc + nf <= 256, who);

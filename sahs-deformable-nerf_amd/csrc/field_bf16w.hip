@@ -20,7 +20,7 @@
 #include "sahs_common.hpp"
 #include "sahs_layout.hpp"
 
-namespace sahs {
+namespace SAHS_NS {
 namespace hw {
 using namespace hb;      // the bf16 layer program, chunking and packed layout of sahs_layout.hpp
 
@@ -30,8 +30,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-enum { FIELD_ALL = 0, FIELD_DEFORM = 1, FIELD_RADIANCE = 2 };      // the kernel's MODE (same values as field_f32.hip / SAHS_FIELD_*)
-constexpr int NH = 2;                              // 32-sample halves per wave
+enum { FIELD_ALL = 0, FIELD_DEFORM = 1, FIELD_RADIANCE = 2 };
+constexpr int KX32 = (KB_XYZ + 1) / 2, KA32 = (KB_AMB + 1) / 2;     // 32-feature blocks of PE(x') and PE(w): 2, 1 | 3, 1 (NeRFaceModel)      // the kernel's MODE (same values as field_f32.hip / SAHS_FIELD_*)
+constexpr int NH = 2;                              // 32-sample halves per wave (1 also builds: the tick / slot maps below are written over NH)
+constexpr int NV = 16 * NH;                        // accumulator values of an output tile per lane
 struct Blk { u32x4 s[NH][2]; };                    // 32 features of this lane's two samples: [half][k-step] bf16x8 fragments (as dwords)
 
 constexpr int W_THREADS = 256;
@@ -181,30 +183,30 @@ template <int T>
 __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float slope, PackState &ps)
 {
 #ifdef SAHS_ABLATE_NOPACK
-    if (T == 0) asm volatile("" :: "v"(acc[0]), "v"(acc[1]));     // keep the chains alive, convert nothing
+    if (T == 0) asm volatile("" :: "v"(acc[0]), "v"(acc[NH - 1]));     // keep the chains alive, convert nothing
     return;
 #endif
 #ifdef SAHS_X_SLOPE1                // timing-only experiments (results wrong by construction)
     slope = 1.0f;
 #endif
 #ifdef SAHS_X_EXTRAVALU
-    if constexpr (T >= 0 && T < 32) { float dmy; asm volatile("v_max_f32 %0, %1, %1" : "=v"(dmy) : "v"(acc[0][T & 15])); }
+    if constexpr (T >= 0 && T < NV) { float dmy; asm volatile("v_max_f32 %0, %1, %1" : "=v"(dmy) : "v"(acc[0][T & 15])); }
 #endif
 #ifndef SAHS_BF16W_FP32_RELU
     if (slope == 0.0f) {
-        if constexpr (T - 2 >= 1 && T - 2 < 32 && ((T - 2) & 1)) {
-            constexpr int U = T - 2, P = U >> 1, hh = P & 1, q = P >> 1;
+        if constexpr (T - 2 >= 1 && T - 2 < NV && ((T - 2) & 1)) {
+            constexpr int U = T - 2, P = U >> 1, hh = P % NH, q = P / NH;
             ps.d[P & 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{acc[hh][2 * q], acc[hh][2 * q + 1]}, bf16x2));
         }
-        if constexpr (T - 4 >= 1 && T - 4 < 32 && ((T - 4) & 1)) {
-            constexpr int U = T - 4, P = U >> 1, hh = P & 1, q = P >> 1, s = q >> 2, jp = q & 3;
+        if constexpr (T - 4 >= 1 && T - 4 < NV && ((T - 4) & 1)) {
+            constexpr int U = T - 4, P = U >> 1, hh = P % NH, q = P / NH, s = q >> 2, jp = q & 3;
             o.s[hh][s][jp] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ps.d[P & 1]), s16x2{0, 0}));
         }
         return;
     }
 #endif
-    if constexpr (T >= 0 && T < 32 && !(T & 1)) {           // A(T), T even: both values of the pair in one v_pk_mul_f32
-        constexpr int P = T >> 1, hh = P & 1, q = P >> 1;
+    if constexpr (T >= 0 && T < NV && !(T & 1)) {           // A(T), T even: both values of the pair
+        constexpr int P = T >> 1, hh = P % NH, q = P / NH;
         if (slope != 0.0f && slope != 1.0f) {
             const f32x2 pr = f32x2{acc[hh][2 * q], acc[hh][2 * q + 1]}, sl = f32x2{slope, slope};
 #ifdef SAHS_BF16W_PKMUL     // measured SLOWER (23.6 vs 22.3 ms per fine launch) although it halves the multiplies: kept as an experiment
@@ -215,17 +217,17 @@ __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float
         }
     }
     constexpr int DB = 1, DC = 2;       // stage distances in ticks (2 and 4 measured: no change, 46.1-48.2 vs 46.9-48.0 cycles per MFMA)
-    if constexpr (T - DB >= 0 && T - DB < 32) {             // B(T-1)
-        constexpr int U = T - DB, P = U >> 1, hh = P & 1, q = P >> 1, e = U & 1;
+    if constexpr (T - DB >= 0 && T - DB < NV) {             // B(T-1)
+        constexpr int U = T - DB, P = U >> 1, hh = P % NH, q = P / NH, e = U & 1;
         const float v = acc[hh][2 * q + e];
         ps.r[U & 3] = slope == 1.0f ? v : (slope == 0.0f ? fmaxf(v, 0.0f) : fmaxf(v, ps.m2[P & 1][e]));
     }
-    if constexpr (T - DC >= 1 && T - DC < 32 && ((T - DC) & 1)) {    // C(T-2): the pair (T-3, T-2) is complete
-        constexpr int U = T - DC, P = U >> 1, hh = P & 1, q = P >> 1, s = q >> 2, jp = q & 3;
+    if constexpr (T - DC >= 1 && T - DC < NV && ((T - DC) & 1)) {    // C(T-2): the pair (T-3, T-2) is complete
+        constexpr int U = T - DC, P = U >> 1, hh = P % NH, q = P / NH, s = q >> 2, jp = q & 3;
         o.s[hh][s][jp] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ps.r[(U - 1) & 3], ps.r[U & 3]}, bf16x2));
     }
 }
-constexpr int PACK_TICKS = 36;
+constexpr int PACK_TICKS = NV + 4;
 template <int LO, int HI>
 __device__ __forceinline__ void pack_ticks(const f32x16 (&acc)[NH], Blk &o, float slope, PackState &ps)
 {
@@ -307,18 +309,19 @@ __device__ __forceinline__ void dense_w(Ctx &cx, St &st, Blk *in0, const Blk *in
                 fence();
                 if constexpr (hh == 0) {
                     if constexpr (S::bias_at(I)) bias_read<128 * (t + 1)>(braw[set ^ 1], baddr);
-                } else {
+                }
+                if constexpr (hh == NH - 1) {
 #ifndef SAHS_X_NOAREAD              // timing-only experiment: the A fragments of the prologue are reused (results wrong by construction)
                     if constexpr (S::aread_at(I)) lds_read16<(I + AP) * 1024>(a[I % AP], abase);
 #endif
                     if constexpr (I % PSTEP == 0 && I / PSTEP < npieces) cx.issue_piece(I / PSTEP);
                 }
                 if constexpr (t > 0 && k >= 1) {              // the finished tile t-1 -> out[t-1]: this slot's share of its conversion ticks
-                    constexpr int NSLOT = 2 * STEPS - 2, slot = 2 * (k - 1) + hh;
+                    constexpr int NSLOT = NH * (STEPS - 1), slot = NH * (k - 1) + hh;
                     constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
                     if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[set ^ 1], out[t - 1], slope, st.ps);
                 } else if constexpr (PEND && t == 0 && k >= 1 && k <= 2 * K0 - 3) {     // the previous layer's last tile -> in0[K0-1]
-                    constexpr int NSLOT = 2 * (2 * K0 - 3), slot = 2 * (k - 1) + hh;
+                    constexpr int NSLOT = NH * (2 * K0 - 3), slot = NH * (k - 1) + hh;
                     constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
                     if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[1], in0[K0 - 1], pslope, st.ps);
                 }
@@ -370,12 +373,12 @@ __device__ __forceinline__ void dense_w_out(Ctx &cx, St &st, Blk *in0, f32x16 (&
             constexpr int hh = decltype(Q)::value;
             acc[hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(a[I % AP]), frag(in0[I >> 1].s[hh][I & 1]), acc[hh], 0, 0, 0);
             fence();
-            if constexpr (hh == 1) {
+            if constexpr (hh == NH - 1) {
                 if constexpr (I + AP < TOTAL) lds_read16<(I + AP) * 1024>(a[I % AP], abase);
                 if constexpr (I < npieces) cx.issue_piece(I);
             }
             if constexpr (I >= 1 && I <= 2 * K0 - 3) {        // the previous layer's last tile -> in0[K0-1], before step 2 (K0 - 1) reads it
-                constexpr int NSLOT = 2 * (2 * K0 - 3), slot = 2 * (I - 1) + hh;
+                constexpr int NSLOT = NH * (2 * K0 - 3), slot = NH * (I - 1) + hh;
                 constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
                 if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[1], in0[K0 - 1], pslope, st.ps);
             }
@@ -390,17 +393,17 @@ __device__ __forceinline__ void dense_w_out(Ctx &cx, St &st, Blk *in0, f32x16 (&
 
 // ---- positional encoding (v_sin_f32 in revolutions, as field_bf16.hip) for both halves -------------------------------------------
 struct PeSlot { float scale; float phase; int axis; int kind; };   // kind: 0 zero pad, 1 raw input, 2 sinusoid
-template <int D, int L>
+template <int D, int L, int INC = 1>      // INC: the encoding starts with its input (nerf_helpers.py:305-349 include_input)
 constexpr PeSlot pe_slot(int f)
 {
-    constexpr int W = D + 2 * D * L;
+    constexpr int W = INC * D + 2 * D * L;
     if (f >= W) return PeSlot{0.0f, 0.0f, 0, 0};
-    if (f < D) return PeSlot{1.0f, 0.0f, f, 1};
-    const int g = f - D, k = g / (2 * D), rem = g % (2 * D);
+    if (INC && f < D) return PeSlot{1.0f, 0.0f, f, 1};
+    const int g = f - INC * D, k = g / (2 * D), rem = g % (2 * D);
     return PeSlot{(float)(1 << k), (rem / D) ? 0.25f : 0.0f, rem % D, 2};
 }
 
-template <int D, int L, int NB>
+template <int D, int L, int NB, int INC = 1>
 __device__ __forceinline__ void pe_blocks_w(const float (*v)[3], int h, Blk *out)
 {
     for_halves([&](auto Q) {
@@ -416,7 +419,7 @@ __device__ __forceinline__ void pe_blocks_w(const float (*v)[3], int h, Blk *out
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int f0 = 32 * b + 16 * s + 8 * (j >> 2) + (j & 3);
-                    const PeSlot a = pe_slot<D, L>(f0), c = pe_slot<D, L>(f0 + 4);   // lane half 0 / 1
+                    const PeSlot a = pe_slot<D, L, INC>(f0), c = pe_slot<D, L, INC>(f0 + 4);   // lane half 0 / 1
                     if (a.kind == 0 && c.kind == 0) {
                         r[j] = 0.0f;
                     } else {
@@ -530,6 +533,9 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
 #endif
         cx.stamp();                                   // 0 tile start
         cx.refresh_bias_base();
+        // the chunk sequence is static, so every chunk's source address is loop-invariant: without this the compiler hoists all ~120 of
+        // them out of the persistent loop and spills them (960 bytes of scratch in the NeRFaceModel build)
+        asm volatile("" : "+s"(cx.off));
         St st;
         // this lane's two samples: halves hh = 0, 1 -> sample (wave*64 + hh*32 + col) of the workgroup tile
         long p_raw[NH], p[NH];
@@ -553,7 +559,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
             if (h == 0) {
                 for_halves([&](auto Q) {
                     constexpr int q = decltype(Q)::value;
-                    const float *row = xw + ((p[q] / S) * (long)xw_row + src[p[q]]) * 8;
+                    const float *row = xw + ((p[q] / S) * (long)xw_row + (src != nullptr ? src[p[q]] : (int)(p[q] % S))) * 8;
                     const f32x4 v = *reinterpret_cast<const f32x4 *>(row);
                     stash(q)[0] = v[0]; stash(q)[1] = v[1]; stash(q)[2] = v[2]; stash(q)[3] = v[3];
                     stash(q)[4] = row[4];
@@ -631,17 +637,17 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
         {
             Blk B[8];
             {
-                Blk in_tr[3];
+                Blk in_tr[KX32 + KA32];
                 float xw[NH][3], amb[NH][3];
                 for_halves([&](auto Q) {
                     constexpr int q = decltype(Q)::value;
                     xw[q][0] = stash(q)[0]; xw[q][1] = stash(q)[1]; xw[q][2] = stash(q)[2];
                     amb[q][0] = stash(q)[3]; amb[q][1] = stash(q)[4]; amb[q][2] = 0.0f;
                 });
-                pe_blocks_w<3, 10, 2>(xw, h, in_tr);
-                pe_blocks_w<2, 4, 1>(amb, h, in_tr + 2);
+                pe_blocks_w<3, L_XYZ, KX32>(xw, h, in_tr);
+                pe_blocks_w<AMB_DIM, L_AMB, KA32, AMB_INC>(amb, h, in_tr + KX32);
                 cx.stamp();                           // 4 PE(x'), PE(w)
-                dense_w<2, 1, 0, 8, CH(H_T1), false>(cx, st, in_tr, in_tr + 2, nullptr, A, Ly[H_T0].bias_off, 0.01f, 0.0f);
+                dense_w<KX32, KA32, 0, 8, CH(H_T1), false>(cx, st, in_tr, in_tr + KX32, nullptr, A, Ly[H_T0].bias_off, 0.01f, 0.0f);
                 cx.stamp();                           // 5 T0
             }
             dense_w<8, 0, 0, 8, CH(H_T2), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T1].bias_off, 0.01f, 0.01f);
@@ -649,19 +655,24 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
             dense_w<8, 0, 0, 8, CH(H_T3), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T2].bias_off, 0.01f, 0.01f);
             cx.stamp();                               // 7 T2
             {   // the re-injected encoding [PE(x') | PE(w)] is rebuilt at the skip layer instead of staying live
-                Blk in_tr[3];
+                Blk in_tr[KX32 + KA32];
                 float xw[NH][3], amb[NH][3];
                 for_halves([&](auto Q) {
                     constexpr int q = decltype(Q)::value;
                     xw[q][0] = stash(q)[0]; xw[q][1] = stash(q)[1]; xw[q][2] = stash(q)[2];
                     amb[q][0] = stash(q)[3]; amb[q][1] = stash(q)[4]; amb[q][2] = 0.0f;
                 });
-                pe_blocks_w<3, 10, 2>(xw, h, in_tr);
-                pe_blocks_w<2, 4, 1>(amb, h, in_tr + 2);
+                pe_blocks_w<3, L_XYZ, KX32>(xw, h, in_tr);
+                pe_blocks_w<AMB_DIM, L_AMB, KA32, AMB_INC>(amb, h, in_tr + KX32);
                 cx.stamp();                           // 8 PE again
-                dense_w<8, 2, 1, 8, CH(H_T4), true>(cx, st, A, in_tr, in_tr + 2, B, Ly[H_T3].bias_off, 0.01f, 0.01f);
+#if SAHS_MODEL == 0
+                dense_w<8, KX32, KA32, 8, CH(H_T4), true>(cx, st, A, in_tr, in_tr + KX32, B, Ly[H_T3].bias_off, 0.01f, 0.01f);
+#else           // NeRFaceModel: a 4-layer trunk, the skip layer is its last (modules.py:176)
+                dense_w<8, KX32, KA32, 8, CH(H_FEAT), true>(cx, st, A, in_tr, in_tr + KX32, B, Ly[H_T3].bias_off, 0.01f, 0.01f);
+#endif
                 cx.stamp();                           // 9 T3 (skip)
             }
+#if SAHS_MODEL == 0
 #pragma unroll 1
             for (int j = 0; j < 2; ++j) {     // T4, T5 | T6, T7 (identical shapes: one copy of the code, run twice)
                 dense_w<8, 0, 0, 8, CH(H_T5), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T4].bias_off + 512 * j, 0.01f, 0.01f);
@@ -670,6 +681,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                 if (j == 0) cx.stamp();               // (diagnostic only) first pass through the loop body: instruction-cache cold
 #endif
             }
+#endif
             cx.stamp();                               // 10 T4..T7
             dense_w<8, 0, 0, 8, CH(H_ALPHA), true>(cx, st, B, nullptr, nullptr, A, Ly[H_FEAT].bias_off, 1.0f, 0.01f);
             cx.stamp();                               // 11 feat
@@ -722,10 +734,10 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
 }
 
 }  // namespace hw
-}  // namespace sahs
+}  // namespace SAHS_NS
 
-using namespace sahs;
-using namespace sahs::hw;
+using namespace SAHS_NS;
+using namespace SAHS_NS::hw;
 
 template <int MODE>
 static int launch_w(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride, const float *zvals,
@@ -744,24 +756,31 @@ static int launch_w(const float *packed, const float *frame, int level, long P, 
     return (int)hipGetLastError();
 }
 
+#if SAHS_MODEL == 0
 extern "C" int sahs_field_forward_bf16w_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays,
                                                int ray_stride, const float *zvals, float *raw, float *dbg, int num_cu,
                                                hipStream_t stream)
 {
     return launch_w<FIELD_ALL>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, nullptr, 0, 0, nullptr, num_cu, stream);
 }
+#endif
 
-// the split evaluation (field_f32.hip: sahs_field_forward_f32_split_launch, same arguments)
-extern "C" int sahs_field_forward_bf16w_split_launch(const float *packed, const float *frame, int level, int mode, long P, int S,
-                                                     const float *rays, int ray_stride, const float *zvals, float *raw, float *xw, int xw_row,
-                                                     int xw_col0, const int *src, int num_cu, hipStream_t stream)
+// the split evaluation (field_f32.hip: sahs_field_forward_f32_split_launch, same arguments).  Built for NeRFaceModel too, radiance nets
+// only (mode 2; src may be null = sample s of a ray is column s of xw): that model's deformation nets stay fp32.
+extern "C" int SAHS_SYM(sahs_field_forward_bf16w_split_launch)(const float *packed, const float *frame, int level, int mode, long P, int S,
+                                                               const float *rays, int ray_stride, const float *zvals, float *raw, float *xw,
+                                                               int xw_row, int xw_col0, const int *src, int num_cu, hipStream_t stream)
 {
     switch (mode) {
+#if SAHS_MODEL == 0
     case FIELD_ALL:
         return launch_w<FIELD_ALL>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, nullptr, xw, xw_row, xw_col0, nullptr, num_cu, stream);
     case FIELD_DEFORM:
         return launch_w<FIELD_DEFORM>(packed, frame, level, P, S, rays, ray_stride, zvals, nullptr, nullptr, xw, xw_row, xw_col0, nullptr, num_cu, stream);
-    default:
+#endif
+    case FIELD_RADIANCE:
         return launch_w<FIELD_RADIANCE>(packed, frame, level, P, S, rays, ray_stride, nullptr, raw, nullptr, xw, xw_row, 0, src, num_cu, stream);
+    default:
+        return -2;
     }
 }

@@ -254,6 +254,7 @@ extern "C" int SAHS_SYM(sahs_fold_conditioning_launch)(const float *flat, const 
 // sizes of this model's buffers, for the C ABI (capi.hip is built once and cannot see both models' constants)
 extern "C" long SAHS_SYM(sahs_layout_param_count)(void) { return kFlat.total; }
 extern "C" long SAHS_SYM(sahs_layout_packed_words_f32)(void) { return PACK_FLOATS; }
+extern "C" long SAHS_SYM(sahs_layout_packed_words_bf16)(void) { return hb::PACKH_WORDS; }
 extern "C" long SAHS_SYM(sahs_layout_frame_words)(void) { return FRAME_FLOATS; }
 extern "C" long SAHS_SYM(sahs_layout_act_words)(void) { return act::STRIDE; }
 // multiply-accumulates per sample evaluation that the field kernel ISSUES (padded tiles and k-blocks of the layer program; the

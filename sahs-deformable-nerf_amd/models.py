@@ -161,6 +161,9 @@ class _FieldModel(nn.Module):
                 raise NotImplementedError("gradients run through the fp32 path; build the model with precision='fp32'")
             raw = ops.FieldFn.apply(self.flat_params(differentiable=True), driving.to(torch.float32), pose.to(torch.float32), rays, z, packed,
                                     lvl, self.arch)
+        elif self.arch == "nerface" and self.precision == ops.SAHS_BF16:     # mixed precision: fp32 deformation launch, bf16 radiance launch
+            xw = torch.empty(P, 1, 8, dtype=torch.float32, device=x.device)
+            raw = ops.field_forward_split(packed, self.frame(driving, pose), lvl, ops.FIELD_ALL, rays, xw, z=z, arch=self.arch, precision=self.precision)
         else:
             raw = ops.field_forward(packed, self.frame(driving, pose), lvl, rays, z, precision=self.precision, arch=self.arch)
         return raw.view(P, 16)
@@ -178,14 +181,16 @@ class AudioFaceModel(_FieldModel):
 class NeRFaceModel(_FieldModel):
     """models.py:189-378: expression-driven (driving = the 76-d expression vector).  Two architectures, chosen by the config as
     the reference does (models.py:231,244): warp + hyper sheet on (config/expression/person_2.yml, person_3.yml) or both off
-    (person_1.yml).  fp32 rendering and training; the bf16 kernel stays with the AudioFaceModel."""
+    (person_1.yml).  fp32 rendering and training; precision="bf16" (the deforming architecture only) is MIXED precision: the
+    deformation nets stay fp32 -- a bf16-level error in the warp output is 16 rad at the 15th octave -- and the radiance nets run on
+    the bf16 matrix pipe; rendering through run_one_iter_of_nerf only (it needs the per-chunk workspace)."""
 
     def __init__(self, cfg, precision="fp32"):
         super().__init__()
-        if precision != "fp32":
-            raise NotImplementedError("NeRFaceModel: only the fp32 kernel is built in this round")
         deform = (bool(cfg.models.warp.use_warp), bool(cfg.models.hyper.use_ambient))
         if deform[0] != deform[1]:
             raise NotImplementedError("NeRFaceModel: warp and hyper sheet are built both on or both off (as in the shipped configs)")
+        if precision not in ("fp32", "f32") and not (precision == "bf16" and deform[0]):
+            raise NotImplementedError("NeRFaceModel: fp32, or bf16 (mixed precision) for the configurations with deformation nets")
         self.arch = "nerface" if deform[0] else "nerface_static"
         self._build(cfg, precision)

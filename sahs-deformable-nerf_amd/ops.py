@@ -210,6 +210,11 @@ def sample_pdf(bins, weights, num_samples, u=None, want_inds=False):
 def render_rays(packed, frame, rays, num_coarse, num_fine, precision=SAHS_F32, lindisp=False, white_background=False, bg=None,
                 t_rand=None, noise_c=None, u=None, noise_f=None, workspace=None, arch="audio"):
     """predict_and_render_radiance for one ray chunk -> the reference's 8-tuple (flat shapes)."""
+    if precision == SAHS_BF16 and arch == "nerface":      # mixed precision exists as the row-writing split chain only
+        rows = torch.empty(rays.shape[0], ROW_COLUMNS, dtype=torch.float32, device=rays.device)
+        render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=precision, lindisp=lindisp, white_background=white_background,
+                         bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f, workspace=workspace, arch=arch)
+        return tuple(c.contiguous() for c in (rows[:, 0:15], rows[:, 15], rows[:, 16], rows[:, 17:32], rows[:, 32], rows[:, 33], rows[:, 34], rows[:, 35]))
     packed, frame, rays = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays")
     bg, t_rand, noise_c, u, noise_f = (_req(t, n) for t, n in ((bg, "background_prior"), (t_rand, "t_rand"), (noise_c, "noise_c"),
                                                                (u, "u"), (noise_f, "noise_f")))
@@ -283,7 +288,10 @@ def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=
     z_c, z_f = buf("z_c", N, num_coarse), buf("z_f", N, Sf)
     raw, weights = buf("raw", N, Sf, 16), buf("weights", N, Sf)
     xw = src = z_new = None
-    if share_deformation and num_fine > 0 and ((precision == SAHS_F32 and arch != "nerface_static") or (precision == SAHS_BF16 and arch == "audio")):
+    mixed = precision == SAHS_BF16 and arch == "nerface"      # fp32 deformation nets + bf16 radiance nets: only the split chain exists
+    if mixed and not (share_deformation and num_fine > 0):
+        raise _lib.SahsError("the mixed-precision NeRFaceModel renders through the split chain (share_deformation=True, num_fine > 0)")
+    if share_deformation and num_fine > 0 and arch != "nerface_static" and precision in (SAHS_F32, SAHS_BF16):
         # extra workspace of the split evaluation: deformed points of every depth, the merge permutation, the new depths
         xw, z_new = buf("xw", N, Sf, 8), buf("z_new", N, num_fine)
         src = ws.get("src")

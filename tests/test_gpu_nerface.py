@@ -43,8 +43,12 @@ def test_sizes_and_errors(ops):
     assert ops.param_count("nerface") == 2_311_140 and ops.param_count() == 2_775_633 and ops.param_count("nerface_static") == 2_066_976
     with pytest.raises(Exception):
         ops.pack_weights(torch.zeros(2_775_633, device=dev()), arch="nerface")        # the audio model's buffer
-    with pytest.raises(Exception):
-        ops.pack_weights(torch.zeros(2_311_140, device=dev()), precision=ops.SAHS_BF16, arch="nerface")
+    with pytest.raises(Exception):      # bf16 exists for the deforming architecture only (mixed precision), not for person_1.yml's
+        ops.pack_weights(torch.zeros(2_066_976, device=dev()), precision=ops.SAHS_BF16, arch="nerface_static")
+    with pytest.raises(Exception):      # and its whole-network entry point needs the split chain's workspace
+        ops.field_forward(ops.pack_weights(torch.zeros(2_311_140, device=dev()), precision=ops.SAHS_BF16, arch="nerface"),
+                          torch.zeros(16384, device=dev()), 0,
+                          torch.zeros(4, 8, device=dev()), torch.zeros(4, 2, device=dev()), precision=ops.SAHS_BF16, arch="nerface")
 
 
 @pytest.mark.parametrize("variant", ["default", "boosted"])
@@ -159,8 +163,9 @@ def test_model_seam_and_config_guard(nf):
     close(raw[:, :15], g["boosted_raw_coarse"][:, :15], 2e-3, 2e-3, "model(...) seam")
     with pytest.raises(NotImplementedError):
         sahs.NeRFaceModel(sahs.default_config("audio"))
-    with pytest.raises(NotImplementedError):
-        sahs.NeRFaceModel(cfg, precision="bf16")
+    with pytest.raises(NotImplementedError):      # mixed precision needs deformation nets to keep in fp32: not for person_1.yml
+        sahs.NeRFaceModel(sahs.default_config("expression_static"), precision="bf16")
+    assert sahs.NeRFaceModel(cfg, precision="bf16").precision == pkg("ops").SAHS_BF16
 
 
 # ---- config/expression/person_1.yml: NeRFaceModel without deformation nets (use_warp False, use_ambient False) ----
@@ -411,3 +416,58 @@ def test_field_backward_seam_vs_autograd(ops, nf, arch, level):
         e, e32 = float((grad_cond[:76].double() - dd64).abs().max()) / sc, float((dd32.double() - dd64).abs().max()) / sc
         assert e <= max(2e-3, 0.5 * e32), (e, e32)
 
+
+
+def test_mixed_precision_bf16_vs_fp32(ops, nf):
+    """NeRFaceModel in mixed precision (precision "bf16": fp32 deformation nets, bf16 radiance nets) against
+    its fp32 path on the same rays, weights and draws: the deformed points are the fp32 launch's own (bit-identical x', w), the
+    radiance nets' raw output differs by bf16 rounding, and the rendered frame stays within the PSNR bound of the audio model's
+    bf16 path.  Observed values are printed; the bounds are ~3x of them."""
+    import json
+    W = pkg("weights")
+    d = dev()
+    # high-dynamic-range weights with the density logit placed so that a ray spreads its weight (mean background weight ~0.25)
+    fw = W.flatten_state_dict(W.hash_state_dict(0, -3.0, 10.0, model="nerface", hdr=True), model="nerface")
+    flat = T(fw)
+    packs = {p: ops.pack_weights(flat, ops.PRECISIONS[p], arch="nerface") for p in ("fp32", "bf16")}
+    g = torch.Generator(device=d).manual_seed(7)
+    frame = ops.fold_conditioning(flat, torch.randn(76, device=d, generator=g) * 0.5,
+                                  T(np.concatenate([np.eye(3), [[0.0], [0.0], [0.5]]], 1).astype(np.float32)), arch="nerface")
+    N, nc, nfine = 1500, 64, 64
+    rays = torch.zeros(N, 8, device=d)
+    rays[:, 2] = 0.5
+    rays[:, 3:6] = torch.randn(N, 3, device=d, generator=g) * 0.15 + torch.tensor([0, 0, -1.0], device=d)
+    rays[:, 6], rays[:, 7] = 0.2, 0.8
+    bg = torch.cat([torch.rand(N, 3, device=d, generator=g), torch.ones(N, 1, device=d), torch.zeros(N, 11, device=d)], 1)
+    t_rand, u = torch.rand(N, nc, device=d, generator=g), torch.rand(N, nfine, device=d, generator=g)
+    out = {}
+    for p in ("fp32", "bf16"):
+        rows = torch.full((N, 36), float("nan"), device=d)
+        ws = {}
+        ops.render_rays_rows(packs[p], frame, rays, nc, nfine, rows, precision=ops.PRECISIONS[p], bg=bg, t_rand=t_rand, u=u, workspace=ws, arch="nerface")
+        out[p] = (rows, ws["xw"].clone(), ws["raw"].clone(), ws["z_f"].clone())
+        assert bool(torch.isfinite(rows).all()), p
+    # coarse pass: same depths, so the fp32 deformation launch gives bit-identical (x', w) for the coarse columns
+    assert torch.equal(out["fp32"][1][:, :nc, :5], out["bf16"][1][:, :nc, :5])
+    a, b = out["fp32"][0], out["bf16"][0]
+    mse = lambda x, y: float(((x - y) ** 2).mean())
+    psnr = lambda m: -10.0 * np.log10(max(m, 1e-30))
+    res = dict(psnr_rgb_coarse=psnr(mse(a[:, 0:3], b[:, 0:3])), psnr_rgb_fine=psnr(mse(a[:, 17:20], b[:, 17:20])),
+               max_abs_rgb_fine=float((a[:, 17:20] - b[:, 17:20]).abs().max()), seg_max_abs=float((a[:, 20:32] - b[:, 20:32]).abs().max()),
+               acc_max_abs=float((a[:, 33] - b[:, 33]).abs().max()), depth_rms=float(((a[:, 35] - b[:, 35]) ** 2).mean().sqrt()),
+               w_bg_mean=float(a[:, 34].mean()))
+    print(json.dumps(res))
+    assert res["psnr_rgb_coarse"] >= 38.0 and res["psnr_rgb_fine"] >= 33.0, res
+    assert res["acc_max_abs"] <= 1e-3 and 0.02 < res["w_bg_mean"] < 0.98, res
+    # the B2 seam of a mixed-precision model: model(level, x) = fp32 deformation launch + bf16 radiance launch
+    sahs = pkg()
+    cfg = sahs.default_config("expression")
+    m32 = sahs.NeRFaceModel(cfg).to(d).load_flat(fw).eval()
+    m16 = sahs.NeRFaceModel(cfg, precision="bf16").to(d).load_flat(fw).eval()
+    x = torch.cat([torch.rand(300, 3, device=d, generator=g) * 0.4 - 0.2, torch.randn(300, 3, device=d, generator=g)], 1)
+    drv, pose = torch.randn(76, device=d, generator=g) * 0.5, T(np.concatenate([np.eye(3), [[0.0], [0.0], [0.5]]], 1).astype(np.float32))
+    with torch.no_grad():
+        r32, r16 = m32("fine", x, drv, pose), m16("fine", x, drv, pose)
+    rel = float((r32 - r16).abs().max() / r32.abs().max())
+    print(json.dumps(dict(seam_raw_rel_max=rel)))
+    assert rel <= 0.1, rel
