@@ -128,7 +128,8 @@ class HipRenderer:
             cam_z = 0.8
         else:   # expression-driven NeRFaceModel: driving = 76-d expression, near/far 0.2/0.8 (config/expression/person_2.yml:43-45)
             self.cfg = pkg.default_config("expression")
-            self.fw = W.flatten_state_dict(W.hash_state_dict(0, 8.0, 30.0, model="nerface"), model="nerface")
+            # high-dynamic-range weights; the density logit placed so that rays spread their weight over many samples (mean w_bg ~0.2)
+            self.fw = W.flatten_state_dict(W.hash_state_dict(0, -3.0, 10.0, model="nerface", hdr=True), model="nerface")
             self.model = pkg.NeRFaceModel(self.cfg, precision=precision).to(dev).load_flat(self.fw)
             self.audio = torch.from_numpy((rng.standard_normal(76) * 0.5).astype(np.float32)).to(dev)
             cam_z = 0.5
@@ -146,7 +147,8 @@ class HipRenderer:
         self.packed, _ = self.model.packed()
         self.flop_per_sample = FLOP_PER_SAMPLE[arch]
         # the deformation nets are evaluated once per depth (sahs_model_field_forward_split), as the drop-in driver does
-        self.split = share_deformation and (precision == "fp32" or (precision == "bf16" and arch == "audio")) and arch != "nerface_static"
+        self.split = share_deformation and precision in ("fp32", "bf16") and arch != "nerface_static"
+        self.mixed = precision == "bf16" and arch == "nerface"       # fp32 deformation launches + bf16 radiance launches
         ex = lambda part: 2 * self.ops.executed_macs_per_sample(arch, self.prec, part)
         self.exec_flop_per_sample = ex(0)
         # executed FLOPs per RAY: coarse = nc whole-network evaluations; fine = nf deformation + (nc + nf) radiance evaluations when split
@@ -239,7 +241,9 @@ class HipRenderer:
                          "shared_deformation the fine pass skips the reference's redundant second evaluation of the deformation nets at the coarse "
                          "depths, so frac can exceed frac_executed (the instructions actually issued) by more than the constant folding alone") if self.split else None,
                 "frac_executed": (samples / (2 * self.nc + self.nf)) * self.exec_flop_per_ray / (field_ms * 1e-3) / 1e12 / peak,
-                "field_time_share": field_ms * 1e-3 / dt}
+                "field_time_share": field_ms * 1e-3 / dt,
+                **({"mixed_precision": "fp32 deformation launches + bf16 radiance launches: 'achieved' / 'frac' price the whole chain against the bf16 "
+                                       "peak and are NOT a kernel roofline here; dominant_kernel is the bf16 radiance launch alone"} if self.mixed else {})}
 
 
 _T0 = time.perf_counter()
@@ -308,6 +312,20 @@ def add_secondary_legs(result, pkg, dev, args):
     rec, _, _ = measure(pkg, dev, size, "fp32", min(args.steps, 5), 1, arch="nerface")
     result["nerface_fp32"] = {"value": rec["value"], "unit": "rays/s", "ms_per_step": rec["ms_per_step"], "dtype": "f32",
                               "workload": rec["config"]["workload"], "roofline": rec["roofline"]}
+    # the same model in mixed precision (fp32 deformation nets, bf16 radiance nets) and the section-8d PSNR protocol on it
+    progress("nerface mixed-precision leg")
+    recm, outm, rm = measure(pkg, dev, size, "bf16", min(args.steps, 5), 1, arch="nerface")
+    rn = HipRenderer(pkg, dev, size, "fp32", arch="nerface")
+    with torch.no_grad():
+        f32n = rn.render(0, rn.R)
+        rn.seed += 1000
+        tgtn = rn.render(0, rn.R)
+    p_b, p_f = psnr(rgb_fine(outm), rgb_fine(tgtn)), psnr(rgb_fine(f32n), rgb_fine(tgtn))
+    result["nerface_mixed_bf16"] = {"value": recm["value"], "unit": "rays/s", "ms_per_step": recm["ms_per_step"], "dtype": "f32 deformation nets + bf16 radiance nets",
+                                    "speedup_vs_nerface_fp32": recm["value"] / rec["value"], "roofline": recm["roofline"],
+                                    "psnr_mixed_vs_fp32_db": psnr(rgb_fine(outm), rgb_fine(f32n)), "psnr_mixed_vs_target_db": p_b,
+                                    "psnr_fp32_vs_target_db": p_f, "delta_psnr_db": abs(p_b - p_f), "w_bg_mean": float(f32n[:, 34].mean())}
+    del rm, rn, outm, f32n, tgtn
     # the num_fine 128 reading (fine pass of 192 samples, 256 evaluations per ray)
     progress("num_fine128 leg")
     rec, _, _ = measure(pkg, dev, size, "fp32", 2, 1, num_fine=128)
