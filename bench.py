@@ -55,7 +55,7 @@ def _static_traffic():
     try:
         d = json.load(open(os.path.join(REPO, "profiles", "r2_pmc_summary.json")))
         return {"fp32": (d["f32_radiance"]["traffic_bytes"], "profiles/r2_pmc_summary.json:f32_radiance"),
-                "bf16": (d["bf16"]["traffic_bytes"], "profiles/r2_pmc_summary.json:bf16")}
+                "bf16": (d["bf16_radiance"]["traffic_bytes"], "profiles/r2_pmc_summary.json:bf16_radiance")}
     except (OSError, KeyError, ValueError):
         return {}
 

@@ -33,8 +33,10 @@ def kernel_stats(sub, dst, header):
 
 def kind(kn):
     """Which field launch a kernel name is: fp32 whole network / deformation nets / radiance net, or the bf16 kernel."""
-    if "field_forward_bf16w" in kn:
-        return "bf16"
+    if "field_forward_bf16w" in kn and "sahs_nf" not in kn:
+        for m, lab in (("0", "bf16_all"), ("1", "bf16_deform"), ("2", "bf16_radiance")):
+            if "kernel<%s>" % m in kn or "kernelILi%sE" % m in kn:
+                return lab
     if "field_forward_f32_kernel" in kn and "sahs_n" not in kn:
         for m, lab in (("0", "f32_all"), ("1", "f32_deform"), ("2", "f32_radiance")):
             if "<false, %s>" % m in kn or "ILb0ELi%sE" % m in kn:
@@ -67,7 +69,7 @@ for rows in (rows32, rows16):
             dur[k] = (float(r["MinNs"]), float(r["MaxNs"]), float(r["AverageNs"]), int(r["Calls"]))
 lines = ["# rocprofv3 PMC summary (separate passes per counter group, tools/profile_r2.sh), bench.py --steps 1 --warmup 0: the first frame's dispatches,",
          "# two 131,072-ray chunks; fp32: per chunk coarse (f32_all, 8.39 M samples), deformation nets (f32_deform, 8.39 M), radiance net (f32_radiance, 16.78 M);",
-         "# bf16: per chunk coarse (8.39 M), fine (16.78 M)",
+         "# bf16: the same three launches per chunk by field_forward_bf16w_kernel<0|1|2>",
          "kernel,counter,dispatch_0,dispatch_1,dispatch_2,dispatch_3"]
 for (k, c), v in agg.items():
     lines.append("%s,%s,%s" % (k, c, ",".join("%.6g" % x for x in v[:4])))
@@ -77,11 +79,13 @@ for k, label, pick, samples, alg_bytes in (
         ("f32_radiance", "fp32 radiance-net launch (the dominant dispatch: 16.78 M fine samples)", 0, P_FINE, P_FINE * (64 + 32 + 4)),
         ("f32_all", "fp32 whole-network launch (coarse pass: 8.39 M samples)", 0, P_FINE // 2, (P_FINE // 2) * (64 + 4 + 32)),
         ("f32_deform", "fp32 deformation-net launch (8.39 M new depths)", 0, P_FINE // 2, (P_FINE // 2) * (4 + 32)),
-        ("bf16", "bf16 field kernel, fine launch (16.78 M samples)", 1, P_FINE, P_FINE * (64 + 4))):
+        ("bf16_radiance", "bf16 radiance-net launch (16.78 M fine samples)", 0, P_FINE, P_FINE * (64 + 32 + 4)),
+        ("bf16_all", "bf16 whole-network launch (coarse pass: 8.39 M samples)", 0, P_FINE // 2, (P_FINE // 2) * (64 + 4 + 32)),
+        ("bf16_deform", "bf16 deformation-net launch (8.39 M new depths)", 0, P_FINE // 2, (P_FINE // 2) * (4 + 32))):
     if k not in dur or (k, "GRBM_GUI_ACTIVE") not in agg:
         continue
     g = lambda c: agg[(k, c)][pick] if (k, c) in agg and len(agg[(k, c)]) > pick else float("nan")
-    t = (dur[k][1] if k == "bf16" else dur[k][2]) * 1e-9     # bf16: coarse and fine share a kernel name, the longest dispatch is a fine one
+    t = dur[k][2] * 1e-9
     wr, fe = g("WRITE_SIZE") * 1024, g("FETCH_SIZE") * 1024
     clk = g("GRBM_GUI_ACTIVE") / 8 / t
     lines += ["", "# %s: %.2f ms under rocprof (%d dispatches in the traced run)" % (label, t * 1e3, dur[k][3]),
@@ -93,7 +97,7 @@ for k, label, pick, samples, alg_bytes in (
         lines.append("#   L2 hit rate %.1f %%" % (100 * g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))))
     lines.append("#   clock = GRBM_GUI_ACTIVE / 8 / time = %.2f GHz;  MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles) = %.1f %%"
                  % (clk / 1e9, 100 * g("SQ_VALU_MFMA_BUSY_CYCLES") / (1024 * g("GRBM_GUI_ACTIVE") / 8)))
-    mops = g("SQ_INSTS_VALU_MFMA_MOPS_BF16") if k == "bf16" else g("SQ_INSTS_VALU_MFMA_MOPS_F32")
+    mops = g("SQ_INSTS_VALU_MFMA_MOPS_BF16") if k.startswith("bf16") else g("SQ_INSTS_VALU_MFMA_MOPS_F32")
     lines.append("#   executed MFMA FLOPs = MOPS x 512 = %.3e" % (mops * 512))
     lines.append("#   wave time: WAIT_ANY %.1f %%, WAIT_INST_ANY %.1f %%, ACTIVE_INST_ANY %.1f %% of SQ_WAVE_CYCLES; LDS bank conflict cycles / LDS instructions = %.3f"
                  % (100 * g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), 100 * g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), 100 * g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"),
