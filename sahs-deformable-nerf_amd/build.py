@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "libsahs_nerf.so")
 SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "field_f32.hip", "field_bf16.hip", "field_bf16w.hip", "field_bwd.hip", "train_bwd.hip"]
 # sources built again for the NeRFaceModel architectures (csrc/sahs_model.hpp: -DSAHS_MODEL=1 / 2, symbols suffixed _nf / _ns)
 MODEL_SOURCES = ["pack.hip", "field_f32.hip", "field_bwd.hip"]
-MODEL1_SOURCES = ["field_bf16w.hip"]      # NeRFaceModel with deformation: the bf16 radiance nets (its deformation nets stay fp32)
+MODEL1_SOURCES = ["field_bf16w.hip"]      # NeRFaceModel: the bf16 radiance nets (with deformation nets: those stay fp32; without: the whole net)
 # field kernels: no sNaN-quieting v_max before every fmaxf (activations); NaNs still propagate through the MFMAs
 FIELD_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
 # Kernels whose correctness or speed rests on an exact count of the wave's vector-memory instructions (a counted s_waitcnt vmcnt
@@ -67,7 +67,7 @@ def build(force=False, verbose=False, defines=(), out=None):
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     procs = []
-    for src, model in [(s, 0) for s in SOURCES] + [(s, m) for m in (1, 2) for s in MODEL_SOURCES] + [(s, 1) for s in MODEL1_SOURCES]:
+    for src, model in [(s, 0) for s in SOURCES] + [(s, m) for m in (1, 2) for s in MODEL_SOURCES] + [(s, m) for m in (1, 2) for s in MODEL1_SOURCES]:
         obj = os.path.join(HERE, "build", (os.path.basename(out) + "." if out else "") + src.replace(".hip", ".m%d.o" % model if model else ".o"))
         objs.append(obj)
         extra = (FIELD_FLAGS if src.startswith("field_") else []) + (["-DSAHS_MODEL=%d" % model] if model else []) + ([] if "SAHS_NOTHING" in defines else PER_FILE_FLAGS.get(src, []))

@@ -79,6 +79,11 @@ int sahs_pack_weights_bf16_launch_nf(const float *flat, float *packed, hipStream
 int sahs_field_forward_bf16w_split_launch_nf(const float *packed, const float *frame, int level, int mode, long P, int S, const float *rays,
                                              int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
                                              int num_cu, hipStream_t stream);
+// NeRFaceModel without deformation nets (person_1.yml): the whole network in bf16
+long sahs_layout_packed_words_bf16_ns(void);
+int sahs_pack_weights_bf16_launch_ns(const float *flat, float *packed, hipStream_t stream);
+int sahs_field_forward_bf16w_launch_ns(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
+                                       const float *zvals, float *raw, float *dbg, int num_cu, hipStream_t stream);
 }
 
 static thread_local char g_err[512] = "";
@@ -365,11 +370,13 @@ long sahs_model_packed_words(int model, int precision)
     if (model == SAHS_MODEL_AUDIO) return sahs_packed_words(precision);
     if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)     // mixed precision: [bf16 radiance pack | fp32 pack (deformation nets)]
         return sahs_layout_packed_words_bf16_nf() + kModels[model].packed_words_f32();
+    if (model == SAHS_MODEL_NERFACE_STATIC && precision == SAHS_BF16) return sahs_layout_packed_words_bf16_ns();
     return precision == SAHS_F32 ? kModels[model].packed_words_f32() : -1;
 }
 long sahs_model_executed_macs_part(int model, int precision, int part)
 {
     if (model < 0 || model > 2 || precision < SAHS_F32 || precision > SAHS_BF16_2W || part < 0 || part > 2) return -1;
+    if (model == SAHS_MODEL_NERFACE_STATIC && part != 0) return part == 2 ? sahs_layout_executed_macs_ns(precision == SAHS_F32 ? SAHS_F32 : SAHS_BF16, 0) : 0;
     if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)      // mixed: fp32 deformation nets + bf16 radiance nets
         return (part != 2 ? sahs_layout_executed_macs_nf(SAHS_F32, 1) : 0) + (part != 1 ? sahs_layout_executed_macs_nf(SAHS_BF16, 2) : 0);
     return model == 0 ? sahs_layout_executed_macs(precision, part)
@@ -386,6 +393,10 @@ int sahs_model_pack_weights(int model, const float *flat_params, void *packed, i
     if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16) {
         int e = sahs_pack_weights_bf16_launch_nf(flat_params, (float *)packed, (hipStream_t)stream);
         if (!e) e = kModels[model].pack_f32(flat_params, (float *)packed + sahs_layout_packed_words_bf16_nf(), (hipStream_t)stream);
+        return e ? hip_fail("sahs_model_pack_weights", e) : 0;
+    }
+    if (model == SAHS_MODEL_NERFACE_STATIC && precision == SAHS_BF16) {
+        int e = sahs_pack_weights_bf16_launch_ns(flat_params, (float *)packed, (hipStream_t)stream);
         return e ? hip_fail("sahs_model_pack_weights", e) : 0;
     }
     if (precision != SAHS_F32) return fail(2, "sahs_model_pack_weights: only SAHS_F32 is built for this model %s%ld", "", precision);
@@ -413,6 +424,10 @@ static int field_forward_model(int model, const void *packed, const float *frame
     if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)
         return fail(2, "sahs_model_field_forward: the mixed-precision NeRFaceModel runs through sahs_model_field_forward_split / "
                        "sahs_model_render_rays_rows (it needs the xw workspace)%s%ld", "", 0L);
+    if (model == SAHS_MODEL_NERFACE_STATIC && precision == SAHS_BF16) {
+        int e = sahs_field_forward_bf16w_launch_ns((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(), (hipStream_t)stream);
+        return e ? hip_fail("sahs_model_field_forward", e) : 0;
+    }
     if (precision != SAHS_F32) return fail(2, "sahs_model_field_forward: only SAHS_F32 is built for this model %s%ld", "", precision);
     int e = kModels[model].field_f32((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, nullptr, num_cus(),
                                      (hipStream_t)stream);

@@ -491,9 +491,14 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                            const int *__restrict__ src)
 {
     constexpr uint32_t RAD_OFF = (uint32_t)kProgH.layer[H_T0].stream_off;      // first radiance-net chunk
+#if SAHS_MODEL == 2      // no deformation nets (config/expression/person_1.yml): the whole network is the radiance net, queried at the raw point
+    static_assert(MODE == FIELD_ALL, "this model has no deformation nets to split off");
+    constexpr int L_FIRST = H_T0, AFTER_RADIANCE = H_T0;
+#else
     constexpr int L_FIRST = MODE == FIELD_RADIANCE ? H_T0 : H_W0;               // the launch's first layer
     constexpr int AFTER_DEFORM = MODE == FIELD_DEFORM ? H_W0 : H_T0;            // the chunk prefetched under the last deformation layer
     constexpr int AFTER_RADIANCE = MODE == FIELD_RADIANCE ? H_T0 : H_W0;        // ... under the last radiance layer
+#endif
     extern __shared__ __attribute__((aligned(16))) char lds_w[];
     Ctx cx;
     cx.stream = reinterpret_cast<const unsigned short *>(packed + PACKH_STREAM_OFF) + (long)level * STREAM_HW;
@@ -566,6 +571,14 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                 });
             }
         } else {
+#if SAHS_MODEL == 2
+        if (h == 0) {
+            for_halves([&](auto Q) {      // models.py:316-327 with use_warp False, use_ambient False: x' = x, no ambient coordinate
+                constexpr int q = decltype(Q)::value;
+                stash(q)[0] = x[q][0]; stash(q)[1] = x[q][1]; stash(q)[2] = x[q][2]; stash(q)[3] = 0.0f; stash(q)[4] = 0.0f;
+            });
+        }
+#else
         Blk pe_x[2];
         pe_blocks_w<3, 10, 2>(x, h, pe_x);
         cx.stamp();                                   // 1 sample points + PE(x)
@@ -617,6 +630,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                 }
             });
         }
+#endif
         }
         __builtin_amdgcn_wave_barrier();
         cx.stamp();                                   // 3 hyper net (RADIANCE: x', w fetched)
@@ -645,7 +659,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                     amb[q][0] = stash(q)[3]; amb[q][1] = stash(q)[4]; amb[q][2] = 0.0f;
                 });
                 pe_blocks_w<3, L_XYZ, KX32>(xw, h, in_tr);
-                pe_blocks_w<AMB_DIM, L_AMB, KA32, AMB_INC>(amb, h, in_tr + KX32);
+                if constexpr (KA32 > 0) pe_blocks_w<(AMB_DIM > 0 ? AMB_DIM : 1), L_AMB, KA32, AMB_INC>(amb, h, in_tr + KX32);
                 cx.stamp();                           // 4 PE(x'), PE(w)
                 dense_w<KX32, KA32, 0, 8, CH(H_T1), false>(cx, st, in_tr, in_tr + KX32, nullptr, A, Ly[H_T0].bias_off, 0.01f, 0.0f);
                 cx.stamp();                           // 5 T0
@@ -663,7 +677,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                     amb[q][0] = stash(q)[3]; amb[q][1] = stash(q)[4]; amb[q][2] = 0.0f;
                 });
                 pe_blocks_w<3, L_XYZ, KX32>(xw, h, in_tr);
-                pe_blocks_w<AMB_DIM, L_AMB, KA32, AMB_INC>(amb, h, in_tr + KX32);
+                if constexpr (KA32 > 0) pe_blocks_w<(AMB_DIM > 0 ? AMB_DIM : 1), L_AMB, KA32, AMB_INC>(amb, h, in_tr + KX32);
                 cx.stamp();                           // 8 PE again
 #if SAHS_MODEL == 0
                 dense_w<8, KX32, KA32, 8, CH(H_T4), true>(cx, st, A, in_tr, in_tr + KX32, B, Ly[H_T3].bias_off, 0.01f, 0.01f);
@@ -756,15 +770,16 @@ static int launch_w(const float *packed, const float *frame, int level, long P, 
     return (int)hipGetLastError();
 }
 
-#if SAHS_MODEL == 0
-extern "C" int sahs_field_forward_bf16w_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays,
-                                               int ray_stride, const float *zvals, float *raw, float *dbg, int num_cu,
-                                               hipStream_t stream)
+#if SAHS_MODEL != 1      // whole-network launches: AudioFaceModel, and NeRFaceModel without deformation nets (all of it is the radiance net)
+extern "C" int SAHS_SYM(sahs_field_forward_bf16w_launch)(const float *packed, const float *frame, int level, long P, int S, const float *rays,
+                                                         int ray_stride, const float *zvals, float *raw, float *dbg, int num_cu,
+                                                         hipStream_t stream)
 {
     return launch_w<FIELD_ALL>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, nullptr, 0, 0, nullptr, num_cu, stream);
 }
 #endif
 
+#if SAHS_MODEL != 2
 // the split evaluation (field_f32.hip: sahs_field_forward_f32_split_launch, same arguments).  Built for NeRFaceModel too, radiance nets
 // only (mode 2; src may be null = sample s of a ray is column s of xw): that model's deformation nets stay fp32.
 extern "C" int SAHS_SYM(sahs_field_forward_bf16w_split_launch)(const float *packed, const float *frame, int level, int mode, long P, int S,
@@ -784,3 +799,4 @@ extern "C" int SAHS_SYM(sahs_field_forward_bf16w_split_launch)(const float *pack
         return -2;
     }
 }
+#endif

@@ -190,7 +190,7 @@ class NeRFaceModel(_FieldModel):
         deform = (bool(cfg.models.warp.use_warp), bool(cfg.models.hyper.use_ambient))
         if deform[0] != deform[1]:
             raise NotImplementedError("NeRFaceModel: warp and hyper sheet are built both on or both off (as in the shipped configs)")
-        if precision not in ("fp32", "f32") and not (precision == "bf16" and deform[0]):
-            raise NotImplementedError("NeRFaceModel: fp32, or bf16 (mixed precision) for the configurations with deformation nets")
+        if precision not in ("fp32", "f32", "bf16"):
+            raise NotImplementedError("NeRFaceModel: fp32, or bf16 (with deformation nets: mixed precision, those stay fp32)")
         self.arch = "nerface" if deform[0] else "nerface_static"
         self._build(cfg, precision)

@@ -43,9 +43,9 @@ def test_sizes_and_errors(ops):
     assert ops.param_count("nerface") == 2_311_140 and ops.param_count() == 2_775_633 and ops.param_count("nerface_static") == 2_066_976
     with pytest.raises(Exception):
         ops.pack_weights(torch.zeros(2_775_633, device=dev()), arch="nerface")        # the audio model's buffer
-    with pytest.raises(Exception):      # bf16 exists for the deforming architecture only (mixed precision), not for person_1.yml's
-        ops.pack_weights(torch.zeros(2_066_976, device=dev()), precision=ops.SAHS_BF16, arch="nerface_static")
-    with pytest.raises(Exception):      # and its whole-network entry point needs the split chain's workspace
+    with pytest.raises(Exception):      # no round-1 bf16 kernel for these models
+        ops.pack_weights(torch.zeros(2_066_976, device=dev()), precision=ops.SAHS_BF16_2W, arch="nerface_static")
+    with pytest.raises(Exception):      # the mixed-precision model's whole-network entry point needs the split chain's workspace
         ops.field_forward(ops.pack_weights(torch.zeros(2_311_140, device=dev()), precision=ops.SAHS_BF16, arch="nerface"),
                           torch.zeros(16384, device=dev()), 0,
                           torch.zeros(4, 8, device=dev()), torch.zeros(4, 2, device=dev()), precision=ops.SAHS_BF16, arch="nerface")
@@ -163,8 +163,8 @@ def test_model_seam_and_config_guard(nf):
     close(raw[:, :15], g["boosted_raw_coarse"][:, :15], 2e-3, 2e-3, "model(...) seam")
     with pytest.raises(NotImplementedError):
         sahs.NeRFaceModel(sahs.default_config("audio"))
-    with pytest.raises(NotImplementedError):      # mixed precision needs deformation nets to keep in fp32: not for person_1.yml
-        sahs.NeRFaceModel(sahs.default_config("expression_static"), precision="bf16")
+    with pytest.raises(NotImplementedError):
+        sahs.NeRFaceModel(cfg, precision="bf16_2w")
     assert sahs.NeRFaceModel(cfg, precision="bf16").precision == pkg("ops").SAHS_BF16
 
 
@@ -471,3 +471,42 @@ def test_mixed_precision_bf16_vs_fp32(ops, nf):
     rel = float((r32 - r16).abs().max() / r32.abs().max())
     print(json.dumps(dict(seam_raw_rel_max=rel)))
     assert rel <= 0.1, rel
+
+
+def test_static_bf16_vs_fp32(ops):
+    """NeRFaceModel without deformation nets (config/expression/person_1.yml) on the bf16 kernel (the whole network is the radiance
+    net, queried at the raw point) against its fp32 path: raw output within bf16 rounding, rendered frame PSNR."""
+    import json
+    W = pkg("weights")
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(9)
+    drv, pose = torch.randn(76, device=d, generator=g) * 0.5, T(np.concatenate([np.eye(3), [[0.0], [0.0], [0.5]]], 1).astype(np.float32))
+    N, nc, nfine = 700, 64, 64
+    rays = torch.zeros(N, 8, device=d)
+    rays[:, 2] = 0.5
+    rays[:, 3:6] = torch.randn(N, 3, device=d, generator=g) * 0.15 + torch.tensor([0, 0, -1.0], device=d)
+    rays[:, 6], rays[:, 7] = 0.2, 0.8
+    z = torch.sort(torch.rand(N, nc, device=d, generator=g) * 0.6 + 0.2, dim=1).values
+    # high-dynamic-range weights; the density bias is placed from a first evaluation so that the mean density logit is ~2 (its spread is
+    # ~3): rays then spread their weight over many samples instead of saturating or vanishing
+    bias = 0.0
+    for _ in range(2):
+        fw = W.flatten_state_dict(W.hash_state_dict(0, bias, 10.0, model="nerface_static", hdr=True), model="nerface_static")
+        flat = T(fw)
+        frame = ops.fold_conditioning(flat, drv, pose, arch="nerface_static")
+        probe = ops.field_forward(ops.pack_weights(flat, arch="nerface_static"), frame, 1, rays, z, arch="nerface_static")
+        bias += 2.0 - float(probe[..., 15].mean())
+    packs = {p: ops.pack_weights(flat, ops.PRECISIONS[p], arch="nerface_static") for p in ("fp32", "bf16")}
+    r32 = ops.field_forward(packs["fp32"], frame, 1, rays, z, arch="nerface_static")
+    r16 = ops.field_forward(packs["bf16"], frame, 1, rays, z, precision=ops.SAHS_BF16, arch="nerface_static")
+    assert bool(torch.isfinite(r16).all())
+    col = float((r32[..., :15] - r16[..., :15]).abs().max() / r32[..., :15].abs().max())
+    sig = float((r32[..., 15] - r16[..., 15]).abs().max() / r32[..., 15].abs().max())
+    bg = torch.cat([torch.rand(N, 3, device=d, generator=g), torch.ones(N, 1, device=d), torch.zeros(N, 11, device=d)], 1)
+    t_rand, u = torch.rand(N, nc, device=d, generator=g), torch.rand(N, nfine, device=d, generator=g)
+    o32 = ops.render_rays(packs["fp32"], frame, rays, nc, nfine, bg=bg, t_rand=t_rand, u=u, arch="nerface_static")
+    o16 = ops.render_rays(packs["bf16"], frame, rays, nc, nfine, precision=ops.SAHS_BF16, bg=bg, t_rand=t_rand, u=u, arch="nerface_static")
+    mse = float(((o32[3][:, :3] - o16[3][:, :3]) ** 2).mean())
+    res = dict(raw_colour_rel_max=col, raw_sigma_rel_max=sig, psnr_rgb_fine=-10.0 * np.log10(max(mse, 1e-30)), w_bg_mean=float(o32[6].mean()))
+    print(json.dumps(res))
+    assert col <= 0.05 and sig <= 0.05 and res["psnr_rgb_fine"] >= 33.0 and 0.02 < res["w_bg_mean"] < 0.9, res
