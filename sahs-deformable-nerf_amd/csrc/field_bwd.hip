@@ -616,6 +616,54 @@ __global__ void axpy_kernel(int n, const float *__restrict__ x, float *__restric
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[i] += x[i];
 }
 
+// ---- the walk's small launches, batched: job lists travel as kernel arguments (no table upload, nothing allocated) ----
+// (1) 16-byte aligned copies of the weight sub-matrices the data-gradient GEMMs stream by LDS-DMA: all of a walk's copies in ONE launch
+//     in front of it (the walk is run once dry to collect them); (2) the per-frame-constant columns and (3) the bias gradients that went
+//     through scratch: their results are read by nothing inside the walk, so they are deferred to one launch each at its end.
+struct CopyJob { const float *src; float *dst; long lds_, ldd; int K, N; };
+struct ConstJob { const float *W; float *dW; const float *db, *c; float *dc; long ld; int rows, cols, col0; };
+struct AxpyJob { const float *x; float *y; int n; };
+constexpr int MAX_COPY_JOBS = 48, MAX_CONST_JOBS = 24, MAX_AXPY_JOBS = 24;
+struct CopyBatch { CopyJob j[MAX_COPY_JOBS]; };
+struct ConstBatch { ConstJob j[MAX_CONST_JOBS]; };
+struct AxpyBatch { AxpyJob j[MAX_AXPY_JOBS]; };
+
+__global__ void __launch_bounds__(256) copy2d_batch_kernel(CopyBatch b)
+{
+    const CopyJob &j = b.j[blockIdx.y];
+    const long total = (long)j.K * j.N;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long m = e / j.N; const int n = (int)(e % j.N);
+        j.dst[m * j.ldd + n] = j.src[m * j.lds_ + n];
+    }
+}
+
+__global__ void __launch_bounds__(256) const_cols_batch_kernel(ConstBatch b)
+{
+    const ConstJob &j = b.j[blockIdx.y];
+    const int k = blockIdx.x;
+    if (k >= j.cols) return;
+    const float ck = j.c[k];
+    float s = 0.0f;
+    for (int r = threadIdx.x; r < j.rows; r += blockDim.x) {
+        const float g = j.db[r];
+        s += j.W[(long)r * j.ld + j.col0 + k] * g;
+        j.dW[(long)r * j.ld + j.col0 + k] += g * ck;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(j.dc + k, (red[0] + red[1]) + (red[2] + red[3]));   // several jobs share a dc (d driving, d pose)
+}
+
+__global__ void __launch_bounds__(256) axpy_batch_kernel(AxpyBatch b)
+{
+    const AxpyJob &j = b.j[blockIdx.y];
+    for (int i = threadIdx.x; i < j.n; i += blockDim.x) j.y[i] += j.x[i];
+}
+
 }  // namespace SAHS_NS
 
 using namespace SAHS_NS;
@@ -630,7 +678,21 @@ struct Bwd {
     long wal_cap = 0;
     long walo = 0;
     int err = 0;
+    bool dry = false;      // the collecting pass: nothing is launched, nn() records the aligned copies it will need
+    CopyBatch copies; int ncopy = 0;
+    ConstBatch consts; int nconst = 0, const_maxcols = 0;
+    AxpyBatch axpys; int naxpy = 0;
     void check() { if (!err) err = (int)hipGetLastError(); }
+    void flush_copies()
+    {
+        if (ncopy > 0 && ncopy <= MAX_COPY_JOBS) { copy2d_batch_kernel<<<dim3(16, ncopy), 256, 0, st>>>(copies); check(); }
+    }
+    void flush_deferred()
+    {
+        if (nconst > 0) { const_cols_batch_kernel<<<dim3(const_maxcols, nconst), 256, 0, st>>>(consts); check(); }
+        if (naxpy > 0) { axpy_batch_kernel<<<dim3(1, naxpy), 256, 0, st>>>(axpys); check(); }
+        nconst = naxpy = 0;
+    }
     static bool al(const void *p, long ld)
     {
         static const bool nodma = getenv("SAHS_BWD_NODMA") != nullptr;     // diagnostic: route every GEMM to the register-staged kernel
@@ -649,13 +711,22 @@ struct Bwd {
                 if (walo + (long)K * ldb > wal_cap) { if (!err) err = (int)hipErrorOutOfMemory; return; }   // scratch sized for one level's weights
                 float *dst = wal + walo;
                 walo += (long)K * ldb;
-                const long tot = (long)K * N;
-                copy2d_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(K, N, W, ldw, dst, ldb, 0);
-                check();
+                if (dry) {
+                    if (ncopy < MAX_COPY_JOBS) copies.j[ncopy] = CopyJob{W, dst, ldw, ldb, K, N};
+                    ++ncopy;       // (more than MAX_COPY_JOBS: the real pass copies one by one, as before)
+                    return;
+                }
+                if (ncopy > MAX_COPY_JOBS) {
+                    const long tot = (long)K * N;
+                    copy2d_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(K, N, W, ldw, dst, ldb, 0);
+                    check();
+                }
                 W = dst; ldw = ldb;
             }
+            if (dry) return;
             gemm_dma_kernel<false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn, zero);
         } else {
+            if (dry) return;
             gemm_f32_kernel<false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn);
         }
         check();
@@ -667,6 +738,7 @@ struct Bwd {
     // changed nothing at any setting (the atomics are not the cost).
     void tn(const float *dY, long ldy, int M, const float *X, long ldx, int N, float *dW, long ldw, float *db = nullptr)
     {
+        if (dry) return;
         const int tiles = ((N + GT - 1) / GT) * ((M + GT - 1) / GT);
         long kslab = (P * tiles / 512 + 15) / 16 * 16;
         kslab = kslab < 512 ? 512 : (kslab > 8192 ? 8192 : kslab);
@@ -679,6 +751,7 @@ struct Bwd {
     }
     void copy(const float *src, long lds_, int N, float *dst, long ldd, int mode)
     {
+        if (dry) return;
         copy2d_kernel<<<2048, 256, 0, st>>>(P, N, src, lds_, dst, ldd, mode);
         check();
     }
@@ -734,13 +807,29 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
     auto W = [&](long off) { return flat + off; };
     auto G = [&](long off) { return grad_flat + off; };
     int dbo = 0;   // running offset into db scratch
+    // The walk runs twice: once dry -- nothing is launched, the data-gradient GEMMs record which weight sub-matrices they need as
+    // 16-byte aligned copies -- then all of those copies in one launch, then for real.  Both passes take the same branches, so the
+    // scratch offsets (walo, dbo) they hand out are the same.
+    auto walk = [&]() -> int {
+    dbo = 0;
+    b.walo = 0;
     // bias-gradient slots of one level: BIAS_FLOATS-ish; the last 64 floats of the scratch are the DMA zero page
     static_assert(BIAS_FLOATS + 16 * 40 <= DB_SCRATCH - 64, "bias-gradient scratch too small for this model");
     // bias gradient of a layer: straight into the flat gradient (boff >= 0), or -- for the six layers whose folded per-frame
     // constants need this call's db on its own -- into a scratch slot that add_bias then adds
     auto newdb = [&](int n, long boff = -1) { if (boff >= 0) return G(boff); float *p = db + dbo; dbo += (n + 3) / 4 * 4; return p; };
-    auto add_bias = [&](float *dbl, long boff, int n) { if (dbl == G(boff)) return; axpy_kernel<<<1, 256, 0, stream>>>(n, dbl, G(boff)); b.check(); };
+    auto add_bias = [&](float *dbl, long boff, int n) {      // deferred to the end of the walk, batched (nothing in the walk reads G(boff))
+        if (dbl == G(boff) || b.dry) return;
+        if (b.naxpy < MAX_AXPY_JOBS) { b.axpys.j[b.naxpy++] = AxpyJob{dbl, G(boff), n}; return; }
+        axpy_kernel<<<1, 256, 0, stream>>>(n, dbl, G(boff)); b.check();
+    };
     auto consts = [&](long woff, long ld, int rows, int col0, int cols, const float *dbl, const float *c, float *dc) {
+        if (b.dry) return;
+        if (b.nconst < MAX_CONST_JOBS) {                     // deferred as well: dW's constant columns and dc are read by nothing in the walk
+            b.consts.j[b.nconst++] = ConstJob{W(woff), G(woff), dbl, c, dc, ld, rows, cols, col0};
+            b.const_maxcols = cols > b.const_maxcols ? cols : b.const_maxcols;
+            return;
+        }
         const_cols_backward_kernel<<<cols, 256, 0, stream>>>(rows, cols, W(woff), G(woff), ld, col0, dbl, c, dc);
         b.check();
     };
@@ -804,7 +893,7 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
         float *dbl = newdb(4, Lv.alpha_b);
         b.tn(dsig, 16, 1, A + (long)(act::FEAT) * P, TR_H, TR_H, G(Lv.alpha_w), TR_H, dbl);
         add_bias(dbl, Lv.alpha_b, 1);
-        rank1_add_kernel<<<2048, 256, 0, stream>>>(P, TR_H, dsig, 16, W(Lv.alpha_w), dfeat, 256); b.check();
+        if (!b.dry) { rank1_add_kernel<<<2048, 256, 0, stream>>>(P, TR_H, dsig, 16, W(Lv.alpha_w), dfeat, 256); b.check(); }
     }
     // ================= trunk (modules.py:267-274) =================
     {
@@ -841,17 +930,19 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
     // ================= encodings + feature grid -> d x', d w =================
     {
         const int tb = (int)(GRID_FLOATS / 32 / 32);   // 32 voxels x 32 channels per block
+        if (!b.dry) {
         grid_transpose_kernel<<<tb, 256, 0, stream>>>(W(F.grid), grid_cl, 0); b.check();
         const long gb = (P + 127) / 128;                // 4 waves x 2 runs of 16 samples per block pass
         grid_backward_kernel<<<(unsigned)(gb < 8192 ? gb : 8192), 256, 0, stream>>>(P, actbuf, dgridf, grid_cl, dgrid_cl, dxw); b.check();
         grid_transpose_kernel<<<tb, 256, 0, stream>>>(dgrid_cl, G(F.grid), 1); b.check();
         encode_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, din, dxw, dw); b.check();
+        }
     }
     }   // do_rad
     // ---- the seam: d x' (P,4) and d w (P,4) ----
     if (do_rad && !do_def && xwg_out != nullptr) { b.copy(dxw, 4, 4, xwg_out, 8, 0); b.copy(dw, 4, 4, xwg_out + 4, 8, 0); }
     if (xwg_in != nullptr && do_def) { b.copy(xwg_in, 8, 4, dxw, 4, do_rad ? 1 : 0); b.copy(xwg_in + 4, 8, 4, dw, 4, do_rad ? 1 : 0); }
-    if (!do_def) { if (!b.err && dbo > DB_SCRATCH - 64) b.err = (int)hipErrorOutOfMemory; return b.err; }
+    if (!do_def) { if (!b.dry) b.flush_deferred(); if (!b.err && dbo > DB_SCRATCH - 64) b.err = (int)hipErrorOutOfMemory; return b.err; }
 #if SAHS_MODEL != 2
     // ================= hyper sheet (modules.py:444-462): w = fc_ambient(g5) =================
     {
@@ -881,7 +972,7 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
     }
     // ================= warp field (modules.py:371-390): x' = x + tanh(fc_final(h5)) =================
     {
-        tanh_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, dxw, g3); b.check();
+        if (!b.dry) { tanh_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, dxw, g3); b.check(); }
         float *dbl = newdb(4, F.warp_fb);
         b.tn(g3, 4, 3, A + (long)(act::WH + 5 * 128) * P, WARP_H, WARP_H, G(F.warp_fw), WARP_H, dbl);
         add_bias(dbl, F.warp_fb, 3);
@@ -910,6 +1001,13 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
     (void)drv; (void)d_p36; (void)p36; (void)g3;   // no deformation nets: the gradient stops at the (input) point
 #endif
     (void)layer_params;
+    if (!b.dry) b.flush_deferred();
     if (!b.err && dbo > DB_SCRATCH - 64) b.err = (int)hipErrorOutOfMemory;
     return b.err;
+    };      // walk
+    b.dry = true;
+    if (int e = walk()) return e;
+    b.flush_copies();
+    b.dry = false;
+    return walk();
 }
