@@ -213,7 +213,10 @@ int sahs_resample_merge(long N, int S, int nf, const float *z, const float *weig
  * of every sample to xw[ray][xw_col0 + s] (xw: (N, xw_row, 8) floats); mode 1: the deformation nets only (raw unused); mode 2: the
  * radiance net of `level` only, for S samples per ray whose (x', w) are xw[ray][src[ray][s]] (z unused).  Same arithmetic on the same
  * operands as sahs_model_field_forward: bit-identical raw.  SAHS_F32 for the models with deformation nets (not SAHS_MODEL_NERFACE_STATIC);
- * SAHS_BF16 for SAHS_MODEL_AUDIO (packed from sahs_pack_weights(..., SAHS_BF16, ...)). */
+ * SAHS_BF16 for SAHS_MODEL_AUDIO (packed from sahs_pack_weights(..., SAHS_BF16, ...)) and for SAHS_MODEL_NERFACE, where it means MIXED
+ * precision: mode 1 runs the fp32 deformation nets, mode 2 the bf16 radiance nets (src may then be NULL: sample s of a ray is column s
+ * of xw), mode 0 both one after the other (xw_col0 must be 0); packed = sahs_model_pack_weights(SAHS_MODEL_NERFACE, ..., SAHS_BF16, ...) =
+ * [bf16 radiance stream | fp32 pack].  SAHS_MODEL_NERFACE_STATIC has no deformation nets: its SAHS_BF16 path is sahs_model_field_forward. */
 int sahs_model_field_forward_split(int model, const void *packed, const float *frame, int precision, int level, int mode, long N, int S, const float *rays,
                                    int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src,
                                    void *stream);
@@ -237,7 +240,8 @@ int sahs_route_xw_grad(long N, int Sc, int nf, const int32_t *src, const float *
 
 /* sahs_model_render_rays writing rows[r * row_ld + column] instead of eight dense arrays (row_ld >= 36; columns 17..33 are
  * left untouched when nf == 0).  Workspace and draws as sahs_render_rays.  Optional extra workspace xw (N,Sc+nf,8) floats, src
- * (N,Sc+nf) int32, z_new (N,nf) floats: when all three are given (nf > 0; SAHS_F32, or SAHS_BF16 with SAHS_MODEL_AUDIO) the chain evaluates the deformation nets once per
+ * (N,Sc+nf) int32, z_new (N,nf) floats: when all three are given (nf > 0; any model with deformation nets, SAHS_F32 or SAHS_BF16 -- required for the mixed-precision
+ * SAHS_MODEL_NERFACE + SAHS_BF16, which exists as this chain only) the chain evaluates the deformation nets once per
  * depth (sahs_model_field_forward_split) -- 6 % less matrix work per frame, identical results. */
 int sahs_model_render_rays_rows(int model, const void *packed, const float *frame, int precision, long N, const float *rays,
                                 int ray_stride, int Sc, int nf, int lindisp, int white_background, const float *bg, const float *t_rand,
