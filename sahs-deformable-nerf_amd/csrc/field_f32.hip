@@ -311,7 +311,11 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         // saved activations are one dense [P x width] array per layer (array at column c of the act:: table starts at c * P):
         // this lane's slot in its sample's row of array (c, w)
         const bool sv_on = SAVE && p_raw < P;
-#define SVP(c, w) (actbuf + (long)(c) * P + p * (long)(w) + 4 * q)
+        // (the plane bases actbuf + c * P are loop-invariant: unless P is opaque per tile the compiler hoists all ~40 of them out of the
+        // persistent loop and spills them -- 176 bytes of scratch whose reloads drain the LDS-DMA prefetch)
+        long Psv = P;
+        if constexpr (SAVE) asm volatile("" : "+s"(Psv));
+#define SVP(c, w) (actbuf + (long)(c) * Psv + p * (long)(w) + 4 * q)
 #define SV(c, w) (sv_on ? SVP(c, w) : nullptr)
         float x[3] = {0.0f, 0.0f, 0.0f};
         if constexpr (MODE != FIELD_RADIANCE) {
