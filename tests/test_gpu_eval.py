@@ -73,3 +73,33 @@ def test_eval_frame_loop_expression_model(tmp_path):
     assert len(out) == 2 and out[0]["rgb"].shape == (H, Wd, 15) and bool(torch.isfinite(out[0]["rgb"]).all())
     assert not torch.equal(out[0]["rgb"], out[1]["rgb"])          # the expression drives the render
     assert os.path.getsize(tmp_path / "o" / "normals" / "f_0001.png") > 0
+
+
+@pytest.mark.parametrize("kind,arch", [("audio", "audio"), ("expression", "nerface"), ("expression_static", "nerface_static")])
+def test_eval_frame_loop_bf16_models(kind, arch, tmp_path):
+    """The evaluation frame loop with precision="bf16" models as drop-ins (AudioFaceModel: bf16 kernel; NeRFaceModel with deformation
+    nets: mixed precision through the split chain; without: bf16 kernel): same frames as the fp32 model within the PSNR the
+    kernel-level tests establish, PNGs written."""
+    sahs = pkg()
+    E = pkg("evaluation")
+    W = pkg("weights")
+    dev = torch.device("cuda:0")
+    cfg = sahs.default_config(kind)
+    cfg.nerf.validation.perturb = False
+    fw = W.flatten_state_dict(W.hash_state_dict(0, 8.0, 30.0, model=arch), model=arch)
+    Model = sahs.AudioFaceModel if arch == "audio" else sahs.NeRFaceModel
+    H = Wd = 20
+    focal = np.array([1100.0 * Wd / 512, 1100.0 * Wd / 512, 0.5, 0.5], np.float32)
+    rng = np.random.default_rng(5)
+    cam = 0.8 if arch == "audio" else 0.5
+    drive = dict(audio=rng.standard_normal((16, 29)).astype(np.float32)) if arch == "audio" else dict(expression=(rng.standard_normal(76) * 0.5).astype(np.float32))
+    frames = [dict(pose=np.concatenate([np.eye(3), [[0.0], [0.0], [cam]]], 1).astype(np.float32), name="f_0000.png", **drive)]
+    bg = torch.rand(H, Wd, 15)
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        model = Model(cfg, precision=prec).to(dev).load_flat(fw).eval()
+        outs[prec] = E.render_frames(model, cfg, frames, (H, Wd, focal), background=bg, savedir=str(tmp_path / prec), log=lambda s: None)[0]["rgb"]
+        assert outs[prec].shape == (H, Wd, 15) and bool(torch.isfinite(outs[prec]).all())
+        assert os.path.getsize(tmp_path / prec / "f_0000.png") > 0
+    mse = float(((outs["fp32"][..., :3] - outs["bf16"][..., :3]) ** 2).mean())
+    assert mse > 0.0 and -10.0 * np.log10(mse) >= 35.0, mse      # a different kernel ran, and it agrees with the fp32 frame
