@@ -17,7 +17,9 @@ VARIANTS = {"base": [],  "nope": ["SAHS_ABLATE_NOPE"], "nobarrier": ["SAHS_ABLAT
             "ntstore": ["SAHS_ABLATE_NTSTORE"], "noact": ["SAHS_ABLATE_NOACT"],
             # round 2: hand-issued A-fragment reads N fragments ahead with counted lgkmcnt; one wave per SIMD (4 waves)
             "apf3": ["SAHS_BF16_APF=3"], "apf4": ["SAHS_BF16_APF=4"], "apf6": ["SAHS_BF16_APF=6"], "apf8": ["SAHS_BF16_APF=8"],
-            "wnopack": ["SAHS_ABLATE_NOPACK"], "wagpr": ["SAHS_NOTHING"], "wnoaccread": ["SAHS_ABLATE_NOACCREAD"], "wnodma": ["SAHS_ABLATE_NODMA"], "wnopack_nodma": ["SAHS_ABLATE_NOPACK", "SAHS_ABLATE_NODMA"],
+            # (wnopack: INVALID as an MFMA-only time -- without the conversions the compiler deletes 45 % of the MFMAs, DESIGN.md section 3.1b;
+            #  wall-time ablations of this kernel also move the clock the chip holds: use tools/stamp_bf16w.py, which counts cycles)
+            "wnopack": ["SAHS_ABLATE_NOPACK"], "wagpr": ["SAHS_NOTHING"], "wnodma": ["SAHS_ABLATE_NODMA"],
             "wfp32relu": ["SAHS_BF16W_FP32_RELU"], "wpkmul": ["SAHS_BF16W_PKMUL"],
             "w4": ["SAHS_BF16_WAVES=4"], "w4apf6": ["SAHS_BF16_WAVES=4", "SAHS_BF16_APF=6"]}
 
