@@ -45,8 +45,9 @@ sys.path.insert(0, REPO)
 FLOP_PER_SAMPLE = {"audio": 1_855_744,            # BASELINE.md section 3 (GEMM work as the reference writes it)
                    "nerface": 2 * 719_168}        # the same count for NeRFaceModel (config/expression/person_2.yml)
 PEAK_TFLOPS = {"fp32": 157.3,        # MI355X_MICROARCH.md: FP32 matrix peak (v_mfma_f32_16x16x4_f32)
-               "bf16": 2500.0}       # dense BF16 MFMA peak (never the 2:1-sparse figure)
-KERNEL = {"fp32": "field_forward_f32_kernel", "bf16": "field_forward_bf16w_kernel"}
+               "bf16": 2500.0,       # dense BF16 MFMA peak (never the 2:1-sparse figure)
+               "bf16x3": 2500.0 / 3}   # three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi): the peak of the ALGORITHMIC work
+KERNEL = {"fp32": "field_forward_f32_kernel", "bf16": "field_forward_bf16w_kernel", "bf16x3": "field_radiance_bf16x3_kernel"}
 HDR = dict(seed=0, density_bias=2.0, density_gain=30.0, hdr=True)      # = VARIANTS["hdr"] of tests/golden/make_golden.py
 # HBM-side bytes of the dominant dispatch (the launch over the 16.8 M fine samples of a ray chunk) from the committed rocprofv3 PMC passes
 # (WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction for 16 B/lane streaming reads).  STATIC: bench.py cannot collect PMCs itself; the
@@ -147,8 +148,8 @@ class HipRenderer:
         self.packed, _ = self.model.packed()
         self.flop_per_sample = FLOP_PER_SAMPLE[arch]
         # the deformation nets are evaluated once per depth (sahs_model_field_forward_split), as the drop-in driver does
-        self.split = share_deformation and precision in ("fp32", "bf16") and arch != "nerface_static"
-        self.mixed = precision == "bf16" and arch == "nerface"       # fp32 deformation launches + bf16 radiance launches
+        self.split = share_deformation and precision in ("fp32", "bf16", "bf16x3") and arch != "nerface_static"
+        self.mixed = self.ops.is_mixed(arch, self.prec)               # fp32 deformation launches + low-precision radiance launches
         ex = lambda part: 2 * self.ops.executed_macs_per_sample(arch, self.prec, part)
         self.exec_flop_per_sample = ex(0)
         # executed FLOPs per RAY: coarse = nc whole-network evaluations; fine = nf deformation + (nc + nf) radiance evaluations when split
@@ -225,9 +226,11 @@ class HipRenderer:
             rms = sum(a.elapsed_time(b) for a, b, _ in self.radiance_events)
             rfl = sum(p for _, _, p in self.radiance_events) * 2 * self.ops.executed_macs_per_sample(self.arch, self.prec, 2)
             alg = {"audio": 2 * 757_760}.get(self.arch)
-            dominant = {"kernel": ("field_forward_f32_kernel<false, 2>" if self.precision_name == "fp32" else "field_forward_bf16w_kernel<2>") + " (radiance net over the fine samples of a ray chunk)",
+            dominant = {"kernel": {"fp32": "field_forward_f32_kernel<false, 2>", "bf16": "field_forward_bf16w_kernel<2>",
+                                   "bf16x3": "field_radiance_bf16x3_kernel"}[self.precision_name] + " (radiance net over the fine samples of a ray chunk)",
                         "avg_launch_ms": rms / len(self.radiance_events), "executed_tflops": rfl / (rms * 1e-3) / 1e12,
-                        "frac_executed": rfl / (rms * 1e-3) / 1e12 / peak}
+                        # bf16x3 issues three MFMAs per product: its executed FLOPs are priced against the pipe's 2.5 PFLOP/s
+                        "frac_executed": rfl / (rms * 1e-3) / 1e12 / (PEAK_TFLOPS["bf16"] if self.precision_name == "bf16x3" else peak)}
             if alg is not None:
                 dominant["achieved"] = sum(p for _, _, p in self.radiance_events) * alg / (rms * 1e-3) / 1e12
                 dominant["frac"] = dominant["achieved"] / peak
@@ -242,8 +245,8 @@ class HipRenderer:
                          "depths, so frac can exceed frac_executed (the instructions actually issued) by more than the constant folding alone") if self.split else None,
                 "frac_executed": (samples / (2 * self.nc + self.nf)) * self.exec_flop_per_ray / (field_ms * 1e-3) / 1e12 / peak,
                 "field_time_share": field_ms * 1e-3 / dt,
-                **({"mixed_precision": "fp32 deformation launches + bf16 radiance launches: 'achieved' / 'frac' price the whole chain against the bf16 "
-                                       "peak and are NOT a kernel roofline here; dominant_kernel is the bf16 radiance launch alone"} if self.mixed else {})}
+                **({"mixed_precision": "fp32 deformation launches + low-precision radiance launches: 'achieved' / 'frac' price the whole chain against "
+                                       "the low-precision peak and are NOT a kernel roofline here; dominant_kernel is the radiance launch alone"} if self.mixed else {})}
 
 
 _T0 = time.perf_counter()
@@ -277,7 +280,7 @@ def measure(pkg, dev, size, precision, steps, warmup, arch="audio", num_fine=Non
 
     with torch.no_grad():
         rec, out = run_headline(r, r.R, world, rank, steps, warmup, dist, gather, torch.cuda.synchronize,
-                                {"fp32": "f32", "bf16": "bf16"}[precision], config, roofline)
+                                {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3 (hi + lo operands, f32 accumulate; deformation nets f32)"}[precision], config, roofline)
     assert bool(torch.isfinite(out).all())
     return rec, out, r
 
@@ -326,6 +329,20 @@ def add_secondary_legs(result, pkg, dev, args):
                                     "psnr_mixed_vs_fp32_db": psnr(rgb_fine(outm), rgb_fine(f32n)), "psnr_mixed_vs_target_db": p_b,
                                     "psnr_fp32_vs_target_db": p_f, "delta_psnr_db": abs(p_b - p_f), "w_bg_mean": float(f32n[:, 34].mean())}
     del rm, rn, outm, f32n, tgtn
+    # near-fp32 on the bf16 pipe: fp32 deformation nets + radiance nets with bf16 hi/lo operands (3 MFMAs per product)
+    progress("bf16x3 leg")
+    recx, outx, rx = measure(pkg, dev, size, "bf16x3", min(args.steps, 5), 1)
+    r32 = HipRenderer(pkg, dev, size, "fp32")
+    with torch.no_grad():
+        f32a = r32.render(0, r32.R)
+    dx = (outx - f32a).abs()
+    coarse_cols = list(range(0, 17))
+    result["bf16x3"] = {"value": recx["value"], "unit": "rays/s", "ms_per_step": recx["ms_per_step"],
+                        "dtype": "f32 deformation nets + bf16 hi/lo radiance nets (3 MFMAs per product, f32 accumulate)",
+                        "speedup_vs_fp32": recx["value"] / result["value"], "roofline": recx["roofline"],
+                        "psnr_vs_fp32_db": psnr(rgb_fine(outx), rgb_fine(f32a)), "max_abs_diff_coarse_outputs": float(dx[:, coarse_cols].max()),
+                        "rays_within_4x_fp32_tolerance": float(((dx <= 4e-5 + 4e-4 * f32a.abs()).all(dim=1)).float().mean())}
+    del rx, r32, outx, f32a, dx
     # the num_fine 128 reading (fine pass of 192 samples, 256 evaluations per ray)
     progress("num_fine128 leg")
     rec, _, _ = measure(pkg, dev, size, "fp32", 2, 1, num_fine=128)
@@ -505,7 +522,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512, help="frame is size x size rays")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="fp32 = configs[1] (exact, headline); bf16 = configs[2] (bf16 MFMA operands, fp32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the torch_gpu_baseline / cpu_baseline legs")
     ap.add_argument("--no-secondary", action="store_true", help="headline only (no bf16 / NeRFace / num_fine128 / training legs)")

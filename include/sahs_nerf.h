@@ -27,6 +27,8 @@ extern "C" {
 #define SAHS_ABI_VERSION 1
 #define SAHS_F32 0
 #define SAHS_BF16 1
+#define SAHS_BF16X3 3    /* near-fp32 on the bf16 pipe (AudioFaceModel, split chain only): operands split into bf16 hi + lo, three MFMAs per product,
+                          * fp32 accumulate, for the RADIANCE nets; the deformation nets run on the fp32 kernel (mixed, like SAHS_MODEL_NERFACE + SAHS_BF16) */
 #define SAHS_BF16_2W 2   /* the same arithmetic and packed stream as SAHS_BF16 through the earlier 2-waves-per-SIMD kernel (A/B reference) */
 
 int sahs_abi_version(void);

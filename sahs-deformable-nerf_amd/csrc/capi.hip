@@ -79,6 +79,11 @@ int sahs_pack_weights_bf16_launch_nf(const float *flat, float *packed, hipStream
 int sahs_field_forward_bf16w_split_launch_nf(const float *packed, const float *frame, int level, int mode, long P, int S, const float *rays,
                                              int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
                                              int num_cu, hipStream_t stream);
+// AudioFaceModel, SAHS_BF16X3: the radiance nets with operands split into bf16 hi + lo (field_bf16x3.hip); deformation nets fp32
+long sahs_layout_packed_words_bf16x3(void);
+int sahs_pack_weights_bf16x3_launch(const float *flat, float *packed, hipStream_t stream);
+int sahs_field_radiance_bf16x3_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
+                                      float *raw, const float *xw, int xw_row, const int *src, int num_cu, hipStream_t stream);
 // NeRFaceModel without deformation nets (person_1.yml): the whole network in bf16
 long sahs_layout_packed_words_bf16_ns(void);
 int sahs_pack_weights_bf16_launch_ns(const float *flat, float *packed, hipStream_t stream);
@@ -122,6 +127,7 @@ const char *sahs_last_error(void) { return g_err; }
 long sahs_param_count(void) { return kFlat.total; }
 long sahs_packed_words(int precision)
 {
+    if (precision == SAHS_BF16X3) return sahs_layout_packed_words_bf16x3() + PACK_FLOATS;     // [hi/lo radiance streams | fp32 pack (deformation nets)]
     return precision == SAHS_F32 ? PACK_FLOATS : ((precision == SAHS_BF16 || precision == SAHS_BF16_2W) ? hb::PACKH_WORDS : -1);
 }
 long sahs_frame_words(void) { return FRAME_FLOATS; }
@@ -130,6 +136,11 @@ int sahs_pack_weights(const float *flat_params, void *packed, int precision, voi
 {
     REQUIRE(flat_params && packed, "sahs_pack_weights");
     REQUIRE(ALIGNED16(packed), "sahs_pack_weights(packed alignment)");
+    if (precision == SAHS_BF16X3) {
+        int e = sahs_pack_weights_bf16x3_launch(flat_params, (float *)packed, (hipStream_t)stream);
+        if (!e) e = sahs_pack_weights_f32_launch(flat_params, (float *)packed + sahs_layout_packed_words_bf16x3(), (hipStream_t)stream);
+        return e ? hip_fail("sahs_pack_weights", e) : 0;
+    }
     if (precision != SAHS_F32 && precision != SAHS_BF16 && precision != SAHS_BF16_2W) return fail(2, "sahs_pack_weights: unknown precision %s%ld", "", precision);
     int e = precision == SAHS_F32 ? sahs_pack_weights_f32_launch(flat_params, (float *)packed, (hipStream_t)stream)
                                   : sahs_pack_weights_bf16_launch(flat_params, (float *)packed, (hipStream_t)stream);
@@ -174,6 +185,9 @@ int sahs_field_forward(const void *packed, const float *frame, int level, long N
     REQUIRE(packed && frame && rays && z && raw, "sahs_field_forward");
     REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_field_forward(shape)");
     REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_field_forward(alignment)");
+    if (precision == SAHS_BF16X3)
+        return fail(2, "sahs_field_forward: SAHS_BF16X3 runs through sahs_model_field_forward_split / sahs_model_render_rays_rows (it needs the xw "
+                       "workspace)%s%ld", "", 0L);
     if (precision != SAHS_F32 && precision != SAHS_BF16 && precision != SAHS_BF16_2W) return fail(2, "sahs_field_forward: unknown precision %s%ld", "", precision);
     int e = precision == SAHS_F32
                 ? sahs_field_forward_f32_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, nullptr, num_cus(),
@@ -375,7 +389,9 @@ long sahs_model_packed_words(int model, int precision)
 }
 long sahs_model_executed_macs_part(int model, int precision, int part)
 {
-    if (model < 0 || model > 2 || precision < SAHS_F32 || precision > SAHS_BF16_2W || part < 0 || part > 2) return -1;
+    if (model < 0 || model > 2 || precision < SAHS_F32 || precision > SAHS_BF16X3 || part < 0 || part > 2) return -1;
+    if (precision == SAHS_BF16X3)       // fp32 deformation nets + three bf16 MFMAs per product of the radiance nets
+        return model != SAHS_MODEL_AUDIO ? -1 : (part != 2 ? sahs_layout_executed_macs(SAHS_F32, 1) : 0) + (part != 1 ? 3 * sahs_layout_executed_macs(SAHS_BF16, 2) : 0);
     if (model == SAHS_MODEL_NERFACE_STATIC && part != 0) return part == 2 ? sahs_layout_executed_macs_ns(precision == SAHS_F32 ? SAHS_F32 : SAHS_BF16, 0) : 0;
     if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)      // mixed: fp32 deformation nets + bf16 radiance nets
         return (part != 2 ? sahs_layout_executed_macs_nf(SAHS_F32, 1) : 0) + (part != 1 ? sahs_layout_executed_macs_nf(SAHS_BF16, 2) : 0);
@@ -493,20 +509,25 @@ int sahs_model_field_forward_split(int model, const void *packed, const float *f
     if (model == SAHS_MODEL_NERFACE_STATIC) return fail(4, "sahs_model_field_forward_split: this model has no deformation nets%s%ld", "", 0L);
     REQUIRE(packed && frame && rays && xw && (level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8 && mode >= 0 && mode <= 2,
             "sahs_model_field_forward_split");
-    const bool mixed = precision == SAHS_BF16 && model == SAHS_MODEL_NERFACE;
+    const bool x3 = precision == SAHS_BF16X3 && model == SAHS_MODEL_AUDIO;
+    const bool mixed = (precision == SAHS_BF16 && model == SAHS_MODEL_NERFACE) || x3;
     REQUIRE((mode == 1 || raw) && (mode == 2 || z) && (mode != 2 || src || mixed), "sahs_model_field_forward_split(buffers of the mode)");
     REQUIRE(xw_col0 >= 0 && xw_row >= xw_col0 + (mode == 2 ? 0 : S) && ALIGNED16(xw) && ALIGNED16(packed) && ALIGNED16(frame) && (!raw || ALIGNED16(raw)),
             "sahs_model_field_forward_split(xw layout / alignment)");
     if (mixed) {      // deformation nets by the fp32 kernel, radiance nets by the bf16 kernel; mode 0 = both, one after the other
-        const float *pk16 = (const float *)packed, *pk32 = pk16 + sahs_layout_packed_words_bf16_nf();
+        const float *pk16 = (const float *)packed, *pk32 = pk16 + (x3 ? sahs_layout_packed_words_bf16x3() : sahs_layout_packed_words_bf16_nf());
         REQUIRE(mode != 0 || xw_col0 == 0, "sahs_model_field_forward_split(mixed precision, mode 0: xw_col0 must be 0)");
         int e = 0;
         if (mode != 2)
-            e = sahs_field_forward_f32_split_launch_nf(pk32, frame, level, 1, N * S, S, rays, ray_stride, z, nullptr, xw, xw_row, xw_col0, nullptr, nullptr,
-                                                       num_cus(), (hipStream_t)stream);
+            e = x3 ? sahs_field_forward_f32_split_launch(pk32, frame, level, 1, N * S, S, rays, ray_stride, z, nullptr, xw, xw_row, xw_col0, nullptr, nullptr,
+                                                         num_cus(), (hipStream_t)stream)
+                   : sahs_field_forward_f32_split_launch_nf(pk32, frame, level, 1, N * S, S, rays, ray_stride, z, nullptr, xw, xw_row, xw_col0, nullptr,
+                                                            nullptr, num_cus(), (hipStream_t)stream);
         if (!e && mode != 1)
-            e = sahs_field_forward_bf16w_split_launch_nf(pk16, frame, level, 2, N * S, S, rays, ray_stride, nullptr, raw, xw, xw_row, 0, mode == 2 ? src : nullptr,
-                                                         num_cus(), (hipStream_t)stream);
+            e = x3 ? sahs_field_radiance_bf16x3_launch(pk16, frame, level, N * S, S, rays, ray_stride, raw, xw, xw_row, mode == 2 ? src : nullptr, num_cus(),
+                                                       (hipStream_t)stream)
+                   : sahs_field_forward_bf16w_split_launch_nf(pk16, frame, level, 2, N * S, S, rays, ray_stride, nullptr, raw, xw, xw_row, 0,
+                                                              mode == 2 ? src : nullptr, num_cus(), (hipStream_t)stream);
         return e ? hip_fail("sahs_model_field_forward_split", e) : 0;
     }
     if (precision != SAHS_F32 && !(precision == SAHS_BF16 && model == SAHS_MODEL_AUDIO))
@@ -612,9 +633,11 @@ int sahs_model_render_rays_rows(int model, const void *packed, const float *fram
     REQUIRE_MODEL(model, "sahs_model_render_rays_rows");
     if (N == 0) return 0;
     REQUIRE(rows && row_ld >= SAHS_ROW_COLUMNS, "sahs_model_render_rays_rows(rows)");
-    if (precision == SAHS_BF16 && model == SAHS_MODEL_NERFACE)
-        REQUIRE(xw && src && z_new && nf > 0, "sahs_model_render_rays_rows(the mixed-precision NeRFaceModel needs the xw / src / z_new workspace and nf > 0)");
-    if (xw && src && z_new && nf > 0 && ((precision == SAHS_F32 && model != SAHS_MODEL_NERFACE_STATIC) || (precision == SAHS_BF16 && model != SAHS_MODEL_NERFACE_STATIC))) {
+    if ((precision == SAHS_BF16 && model == SAHS_MODEL_NERFACE) || precision == SAHS_BF16X3) {
+        REQUIRE(xw && src && z_new && nf > 0, "sahs_model_render_rays_rows(a mixed-precision model needs the xw / src / z_new workspace and nf > 0)");
+        REQUIRE(precision != SAHS_BF16X3 || model == SAHS_MODEL_AUDIO, "sahs_model_render_rays_rows(SAHS_BF16X3 is built for SAHS_MODEL_AUDIO)");
+    }
+    if (xw && src && z_new && nf > 0 && model != SAHS_MODEL_NERFACE_STATIC && (precision == SAHS_F32 || precision == SAHS_BF16 || precision == SAHS_BF16X3)) {
         // the deformation nets are shared by the two levels and the fine depths contain the coarse ones: evaluate them once per depth
         const char *who = "sahs_model_render_rays_rows";
         REQUIRE(packed && frame && rays && z_c && z_f && raw && weights && Sc + nf <= 256, who);

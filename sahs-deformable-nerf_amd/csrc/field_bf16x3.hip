@@ -1,0 +1,563 @@
+// field_bf16x3.hip -- near-fp32 radiance nets on the bf16 matrix pipe (precision SAHS_BF16X3).
+//
+// Every operand is split into two bf16 numbers, x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16-17 significant bits together),
+// and a product is three MFMAs with fp32 accumulation,
+//     W x  ~=  W_hi x_hi + W_hi x_lo + W_lo x_hi            (the dropped W_lo x_lo term is ~2^-18 of the product).
+// Derived from field_bf16w.hip (one wave per SIMD: read that file for the structure -- chunked weight stream through LDS-DMA, hand-issued
+// A reads with counted lgkmcnt, bias as the C operand of a tile's first MFMA, conversion "ticks" dealt into the MFMA gaps) with these
+// differences:
+//   * RADIANCE NETS ONLY (the split evaluation's FIELD_RADIANCE launch): the deformation nets stay on the fp32 kernel, exactly as for the
+//     mixed-precision NeRFaceModel -- the deformed point feeds sin/cos(2^9 x') and must keep fp32 accuracy.  AudioFaceModel only.
+//   * ONE 32-sample half per wave: an activation block holds hi AND lo fragments -- the registers two halves of plain bf16 would take.
+//   * The packed stream holds [hi fragment | lo fragment] per k-step (2 KB), so a 64 KB chunk holds half as many tiles.
+//   * The conversion produces hi and lo (about 5 VALU per value instead of 2.5); with three MFMAs per value it hides under them.
+#include <hip/hip_runtime.h>
+#include <utility>
+#include "sahs_common.hpp"
+#include "sahs_layout.hpp"
+
+#if SAHS_MODEL != 0
+#error "field_bf16x3.hip is built for the AudioFaceModel only"
+#endif
+
+namespace sahs {
+namespace hx3 {
+using namespace hb;      // the bf16 layer program of sahs_layout.hpp (layers, blocks, bias offsets); offsets of the doubled stream derived below
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct Blk { u32x4 s[2]; u32x4 l[2]; };            // 32 features of this lane's sample: hi (s) and lo (l) bf16x8 fragments per k-step (as dwords)
+
+constexpr int X_THREADS = 256;
+constexpr int X_PTS_PER_WAVE = 32;
+constexpr int X_PTS_PER_WG = (X_THREADS / WAVE) * X_PTS_PER_WAVE;     // 128
+constexpr int LDS_BUF_BYTES = CHUNK_HW_MAX * 2;                       // 64 KB each, two of them
+constexpr int LDS_BIAS_BYTE_OFF = 2 * LDS_BUF_BYTES;
+constexpr int LDS_STASH_BYTE_OFF = LDS_BIAS_BYTE_OFF + ((BIAS_FLOATS + 3) / 4) * 16;
+constexpr int STASH_FLOATS = 8;                                       // per sample: x'[3], w[2] (+pad)
+constexpr int LDS_BYTES = LDS_STASH_BYTE_OFF + X_PTS_PER_WG * STASH_FLOATS * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int AP = 4;                                                  // k-steps whose A fragments (hi and lo) are in flight ahead of their MFMAs
+constexpr int PIECE_HW = X_THREADS * 8;                                // one LDS-DMA piece: 4 KB = 2048 halfwords (1 KB per wave)
+constexpr int DMA_PIECES = LDS_BUF_BYTES / (X_THREADS * 16);           // 16
+constexpr int FRAG_BYTES = 1024;                                       // one fragment of 64 lanes x 8 halfwords
+constexpr int STEP_BYTES = 2 * FRAG_BYTES;                             // hi + lo
+// chunking of the doubled stream: a k-step of a tile is 2 KB, a chunk at most 64 KB
+constexpr int pick_GX(int KB32, int NT32)
+{
+    int g = (CHUNK_HW_MAX / 2) / (KB32 * 1024);
+    if (g < 1) g = 1;
+    if (g > NT32) g = NT32;
+    while (NT32 % g) --g;
+    return g;
+}
+constexpr long STREAM_HWX = 2 * STREAM_HW;                             // halfwords per level; layer i starts at 2 * kProgH.layer[i].stream_off
+static_assert(11 * 2048 * 2 <= LDS_BUF_BYTES, "one tile of the widest layer (11 k-blocks) must fit a buffer");
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p; }
+
+// hand-issued LDS reads (volatile asm: they stay where they are written; destinations are unprotected until the counted wait)
+template <int OFF, class V>
+__device__ __forceinline__ void lds_read16(V &dst, uint32_t addr)
+{
+    static_assert(sizeof(V) == 16, "one ds_read_b128");
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm()
+{
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+}
+__device__ __forceinline__ void fence() { __builtin_amdgcn_sched_barrier(0); }
+
+struct Ctx {
+    const unsigned short *stream;   // this level's packed hi/lo stream
+    char *lds;
+    int buf;
+    int lane, h, wave;
+    const f32x4 *nx_src; f32x4 *nx_dst;
+    uint32_t off;                   // halfword offset of the NEXT chunk to prefetch (uniform)
+    uint32_t wrap_at, wrap_to;      // the radiance nets' range of the stream
+    uint32_t bias_addr;             // LDS byte address of this lane's first bias row (+4h rows)
+
+    __device__ __forceinline__ void prepare(int hw, int b)
+    {
+        if (off >= wrap_at) off = wrap_to;
+        nx_src = reinterpret_cast<const f32x4 *>(stream + off) + lane;
+        nx_dst = reinterpret_cast<f32x4 *>(lds + b * LDS_BUF_BYTES);
+        off += (uint32_t)hw;
+    }
+    __device__ __forceinline__ void issue_piece(int p)
+    {
+        const int base = p * X_THREADS + wave * WAVE;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(nx_src + base), (lds_ptr_t)(nx_dst + base), 16, 0, 0);
+    }
+    __device__ __forceinline__ void begin_chunk(int next_hw) { prepare(next_hw, buf ^ 1); }
+    __device__ __forceinline__ void end_chunk()
+    {
+        __syncthreads();            // vmcnt(0) (the next chunk has landed) + barrier (every wave is done with this one)
+        buf ^= 1;
+    }
+    __device__ __forceinline__ uint32_t cur_addr() const { return lds_addr_of(lds + buf * LDS_BUF_BYTES) + 16 * lane; }
+    __device__ __forceinline__ void refresh_bias_base()
+    {
+        uint32_t a = lds_addr_of(lds) + LDS_BIAS_BYTE_OFF + 16 * h;
+        asm volatile("" : "+v"(a));
+        bias_addr = a;
+    }
+};
+
+template <int OFF>
+__device__ __forceinline__ void bias_read(f32x4 (&t)[4], uint32_t addr)
+{
+    lds_read16<OFF>(t[0], addr);
+    lds_read16<OFF + 32>(t[1], addr);
+    lds_read16<OFF + 64>(t[2], addr);
+    lds_read16<OFF + 96>(t[3], addr);
+}
+__device__ __forceinline__ f32x16 bias_as_c(const f32x4 (&t)[4])
+{
+    f32x16 b;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[4 * g + r] = t[g][r];
+    return b;
+}
+
+// hi/lo split of a pair of fp32 values: hi = bf16 pair (RNE), lo = bf16 pair of the remainders
+__device__ __forceinline__ uint32_t cvt_pair(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2)); }
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t &hi, uint32_t &lo)
+{
+    hi = cvt_pair(a, b);
+    lo = cvt_pair(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u));
+}
+
+// ---- activation + hi/lo conversion of a finished accumulator tile, software-pipelined (field_bf16w.hip: pack_tick) -------------------
+// 16 values per lane and tile.  tick T:  A(T)    m = v_{T,T+1} * slope              (leaky only, T even)
+//                                        B(T-1)  r = max(v, m) | v
+//                                        C(T-2)  hi dword = cvt_pk(r_{T-3}, r_{T-2})                       when T-2 is odd
+//                                        D(T-3)  e = r - float(hi) for both values of the pair              when T-3 is odd
+//                                        E(T-4)  lo dword = cvt_pk(e0, e1)                                  when T-4 is odd
+struct PackState { f32x2 m2[2]; float r[4]; uint32_t hi[2]; float e[2][2]; };
+constexpr int NV = 16;
+constexpr int PACK_TICKS = NV + 5;
+template <int T>
+__device__ __forceinline__ void pack_tick(const f32x16 &acc, Blk &o, float slope, PackState &ps)
+{
+    if constexpr (T >= 0 && T < NV && !(T & 1)) {           // A(T), T even: both values of the pair
+        constexpr int P = T >> 1;
+        if (slope != 1.0f) ps.m2[P & 1] = f32x2{acc[2 * P], acc[2 * P + 1]} * f32x2{slope, slope};
+    }
+    if constexpr (T - 1 >= 0 && T - 1 < NV) {               // B(T-1)
+        constexpr int U = T - 1, P = U >> 1, e = U & 1;
+        const float v = acc[2 * P + e];
+        ps.r[U & 3] = slope == 1.0f ? v : fmaxf(v, ps.m2[P & 1][e]);
+    }
+    if constexpr (T - 2 >= 1 && T - 2 < NV && ((T - 2) & 1)) {    // C(T-2): the pair (U-1, U) is complete -> hi
+        constexpr int U = T - 2, P = U >> 1, s = P >> 2, jp = P & 3;
+        ps.hi[P & 1] = cvt_pair(ps.r[(U - 1) & 3], ps.r[U & 3]);
+        o.s[s][jp] = ps.hi[P & 1];
+    }
+    if constexpr (T - 3 >= 1 && T - 3 < NV && ((T - 3) & 1)) {    // D(T-3): remainders (r[U-1], r[U] are still theirs: B has since
+        constexpr int U = T - 3, P = U >> 1;                      //          written r[(U+1)&3] and r[(U+2)&3] only)
+        ps.e[P & 1][0] = ps.r[(U - 1) & 3] - __builtin_bit_cast(float, ps.hi[P & 1] << 16);
+        ps.e[P & 1][1] = ps.r[U & 3] - __builtin_bit_cast(float, ps.hi[P & 1] & 0xffff0000u);
+    }
+    if constexpr (T - 4 >= 1 && T - 4 < NV && ((T - 4) & 1)) {    // E(T-4): lo
+        constexpr int U = T - 4, P = U >> 1, s = P >> 2, jp = P & 3;
+        o.l[s][jp] = cvt_pair(ps.e[P & 1][0], ps.e[P & 1][1]);
+    }
+}
+template <int LO, int HI>
+__device__ __forceinline__ void pack_ticks(const f32x16 &acc, Blk &o, float slope, PackState &ps)
+{
+    [&]<int... Is>(std::integer_sequence<int, Is...>) { (pack_tick<LO + Is>(acc, o, slope, ps), ...); }(std::make_integer_sequence<int, HI - LO>{});
+}
+
+__device__ __forceinline__ bf16x8 frag(const u32x4 &v) { return __builtin_bit_cast(bf16x8, v); }
+
+// LGKM bookkeeping as in field_bf16w.hip (Sched), with TWO A reads (hi, lo) per k-step: step I issues [wait] [3 MFMAs] [bias batch of the
+// next tile: 4 reads, when I starts a tile that has a successor] [A reads of step I+AP: hi then lo]; the wait of step I allows exactly
+// the reads issued after A_lo(I).
+template <int STEPS, int TOTAL, int NT32, int T0>
+struct Sched {
+    static constexpr bool bias_at(int s) { return s >= 0 && s < TOTAL && (s % STEPS == 0) && (T0 + s / STEPS + 1 < NT32); }
+    static constexpr bool aread_at(int s) { return s >= 0 && s + AP < TOTAL; }
+    static constexpr int cnt(int I)
+    {
+        int n = 0, lo = 0;
+        if (I < AP) n += 2 * ((AP < TOTAL ? AP : TOTAL) - 1 - I);   // read in the prologue: the later prologue reads, then steps 0..I-1
+        else lo = I - AP + 1;                                        // read at the END of step I-AP (after that step's bias batch)
+        for (int s = lo; s < I; ++s) n += (aread_at(s) ? 2 : 0) + (bias_at(s) ? 4 : 0);
+        return n;
+    }
+    static constexpr int max_cnt()
+    {
+        int m = 0;
+        for (int i = 0; i < TOTAL; ++i) m = cnt(i) > m ? cnt(i) : m;
+        return m;
+    }
+};
+
+struct St {
+    f32x16 acc[2];       // two accumulator sets: tile t accumulates into one while tile t-1 is converted from the other
+    PackState ps;
+};
+
+// hidden layer: NT32 output tiles of 32 rows.  The layer's last tile stays in st.acc[1]; the NEXT layer converts it (PEND) into
+// in0[K0-1] with activation slope pslope under its own first MFMAs, before the step that first reads that block.
+template <int K0, int K1, int K2, int NT32, int NEXT_HW, bool PEND>
+__device__ __forceinline__ void dense_x(Ctx &cx, St &st, Blk *in0, const Blk *in1, const Blk *in2, Blk *out, int bias_off, float slope, float pslope)
+{
+    constexpr int KB = K0 + K1 + K2;
+    constexpr int G = pick_GX(KB, NT32);
+    constexpr int STEPS = KB * 2, TOTAL = G * STEPS, NCH = NT32 / G;
+    static_assert(NT32 % 2 == 0, "the last tile of a layer must land in accumulator set 1");
+    static_assert(TOTAL * STEP_BYTES <= LDS_BUF_BYTES, "chunk does not fit its buffer");
+    const uint32_t baddr = cx.bias_addr + 4u * (uint32_t)bias_off;
+    f32x4 braw[2][4];
+    bias_read<0>(braw[0], baddr);
+
+    auto chunk = [&]<int C>() {
+        constexpr int T0 = C * G;
+        constexpr int nhw = (C + 1 < NCH) ? G * KB * 2048 : NEXT_HW;
+        constexpr int npieces = (nhw + PIECE_HW - 1) / PIECE_HW;
+        constexpr int PSTEP = (TOTAL * 3 / 4) / (npieces > 0 ? npieces : 1) > 0 ? (TOTAL * 3 / 4) / (npieces > 0 ? npieces : 1) : 1;
+        using S = Sched<STEPS, TOTAL, NT32, T0>;
+        static_assert(S::max_cnt() <= 15, "lgkmcnt is a 4-bit counter");
+        cx.begin_chunk(nhw);
+        const uint32_t abase = cx.cur_addr();
+        u32x4 ah[AP], al[AP];
+        [&]<int... Is>(std::integer_sequence<int, Is...>) {
+            ((lds_read16<Is * STEP_BYTES>(ah[Is], abase), lds_read16<Is * STEP_BYTES + FRAG_BYTES>(al[Is], abase)), ...);
+        }(std::make_integer_sequence<int, (AP < TOTAL ? AP : TOTAL)>{});
+        fence();
+        auto step = [&]<int I>() {
+            constexpr int g = I / STEPS, k = I % STEPS, b = k >> 1, st_ = k & 1, t = T0 + g, set = t & 1;
+            const Blk &x = (b < K0) ? in0[b] : ((b < K0 + K1) ? in1[b - K0] : in2[b - K0 - K1]);
+            wait_lgkm<S::cnt(I)>();
+            fence();
+            f32x16 cb;
+            if constexpr (k == 0) cb = bias_as_c(braw[set]);
+            // W x ~= W_hi x_hi + W_hi x_lo + W_lo x_hi: one accumulation chain (back-to-back MFMAs on one accumulator run at the pipe's rate)
+            if constexpr (k == 0) st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.s[st_]), cb, 0, 0, 0);
+            else st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.s[st_]), st.acc[set], 0, 0, 0);
+            fence();
+            if constexpr (S::bias_at(I)) bias_read<128 * (t + 1)>(braw[set ^ 1], baddr);
+            fence();
+            st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.l[st_]), st.acc[set], 0, 0, 0);
+            fence();
+            st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(al[I % AP]), frag(x.s[st_]), st.acc[set], 0, 0, 0);
+            fence();
+            if constexpr (S::aread_at(I)) {
+                lds_read16<(I + AP) * STEP_BYTES>(ah[I % AP], abase);
+                lds_read16<(I + AP) * STEP_BYTES + FRAG_BYTES>(al[I % AP], abase);
+            }
+            if constexpr (I % PSTEP == 0 && I / PSTEP < npieces) cx.issue_piece(I / PSTEP);
+            if constexpr (t > 0 && k >= 1) {              // the finished tile t-1 -> out[t-1]: this step's share of its conversion ticks
+                constexpr int NSLOT = STEPS - 1, slot = k - 1;
+                constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
+                if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[set ^ 1], out[t - 1], slope, st.ps);
+            } else if constexpr (PEND && t == 0 && k >= 1 && k <= 2 * K0 - 3) {     // the previous layer's last tile -> in0[K0-1]
+                constexpr int NSLOT = 2 * K0 - 3, slot = k - 1;
+                constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
+                if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[1], in0[K0 - 1], pslope, st.ps);
+            }
+            fence();
+        };
+        [&]<int... Is>(std::integer_sequence<int, Is...>) { (step.template operator()<Is>(), ...); }(std::make_integer_sequence<int, TOTAL>{});
+        [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
+            ((Ps >= (TOTAL + PSTEP - 1) / PSTEP && Ps < npieces ? cx.issue_piece(Ps) : (void)0), ...);
+        }(std::make_integer_sequence<int, DMA_PIECES>{});
+        cx.end_chunk();
+    };
+    [&]<int... Cs>(std::integer_sequence<int, Cs...>) { (chunk.template operator()<Cs>(), ...); }(std::make_integer_sequence<int, NCH>{});
+}
+
+// 16-row output layer (ALPHA -> RGB -> SEG into one tile) accumulated in fp32: first = start from the bias, else from the running tile.
+template <int K0, int NEXT_HW>
+__device__ __forceinline__ void dense_x_out(Ctx &cx, St &st, Blk *in0, f32x16 &acc, int bias_off, bool first, float pslope)
+{
+    constexpr int TOTAL = K0 * 2;
+    constexpr int npieces = (NEXT_HW + PIECE_HW - 1) / PIECE_HW;
+    static_assert(TOTAL * STEP_BYTES <= LDS_BUF_BYTES, "chunk does not fit its buffer");
+    cx.begin_chunk(NEXT_HW);
+    const uint32_t abase = cx.cur_addr();
+    if (first) {       // rows 0..15 of the 32-row tile carry the layer's bias (registers 0..7), rows 16..31 are unused
+        const uint32_t baddr = cx.bias_addr + 4u * (uint32_t)bias_off;
+        f32x4 t0, t1;
+        lds_read16<0>(t0, baddr);
+        lds_read16<32>(t1, baddr);
+        wait_lgkm<0>();
+        fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[r] = t0[r]; acc[4 + r] = t1[r]; }
+#pragma unroll
+        for (int r = 8; r < 16; ++r) acc[r] = 0.0f;
+    }
+    u32x4 ah[AP], al[AP];
+    [&]<int... Is>(std::integer_sequence<int, Is...>) {
+        ((lds_read16<Is * STEP_BYTES>(ah[Is], abase), lds_read16<Is * STEP_BYTES + FRAG_BYTES>(al[Is], abase)), ...);
+    }(std::make_integer_sequence<int, (AP < TOTAL ? AP : TOTAL)>{});
+    fence();
+    auto step = [&]<int I>() {
+        wait_lgkm<2 * ((TOTAL - 1 - I) < (AP - 1) ? (TOTAL - 1 - I) : (AP - 1))>();
+        fence();
+        const Blk &x = in0[I >> 1];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.s[I & 1]), acc, 0, 0, 0);
+        fence();
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.l[I & 1]), acc, 0, 0, 0);
+        fence();
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(al[I % AP]), frag(x.s[I & 1]), acc, 0, 0, 0);
+        fence();
+        if constexpr (I + AP < TOTAL) {
+            lds_read16<(I + AP) * STEP_BYTES>(ah[I % AP], abase);
+            lds_read16<(I + AP) * STEP_BYTES + FRAG_BYTES>(al[I % AP], abase);
+        }
+        if constexpr (I < npieces) cx.issue_piece(I);
+        if constexpr (I >= 1 && I <= 2 * K0 - 3) {        // the previous layer's last tile -> in0[K0-1], before step 2 (K0 - 1) reads it
+            constexpr int NSLOT = 2 * K0 - 3, slot = I - 1;
+            constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
+            if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[1], in0[K0 - 1], pslope, st.ps);
+        }
+        fence();
+    };
+    [&]<int... Is>(std::integer_sequence<int, Is...>) { (step.template operator()<Is>(), ...); }(std::make_integer_sequence<int, TOTAL>{});
+    [&]<int... Ps>(std::integer_sequence<int, Ps...>) { ((Ps >= TOTAL && Ps < npieces ? cx.issue_piece(Ps) : (void)0), ...); }(
+        std::make_integer_sequence<int, DMA_PIECES>{});
+    cx.end_chunk();
+}
+
+// ---- positional encoding (v_sin_f32 on an fp32 revolution count reduced exactly: the value keeps ~fp32 accuracy, then hi/lo split) ------
+struct PeSlot { float scale; float phase; int axis; int kind; };   // kind: 0 zero pad, 1 raw input, 2 sinusoid
+template <int D, int L>
+constexpr PeSlot pe_slot(int f)
+{
+    constexpr int W = D + 2 * D * L;
+    if (f >= W) return PeSlot{0.0f, 0.0f, 0, 0};
+    if (f < D) return PeSlot{1.0f, 0.0f, f, 1};
+    const int g = f - D, k = g / (2 * D), rem = g % (2 * D);
+    return PeSlot{(float)(1 << k), (rem / D) ? 0.25f : 0.0f, rem % D, 2};
+}
+// sin(2 pi t) for t = 2^k u + phase with u = x / (2 pi) held as an unevaluated fp32 sum (uh + ul): the product by a power of two and the
+// reduction to [-0.5, 0.5) are exact, so the argument error is that of u (2^-24 relative), not 2^k times it
+__device__ __forceinline__ float sin_rev(float uh, float ul, float scale, float phase)
+{
+    const float a = uh * scale;                     // exact (power of two)
+    const float r = a - rintf(a);                   // exact
+    const float t = (r + phase) + ul * scale;       // |t| < 1: fp32 rounding of a small number
+    return __builtin_amdgcn_sinf(t - rintf(t));     // v_sin_f32 takes revolutions
+}
+template <int D, int L, int NB>
+__device__ __forceinline__ void pe_blocks_x(const float *v, int h, Blk *out)
+{
+    float uh[3], ul[3];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {       // u = v / (2 pi) as hi + lo (two-product with the split constant 1/(2 pi) = C_HI + C_LO)
+        const float C_HI = 0.15915494f, C_LO = 6.4206382e-09f;
+        uh[i] = v[i] * C_HI;
+        ul[i] = fmaf(v[i], C_HI, -uh[i]) + v[i] * C_LO;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f0 = 32 * b + 16 * s + 8 * (j >> 2) + (j & 3);
+                const PeSlot a = pe_slot<D, L>(f0), c = pe_slot<D, L>(f0 + 4);   // lane half 0 / 1
+                if (a.kind == 0 && c.kind == 0) {
+                    r[j] = 0.0f;
+                } else {
+                    const int kind = h ? c.kind : a.kind;
+                    const float sn = sin_rev(h ? uh[c.axis] : uh[a.axis], h ? ul[c.axis] : ul[a.axis], h ? c.scale : a.scale, h ? c.phase : a.phase);
+                    r[j] = (kind == 2) ? sn : ((kind == 1) ? (h ? v[c.axis] : v[a.axis]) : 0.0f);
+                }
+            }
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {
+                uint32_t hi, lo;
+                split_pair(r[2 * jp], r[2 * jp + 1], hi, lo);
+                out[b].s[s][jp] = hi; out[b].l[s][jp] = lo;
+            }
+        }
+}
+
+// trilinear lookup (fp32, ATen corner order, zeros padding); this lane takes channels 16s + 8g + 4h + 0..3
+__device__ __forceinline__ void grid_block_x(const float *__restrict__ grid, float x, float y, float z, int h, Blk &out)
+{
+    const float R1 = (float)(G_RES - 1);
+    const float ix = ((x + 1.0f) / 2.0f) * R1, iy = ((y + 1.0f) / 2.0f) * R1, iz = ((z + 1.0f) / 2.0f) * R1;
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const float wx[2] = {(fx + 1.0f) - ix, ix - fx}, wy[2] = {(fy + 1.0f) - iy, iy - fy}, wz[2] = {(fz + 1.0f) - iz, iz - fz};
+    const bool ok = fx >= -1.0f && fx <= (float)G_RES && fy >= -1.0f && fy <= (float)G_RES && fz >= -1.0f && fz <= (float)G_RES;
+    const int xi = ok ? (int)fx : -2, yi = ok ? (int)fy : -2, zi = ok ? (int)fz : -2;
+    f32x4 a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int cx = xi + (n & 1), cy = yi + ((n >> 1) & 1), cz = zi + (n >> 2);
+        const bool inb = cx >= 0 && cx < G_RES && cy >= 0 && cy < G_RES && cz >= 0 && cz < G_RES;
+        const float wt = (wx[n & 1] * wy[(n >> 1) & 1]) * wz[n >> 2];
+        const long vox = inb ? (((long)cz * G_RES + cy) * G_RES + cx) : 0;
+        const f32x4 *g = reinterpret_cast<const f32x4 *>(grid + vox * D_GRID) + h;
+        const float we = inb ? wt : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 gv = g[2 * k];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[k][r] = a[k][r] + gv[r] * we;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+            const int j = 2 * jp;
+            uint32_t hi, lo;
+            split_pair(a[2 * s + (j >> 2)][j & 3], a[2 * s + (j >> 2)][(j & 3) + 1], hi, lo);
+            out.s[s][jp] = hi; out.l[s][jp] = lo;
+        }
+}
+
+#define CHX(id) (pick_GX(kProgH.layer[id].KB32, kProgH.layer[id].NT32) * kProgH.layer[id].KB32 * 2048)   /* halfwords in one chunk of layer id */
+
+// The radiance nets of `level` on S samples per ray whose (x', w) are xw[ray][src ? src[ray][s] : s] (field_f32.hip, FIELD_RADIANCE).
+__global__ void __launch_bounds__(X_THREADS, 1)
+field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__restrict__ frame, int level, long P, int S,
+                             const float *__restrict__ rays, int ray_stride, float *__restrict__ raw, const float *__restrict__ xw, int xw_row,
+                             const int *__restrict__ src)
+{
+    constexpr uint32_t RAD_OFF = (uint32_t)(2 * kProgH.layer[H_T0].stream_off);
+    extern __shared__ __attribute__((aligned(16))) char lds_x[];
+    Ctx cx;
+    cx.stream = reinterpret_cast<const unsigned short *>(packed + PACKX_STREAM_OFF) + (long)level * STREAM_HWX;
+    cx.lds = lds_x;
+    cx.buf = 0;
+    cx.lane = threadIdx.x & 63;
+    cx.h = cx.lane >> 5;
+    cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float *grid = packed + PACKX_GRID_OFF;
+    const int h = cx.h, col = cx.lane & 31;
+    {
+        const float *bsrc = frame + FRAME_BIAS_OFF + level * BIAS_FLOATS;
+        float *bl = reinterpret_cast<float *>(lds_x + LDS_BIAS_BYTE_OFF);
+        for (int i = threadIdx.x; i < BIAS_FLOATS; i += X_THREADS) bl[i] = bsrc[i];
+        cx.wrap_at = (uint32_t)STREAM_HWX;
+        cx.wrap_to = RAD_OFF;
+        cx.off = RAD_OFF;
+        cx.prepare(CHX(H_T0), 0);
+#pragma unroll
+        for (int pc = 0; pc < (CHX(H_T0) + PIECE_HW - 1) / PIECE_HW; ++pc) cx.issue_piece(pc);
+        __syncthreads();
+    }
+    constexpr const LayerH *Ly = kProgH.layer;
+
+    const long ntiles = (P + X_PTS_PER_WG - 1) / X_PTS_PER_WG;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        cx.refresh_bias_base();
+        asm volatile("" : "+s"(cx.off));      // (chunk addresses are loop-invariant: keep them from being hoisted and spilled)
+        St st;
+        const long p_raw = tile * X_PTS_PER_WG + cx.wave * X_PTS_PER_WAVE + col;
+        const long p = p_raw < P ? p_raw : P - 1;
+        typedef __attribute__((address_space(3))) float *lds_float;
+        const lds_float stash = (lds_float)(__attribute__((address_space(3))) char *)(lds_x + LDS_STASH_BYTE_OFF) + (cx.wave * X_PTS_PER_WAVE + col) * STASH_FLOATS;
+        if (h == 0) {
+            const float *row = xw + ((p / S) * (long)xw_row + (src != nullptr ? src[p] : (int)(p % S))) * 8;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(row);
+            stash[0] = v[0]; stash[1] = v[1]; stash[2] = v[2]; stash[3] = v[3];
+            stash[4] = row[4];
+        }
+        __builtin_amdgcn_wave_barrier();
+        Blk A[8];
+        f32x16 fin;
+        {
+            Blk B[8];
+            {
+                Blk in_tr[3];
+                const float xp[3] = {stash[0], stash[1], stash[2]}, amb[3] = {stash[3], stash[4], 0.0f};
+                pe_blocks_x<3, 10, 2>(xp, h, in_tr);
+                pe_blocks_x<2, 4, 1>(amb, h, in_tr + 2);
+                dense_x<2, 1, 0, 8, CHX(H_T1), false>(cx, st, in_tr, in_tr + 2, nullptr, A, Ly[H_T0].bias_off, 0.01f, 1.0f);
+            }
+            dense_x<8, 0, 0, 8, CHX(H_T2), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T1].bias_off, 0.01f, 0.01f);
+            dense_x<8, 0, 0, 8, CHX(H_T3), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T2].bias_off, 0.01f, 0.01f);
+            {   // the re-injected encoding [PE(x') | PE(w)] is rebuilt at the skip layer instead of staying live
+                Blk in_tr[3];
+                const float xp[3] = {stash[0], stash[1], stash[2]}, amb[3] = {stash[3], stash[4], 0.0f};
+                pe_blocks_x<3, 10, 2>(xp, h, in_tr);
+                pe_blocks_x<2, 4, 1>(amb, h, in_tr + 2);
+                dense_x<8, 2, 1, 8, CHX(H_T4), true>(cx, st, A, in_tr, in_tr + 2, B, Ly[H_T3].bias_off, 0.01f, 0.01f);
+            }
+#pragma unroll 1
+            for (int j = 0; j < 2; ++j) {     // T4, T5 | T6, T7 (identical shapes: one copy of the code, run twice)
+                dense_x<8, 0, 0, 8, CHX(H_T5), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T4].bias_off + 512 * j, 0.01f, 0.01f);
+                dense_x<8, 0, 0, 8, CHX(H_T5), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T4].bias_off + 512 * j + 256, 0.01f, 0.01f);
+            }
+            dense_x<8, 0, 0, 8, CHX(H_ALPHA), true>(cx, st, B, nullptr, nullptr, A, Ly[H_FEAT].bias_off, 1.0f, 0.01f);
+        }
+        dense_x_out<8, CHX(H_D0)>(cx, st, A, fin, Ly[H_ALPHA].bias_off, true, 1.0f);
+        {   // colour branch
+            Blk in_d[2];
+            {
+                const float *rq = rays + (p / S) * ray_stride;
+                const float rdir[3] = {rq[3], rq[4], rq[5]};
+                pe_blocks_x<3, 4, 1>(rdir, h, in_d);
+                grid_block_x(grid, stash[0], stash[1], stash[2], h, in_d[1]);
+            }
+            Blk c[4], cn[4];
+            dense_x<8, 1, 1, 4, CHX(H_D1), false>(cx, st, A, in_d, in_d + 1, c, Ly[H_D0].bias_off, 0.01f, 1.0f);
+            dense_x<4, 0, 0, 4, CHX(H_D1), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D1].bias_off, 0.01f, 0.01f);
+            dense_x<4, 0, 0, 4, CHX(H_D1), true>(cx, st, cn, nullptr, nullptr, c, Ly[H_D1].bias_off + 128, 0.01f, 0.01f);
+            dense_x<4, 0, 0, 4, CHX(H_RGB), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D3].bias_off, 0.01f, 0.01f);
+            dense_x_out<4, CHX(H_S0)>(cx, st, cn, fin, 0, false, 0.01f);
+        }
+        {   // seg branch
+            Blk s[4], sn[4];
+            dense_x<8, 0, 0, 4, CHX(H_S1), false>(cx, st, A, nullptr, nullptr, s, Ly[H_S0].bias_off, 0.01f, 1.0f);
+            dense_x<4, 0, 0, 4, CHX(H_S1), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S1].bias_off, 0.01f, 0.01f);
+            dense_x<4, 0, 0, 4, CHX(H_S1), true>(cx, st, sn, nullptr, nullptr, s, Ly[H_S1].bias_off + 128, 0.01f, 0.01f);
+            dense_x<4, 0, 0, 4, CHX(H_SEG), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S3].bias_off, 0.01f, 0.01f);
+            dense_x_out<4, CHX(H_T0)>(cx, st, sn, fin, 0, false, 0.01f);
+        }
+        if (p_raw < P) {   // rows 4h..4h+3 and 8+4h..8+4h+3 of [rgb3 | seg12 | sigma]
+            *reinterpret_cast<f32x4 *>(raw + p_raw * D_RAW + 4 * h) = f32x4{fin[0], fin[1], fin[2], fin[3]};
+            *reinterpret_cast<f32x4 *>(raw + p_raw * D_RAW + 8 + 4 * h) = f32x4{fin[4], fin[5], fin[6], fin[7]};
+        }
+    }
+}
+
+}  // namespace hx3
+}  // namespace sahs
+
+using namespace sahs;
+using namespace sahs::hx3;
+
+// the radiance launch of the split evaluation (field_f32.hip: sahs_field_forward_f32_split_launch mode 2, same arguments)
+extern "C" int sahs_field_radiance_bf16x3_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays,
+                                                 int ray_stride, float *raw, const float *xw, int xw_row, const int *src, int num_cu,
+                                                 hipStream_t stream)
+{
+    if (P <= 0) return 0;
+    const long ntiles = (P + X_PTS_PER_WG - 1) / X_PTS_PER_WG;
+    const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
+    static sahs_once::Flags attr_set;
+    hipError_t ae = sahs_once::per_device(attr_set, [&]() {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_radiance_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    });
+    if (ae != hipSuccess) return (int)ae;
+    field_radiance_bf16x3_kernel<<<grid, X_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, raw, xw, xw_row, src);
+    return (int)hipGetLastError();
+}

@@ -119,6 +119,53 @@ __global__ void pack_stream_bf16_kernel(const float *__restrict__ flat, float *_
     }
 }
 
+// ---- bf16x3 stream (field_bf16x3.hip): the bf16 stream with every fragment followed by the fragment of the remainders w - bf16(w) ----
+__global__ void pack_stream_bf16x3_kernel(const float *__restrict__ flat, float *__restrict__ packed)
+{
+    using namespace hb;
+    unsigned short *out = reinterpret_cast<unsigned short *>(packed + PACKX_STREAM_OFF);
+    const long total = 2 * STREAM_HW / 8;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long hw = e * 8;                                  // position in the plain bf16 stream
+        const int level = (int)(hw / STREAM_HW);
+        const long sidx = hw - (long)level * STREAM_HW;
+        int li = 0;
+        while (li + 1 < NUM_LAYERS_H && dProgH.layer[li + 1].stream_off <= sidx) ++li;
+        const LayerH &L = dProgH.layer[li];
+        const long w = sidx - L.stream_off;
+        const int per_tile = L.KB32 * 1024;
+        const int t = (int)(w / per_tile);
+        const int rem = (int)(w - (long)t * per_tile);
+        const int b = rem >> 10, st = (rem >> 9) & 1, lane = (rem & 511) >> 3;
+        const int i = lane & 31, h = lane >> 5;
+        const int row = 32 * t + i - L.row_shift;
+        int bb = b, seg = -1;
+        for (int sg = 0; sg < L.nseg; ++sg) {
+            if (bb < L.seg[sg].blocks) { seg = sg; break; }
+            bb -= L.seg[sg].blocks;
+        }
+        unsigned short vh[8], vl[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 32 * bb + 16 * st + 8 * (j >> 2) + 4 * h + (j & 3);
+            float x = 0.0f;
+            if (seg >= 0 && c < L.seg[seg].valid && row >= 0 && row < L.src_rows)
+                x = flat[L.w_off[level] + (long)row * L.src_ld + L.seg[seg].src_col + c];
+            vh[j] = f32_to_bf16_rne(x);
+            vl[j] = f32_to_bf16_rne(x - __builtin_bit_cast(float, (unsigned)vh[j] << 16));
+        }
+        // fragment f = 2b + st of tile t: hi at 2f, lo at 2f + 1 (512 halfwords each) of the doubled tile
+        unsigned short *dst = out + (long)level * 2 * STREAM_HW + 2 * L.stream_off + (long)t * 2 * per_tile + (long)(2 * b + st) * 1024 + lane * 8;
+        uint4 q;
+        q.x = vh[0] | ((unsigned)vh[1] << 16); q.y = vh[2] | ((unsigned)vh[3] << 16);
+        q.z = vh[4] | ((unsigned)vh[5] << 16); q.w = vh[6] | ((unsigned)vh[7] << 16);
+        *reinterpret_cast<uint4 *>(dst) = q;
+        q.x = vl[0] | ((unsigned)vl[1] << 16); q.y = vl[2] | ((unsigned)vl[3] << 16);
+        q.z = vl[4] | ((unsigned)vl[5] << 16); q.w = vl[6] | ((unsigned)vl[7] << 16);
+        *reinterpret_cast<uint4 *>(dst + 512) = q;
+    }
+}
+
 __global__ void pack_table_bf16_kernel(float *__restrict__ packed)
 {
     using namespace hb;
@@ -243,6 +290,15 @@ extern "C" int SAHS_SYM(sahs_pack_weights_bf16_launch)(const float *flat, float 
     pack_table_bf16_kernel<<<1, 64, 0, stream>>>(packed);
     return (int)hipGetLastError();
 }
+
+// [grid fp32 channel-last][hi/lo streams of both levels] for field_bf16x3.hip
+extern "C" int SAHS_SYM(sahs_pack_weights_bf16x3_launch)(const float *flat, float *packed, hipStream_t stream)
+{
+    pack_stream_bf16x3_kernel<<<1024, 256, 0, stream>>>(flat, packed);
+    pack_grid_f32_kernel<<<1024, 256, 0, stream>>>(flat, packed);    // same offset as in the other packs (PACKX_GRID_OFF == 0)
+    return (int)hipGetLastError();
+}
+extern "C" long SAHS_SYM(sahs_layout_packed_words_bf16x3)(void) { return hb::PACKX_WORDS; }
 
 extern "C" int SAHS_SYM(sahs_fold_conditioning_launch)(const float *flat, const float *audio, const float *pose, int pose_ld, float *frame,
                                              hipStream_t stream)

@@ -390,6 +390,11 @@ constexpr long PACKH_GRID_OFF = 0;
 constexpr long PACKH_STREAM_OFF = GRID_FLOATS;                       // words
 constexpr long PACKH_TABLE_OFF = PACKH_STREAM_OFF + STREAM_HW;       // 2 levels * STREAM_HW halfwords = STREAM_HW words
 constexpr long PACKH_WORDS = PACKH_TABLE_OFF + ((NUM_CHUNKS_H + 1 + 3) / 4) * 4;
+// packed (bf16x3, field_bf16x3.hip), in 4-byte words: [grid channel-last fp32][level0 hi/lo stream][level1 hi/lo stream]; a level's stream is the
+// bf16 stream with every 1-KB fragment followed by the fragment of the remainders (layer i at 2 * stream_off[i], 2 * STREAM_HW halfwords)
+constexpr long PACKX_GRID_OFF = 0;
+constexpr long PACKX_STREAM_OFF = GRID_FLOATS;
+constexpr long PACKX_WORDS = PACKX_STREAM_OFF + 2 * STREAM_HW;
 
 }  // namespace hb
 }  // namespace SAHS_NS

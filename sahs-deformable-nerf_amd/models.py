@@ -161,7 +161,7 @@ class _FieldModel(nn.Module):
                 raise NotImplementedError("gradients run through the fp32 path; build the model with precision='fp32'")
             raw = ops.FieldFn.apply(self.flat_params(differentiable=True), driving.to(torch.float32), pose.to(torch.float32), rays, z, packed,
                                     lvl, self.arch)
-        elif self.arch == "nerface" and self.precision == ops.SAHS_BF16:     # mixed precision: fp32 deformation launch, bf16 radiance launch
+        elif ops.is_mixed(self.arch, self.precision):     # mixed precision: fp32 deformation launch, low-precision radiance launch
             xw = torch.empty(P, 1, 8, dtype=torch.float32, device=x.device)
             raw = ops.field_forward_split(packed, self.frame(driving, pose), lvl, ops.FIELD_ALL, rays, xw, z=z, arch=self.arch, precision=self.precision)
         else:

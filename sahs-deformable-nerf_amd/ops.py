@@ -14,9 +14,15 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import SAHS_F32, SAHS_BF16, SAHS_BF16_2W, check
+from ._lib import SAHS_F32, SAHS_BF16, SAHS_BF16_2W, SAHS_BF16X3, check
 
-PRECISIONS = {"fp32": SAHS_F32, "f32": SAHS_F32, "bf16": SAHS_BF16, "bf16_2w": SAHS_BF16_2W}   # bf16_2w: the round-1 kernel, A/B reference
+PRECISIONS = {"fp32": SAHS_F32, "f32": SAHS_F32, "bf16": SAHS_BF16, "bf16_2w": SAHS_BF16_2W,      # bf16_2w: the round-1 kernel, A/B reference
+              "bf16x3": SAHS_BF16X3}    # near-fp32 on the bf16 pipe: radiance nets with hi + lo bf16 operands (3 MFMAs per product), deformation nets fp32
+
+
+def is_mixed(arch, precision):
+    """Precisions that exist as the split chain only (fp32 deformation launches + a low-precision radiance launch, exchanging x', w)."""
+    return (precision == SAHS_BF16 and arch == "nerface") or (precision == SAHS_BF16X3 and arch == "audio")
 
 
 def _p(t):
@@ -210,7 +216,7 @@ def sample_pdf(bins, weights, num_samples, u=None, want_inds=False):
 def render_rays(packed, frame, rays, num_coarse, num_fine, precision=SAHS_F32, lindisp=False, white_background=False, bg=None,
                 t_rand=None, noise_c=None, u=None, noise_f=None, workspace=None, arch="audio"):
     """predict_and_render_radiance for one ray chunk -> the reference's 8-tuple (flat shapes)."""
-    if precision == SAHS_BF16 and arch == "nerface":      # mixed precision exists as the row-writing split chain only
+    if is_mixed(arch, precision):      # mixed precision exists as the row-writing split chain only
         rows = torch.empty(rays.shape[0], ROW_COLUMNS, dtype=torch.float32, device=rays.device)
         render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=precision, lindisp=lindisp, white_background=white_background,
                          bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f, workspace=workspace, arch=arch)
@@ -288,10 +294,10 @@ def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=
     z_c, z_f = buf("z_c", N, num_coarse), buf("z_f", N, Sf)
     raw, weights = buf("raw", N, Sf, 16), buf("weights", N, Sf)
     xw = src = z_new = None
-    mixed = precision == SAHS_BF16 and arch == "nerface"      # fp32 deformation nets + bf16 radiance nets: only the split chain exists
+    mixed = is_mixed(arch, precision)      # fp32 deformation nets + low-precision radiance nets: only the split chain exists
     if mixed and not (share_deformation and num_fine > 0):
-        raise _lib.SahsError("the mixed-precision NeRFaceModel renders through the split chain (share_deformation=True, num_fine > 0)")
-    if share_deformation and num_fine > 0 and arch != "nerface_static" and precision in (SAHS_F32, SAHS_BF16):
+        raise _lib.SahsError("a mixed-precision model renders through the split chain (share_deformation=True, num_fine > 0)")
+    if share_deformation and num_fine > 0 and arch != "nerface_static" and precision in (SAHS_F32, SAHS_BF16, SAHS_BF16X3):
         # extra workspace of the split evaluation: deformed points of every depth, the merge permutation, the new depths
         xw, z_new = buf("xw", N, Sf, 8), buf("z_new", N, num_fine)
         src = ws.get("src")

@@ -110,3 +110,100 @@ def test_bf16_full_frame_psnr(weights_mod):
     assert 0.02 < res["w_bg_mean"] < 0.9, "the volume must be semi-transparent for the protocol to mean anything"
     assert res["delta_psnr"] <= 0.05, res      # north_star: PSNR within 0.05 dB of the reference
     assert res["psnr_bf16_vs_fp32"] > 35.0, res
+
+
+# ---- SAHS_BF16X3: near-fp32 on the bf16 matrix pipe (radiance nets with bf16 hi + lo operands, three MFMAs per product; the
+# deformation nets on the fp32 kernel) -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["boosted", "hdr"])
+def test_bf16x3_field_vs_oracle(flat_weights, variant):
+    """Field seam against the CPU oracle: (x', w) are the fp32 kernel's own (same bounds as the fp32 path); the radiance nets' raw
+    output carries 16-17 significant bits per operand: bounds ~4x the observed error, 500-1000x below plain bf16's."""
+    from conftest import VARIANT_KW
+    ops, lib = pkg("ops"), pkg("_lib")
+    g = load_golden("cond")
+    fw = flat_weights(**VARIANT_KW[variant])
+    flat = T(fw)
+    packed = ops.pack_weights(flat, lib.SAHS_BF16X3)
+    frame = ops.fold_conditioning(flat, T(g["audio"]), T(g["pose"]))
+    rng = np.random.default_rng(11)
+    N, S = 61, 64     # ragged: 3904 samples, not a multiple of the 128-sample tile
+    rays = np.zeros((N, 8), np.float32)
+    rays[:, 0:3] = rng.normal(0, 0.05, (N, 3)) + np.array([0, 0, 0.8])
+    rays[:, 3:6] = rng.normal(0, 0.15, (N, 3)) + np.array([0, 0, -1.0])
+    z = np.sort(rng.uniform(0.48, 1.08, (N, S)).astype(np.float32), axis=1)
+    x6 = np.concatenate([rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None], np.broadcast_to(rays[:, None, 3:6], (N, S, 3))], -1).reshape(-1, 6)
+    drv, p36 = oracle.audionet(fw, g["audio"]), oracle.pose_encoding(g["pose"])
+    stats = {}
+    for level in (0, 1):
+        ref, rdx, rw, _ = oracle.field_forward(fw, level, x6.astype(np.float32), drv, p36, debug=True)
+        xw = torch.zeros(N, S, 8, device=dev())
+        raw = ops.field_forward_split(packed, frame, level, ops.FIELD_ALL, T(rays), xw, z=T(z), precision=lib.SAHS_BF16X3).view(-1, 16).cpu().numpy()
+        xwn = xw.view(-1, 8).cpu().numpy()
+        e_x = np.abs(xwn[:, :3] - (x6[:, :3] + rdx)).max()
+        e_w = np.abs(xwn[:, 3:5] - rw).max()
+        e_col, e_sig = np.abs(raw[:, :15] - ref[:, :15]), np.abs(raw[:, 15] - ref[:, 15])
+        stats[level] = dict(xprime_max=float(e_x), w_max=float(e_w), col_max=float(e_col.max()), col_rms=float(np.sqrt((e_col ** 2).mean())),
+                            col_scale=float(np.sqrt((ref[:, :15] ** 2).mean())), sig_max=float(e_sig.max()),
+                            sig_rms=float(np.sqrt((e_sig ** 2).mean())), sig_scale=float(np.abs(ref[:, 15]).mean()))
+        assert np.isfinite(raw).all()
+    json.dump(stats, open(os.path.join(REPO, "gpurun_out", "bf16x3_field_stats_%s.json" % variant), "w"), indent=1)
+    print(variant, json.dumps(stats))
+    for level in (0, 1):
+        st = stats[level]
+        assert st["xprime_max"] < 2e-6 and st["w_max"] < 2e-6, st                    # fp32 deformation nets
+        assert st["col_rms"] < 6e-5 * max(1.0, st["col_scale"]) and st["sig_rms"] < 6e-5 * max(1.0, st["sig_scale"]), st
+        assert st["col_max"] < 6e-4 * max(1.0, st["col_scale"]) and st["sig_max"] < 6e-4 * max(1.0, st["sig_scale"]), st
+
+
+def test_bf16x3_frame_vs_fp32_within_4x_of_its_tolerance(weights_mod):
+    """End to end (drop-in driver, validation mode, HDR weights): the bf16x3 frame against the fp32 path's on the same rays and draws at
+    FOUR times the fp32 path's tolerance (rtol 4e-4 / atol 4e-5; SURVEY.md section 8d states 1e-4 / 1e-5 for fp32), a few rays excepted
+    in the fine pass (a resampled depth that lands on the other side of a cdf knot -- as between any two fp32 implementations)."""
+    sahs = pkg()
+    d = dev()
+    cfg = sahs.default_config()
+    fw = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 2.0, 30.0, hdr=True))
+    H = W = 48
+    rng = np.random.default_rng(3)
+    audio = T(rng.standard_normal((16, 29)).astype(np.float32))
+    pose = T(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32))
+    intr = np.array([1200.0 * W / 512, 1200.0 * W / 512, 0.5, 0.5], np.float32)
+    bg = T(np.concatenate([rng.uniform(0, 1, (H * W, 3)), np.ones((H * W, 1)), np.zeros((H * W, 11))], 1).astype(np.float32))
+    outs = {}
+    for prec in ("fp32", "bf16x3"):
+        model = sahs.AudioFaceModel(cfg, precision=prec).to(d).load_flat(fw).eval()
+        ro, rd = sahs.get_ray_bundle(H, W, intr, pose)
+        with torch.no_grad(), sahs.train_utils.partition_invariant_rng(7):
+            outs[prec] = sahs.run_one_iter_of_nerf(H, W, intr, model, ro, rd, cfg, mode="validation", driving=audio, pose=pose, background_prior=bg)
+    names = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"]
+    worst = {}
+    for nm, a, b in zip(names, outs["fp32"], outs["bf16x3"]):
+        a, b = a.reshape(H * W, -1), b.reshape(H * W, -1)
+        assert bool(torch.isfinite(b).all()), nm
+        bad = ((a - b).abs() > 4e-5 + 4e-4 * a.abs()).any(dim=1)
+        worst[nm] = (float((a - b).abs().max()), float(bad.float().mean()))
+        # coarse pass: every ray; chained fine pass: the resampled depths differ where a sample sits on a cdf knot (the coarse weights
+        # differ by ~1e-5), which moves a depth by a bin -- those rays are excepted here and pinned below on identical depths
+        assert float(bad.float().mean()) <= (0.0 if nm.endswith("_c") else 0.08), (nm, worst[nm])
+    print(json.dumps({k: v for k, v in worst.items()}))
+    assert float(outs["fp32"][6].mean()) > 0.02          # rays do spread their weight (the frame is not all foreground)
+    assert psnr(outs["fp32"][3][..., :3], outs["bf16x3"][3][..., :3]) >= 60.0
+    # the fine pass on IDENTICAL depths (the fp32 run's): field + compositing, every ray within 4x of the fp32 tolerance
+    ops = pkg("ops")
+    flat = T(fw)
+    frame = ops.fold_conditioning(flat, audio, pose)
+    ro, rd = sahs.get_ray_bundle(H, W, intr, pose)
+    N = H * W
+    rays = torch.cat([ro.reshape(-1, 3), rd.reshape(-1, 3), torch.full((N, 1), float(cfg.dataset.near), device=d),
+                      torch.full((N, 1), float(cfg.dataset.far), device=d)], 1)
+    g = torch.Generator(device=d).manual_seed(5)
+    z_f = torch.sort(torch.rand(N, 128, device=d, generator=g) * 0.6 + 0.4838, dim=1).values
+    res = {}
+    for prec in ("fp32", "bf16x3"):
+        pk = ops.pack_weights(flat, ops.PRECISIONS[prec])
+        xw = torch.zeros(N, 128, 8, device=d)
+        raw = ops.field_forward_split(pk, frame, 1, ops.FIELD_ALL, rays, xw, z=z_f, precision=ops.PRECISIONS[prec])
+        res[prec] = ops.composite_forward(raw, z_f, rays, bg=bg)
+    for nm, a, b in zip(("rgb", "disp", "acc", "weights", "depth"), res["fp32"], res["bf16x3"]):
+        a, b = a.reshape(N, -1), b.reshape(N, -1)
+        assert bool(((a - b).abs() <= 4e-5 + 4e-4 * a.abs()).all()), (nm, float((a - b).abs().max()))
