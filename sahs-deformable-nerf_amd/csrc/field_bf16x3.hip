@@ -249,13 +249,30 @@ __device__ __forceinline__ void dense_x(Ctx &cx, St &st, Blk *in0, const Blk *in
             fence();
             f32x16 cb;
             if constexpr (k == 0) cb = bias_as_c(braw[set]);
-            // W x ~= W_hi x_hi + W_hi x_lo + W_lo x_hi: one accumulation chain (back-to-back MFMAs on one accumulator run at the pipe's rate)
+            // this step's share of the conversion ticks, dealt over its THREE MFMA gaps (a gap hides ~6 VALU instructions, not more):
+            // the finished tile t-1 -> out[t-1] over steps 1..STEPS-1, or the previous layer's last tile -> in0[K0-1] over steps 1..2K0-3
+            auto ticks = [&]<int J>() {
+                if constexpr (t > 0 && k >= 1) {
+                    constexpr int NSLOT = 3 * (STEPS - 1), slot = 3 * (k - 1) + J;
+                    constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
+                    if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[set ^ 1], out[t - 1], slope, st.ps);
+                } else if constexpr (PEND && t == 0 && k >= 1 && k <= 2 * K0 - 3) {
+                    constexpr int NSLOT = 3 * (2 * K0 - 3), slot = 3 * (k - 1) + J;
+                    constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
+                    if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[1], in0[K0 - 1], pslope, st.ps);
+                }
+            };
+            // W x ~= W_hi x_hi + W_hi x_lo + W_lo x_hi on ONE accumulator: back-to-back dependent MFMAs of this shape run at the pipe's rate
+            // (three separate accumulation chains were measured: 59.6 against 56.8 ms per fine launch -- slower, not faster)
             if constexpr (k == 0) st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.s[st_]), cb, 0, 0, 0);
             else st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.s[st_]), st.acc[set], 0, 0, 0);
             fence();
             if constexpr (S::bias_at(I)) bias_read<128 * (t + 1)>(braw[set ^ 1], baddr);
+            ticks.template operator()<0>();
             fence();
             st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.l[st_]), st.acc[set], 0, 0, 0);
+            fence();
+            ticks.template operator()<1>();
             fence();
             st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(al[I % AP]), frag(x.s[st_]), st.acc[set], 0, 0, 0);
             fence();
@@ -264,15 +281,7 @@ __device__ __forceinline__ void dense_x(Ctx &cx, St &st, Blk *in0, const Blk *in
                 lds_read16<(I + AP) * STEP_BYTES + FRAG_BYTES>(al[I % AP], abase);
             }
             if constexpr (I % PSTEP == 0 && I / PSTEP < npieces) cx.issue_piece(I / PSTEP);
-            if constexpr (t > 0 && k >= 1) {              // the finished tile t-1 -> out[t-1]: this step's share of its conversion ticks
-                constexpr int NSLOT = STEPS - 1, slot = k - 1;
-                constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
-                if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[set ^ 1], out[t - 1], slope, st.ps);
-            } else if constexpr (PEND && t == 0 && k >= 1 && k <= 2 * K0 - 3) {     // the previous layer's last tile -> in0[K0-1]
-                constexpr int NSLOT = 2 * K0 - 3, slot = k - 1;
-                constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
-                if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[1], in0[K0 - 1], pslope, st.ps);
-            }
+            ticks.template operator()<2>();
             fence();
         };
         [&]<int... Is>(std::integer_sequence<int, Is...>) { (step.template operator()<Is>(), ...); }(std::make_integer_sequence<int, TOTAL>{});
@@ -314,9 +323,20 @@ __device__ __forceinline__ void dense_x_out(Ctx &cx, St &st, Blk *in0, f32x16 &a
         wait_lgkm<2 * ((TOTAL - 1 - I) < (AP - 1) ? (TOTAL - 1 - I) : (AP - 1))>();
         fence();
         const Blk &x = in0[I >> 1];
+        auto ticks = [&]<int J>() {      // the previous layer's last tile -> in0[K0-1], before step 2 (K0 - 1) reads it
+            if constexpr (I >= 1 && I <= 2 * K0 - 3) {
+                constexpr int NSLOT = 3 * (2 * K0 - 3), slot = 3 * (I - 1) + J;
+                constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
+                if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[1], in0[K0 - 1], pslope, st.ps);
+            }
+        };
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.s[I & 1]), acc, 0, 0, 0);
         fence();
+        ticks.template operator()<0>();
+        fence();
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.l[I & 1]), acc, 0, 0, 0);
+        fence();
+        ticks.template operator()<1>();
         fence();
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(al[I % AP]), frag(x.s[I & 1]), acc, 0, 0, 0);
         fence();
@@ -325,11 +345,7 @@ __device__ __forceinline__ void dense_x_out(Ctx &cx, St &st, Blk *in0, f32x16 &a
             lds_read16<(I + AP) * STEP_BYTES + FRAG_BYTES>(al[I % AP], abase);
         }
         if constexpr (I < npieces) cx.issue_piece(I);
-        if constexpr (I >= 1 && I <= 2 * K0 - 3) {        // the previous layer's last tile -> in0[K0-1], before step 2 (K0 - 1) reads it
-            constexpr int NSLOT = 2 * K0 - 3, slot = I - 1;
-            constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
-            if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[1], in0[K0 - 1], pslope, st.ps);
-        }
+        ticks.template operator()<2>();
         fence();
     };
     [&]<int... Is>(std::integer_sequence<int, Is...>) { (step.template operator()<Is>(), ...); }(std::make_integer_sequence<int, TOTAL>{});
