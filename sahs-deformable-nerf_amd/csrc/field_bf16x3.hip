@@ -98,13 +98,19 @@ struct Ctx {
     }
     __device__ __forceinline__ void issue_piece(int p)
     {
+#ifndef SAHS_X3_NODMA           // timing-only experiments (tools/ablate.py x3*): results wrong by construction
         const int base = p * X_THREADS + wave * WAVE;
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(nx_src + base), (lds_ptr_t)(nx_dst + base), 16, 0, 0);
+#endif
     }
     __device__ __forceinline__ void begin_chunk(int next_hw) { prepare(next_hw, buf ^ 1); }
     __device__ __forceinline__ void end_chunk()
     {
+#ifdef SAHS_X3_NOBARRIER
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         __syncthreads();            // vmcnt(0) (the next chunk has landed) + barrier (every wave is done with this one)
+#endif
         buf ^= 1;
     }
     __device__ __forceinline__ uint32_t cur_addr() const { return lds_addr_of(lds + buf * LDS_BUF_BYTES) + 16 * lane; }
@@ -276,10 +282,12 @@ __device__ __forceinline__ void dense_x(Ctx &cx, St &st, Blk *in0, const Blk *in
             fence();
             st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(al[I % AP]), frag(x.s[st_]), st.acc[set], 0, 0, 0);
             fence();
+#ifndef SAHS_X3_NOAREAD
             if constexpr (S::aread_at(I)) {
                 lds_read16<(I + AP) * STEP_BYTES>(ah[I % AP], abase);
                 lds_read16<(I + AP) * STEP_BYTES + FRAG_BYTES>(al[I % AP], abase);
             }
+#endif
             if constexpr (I % PSTEP == 0 && I / PSTEP < npieces) cx.issue_piece(I / PSTEP);
             ticks.template operator()<2>();
             fence();

@@ -21,6 +21,7 @@ VARIANTS = {"base": [],  "nope": ["SAHS_ABLATE_NOPE"], "nobarrier": ["SAHS_ABLAT
             #  wall-time ablations of this kernel also move the clock the chip holds: use tools/stamp_bf16w.py, which counts cycles)
             "wnopack": ["SAHS_ABLATE_NOPACK"], "wagpr": ["SAHS_NOTHING"], "wnodma": ["SAHS_ABLATE_NODMA"],
             "wfp32relu": ["SAHS_BF16W_FP32_RELU"], "wpkmul": ["SAHS_BF16W_PKMUL"],
+            "x3nodma": ["SAHS_X3_NODMA"], "x3nobar": ["SAHS_X3_NOBARRIER"], "x3noaread": ["SAHS_X3_NOAREAD"], "x3floor": ["SAHS_X3_NODMA", "SAHS_X3_NOBARRIER", "SAHS_X3_NOAREAD"],
             "w4": ["SAHS_BF16_WAVES=4"], "w4apf6": ["SAHS_BF16_WAVES=4", "SAHS_BF16_APF=6"]}
 
 
@@ -54,12 +55,19 @@ def time_one(precision, libpath=None, N=131072, S=128):
     rays[:, 3:6] = torch.randn(N, 3, device=dev) * 0.15 + torch.tensor([0, 0, -1.0], device=dev)
     z = torch.sort(torch.rand(N, S, device=dev) * 0.6 + 0.48, dim=1).values
     raw = torch.empty(N, S, 16, device=dev)
+    if precision == "bf16x3":       # the radiance launch of the split chain alone (x', w from a deformation launch)
+        xw = torch.zeros(N, S, 8, device=dev)
+        pkg.ops.field_forward_split(packed, frame, 1, pkg.ops.FIELD_DEFORM, rays, xw, z=z, precision=prec)
+        src = torch.arange(S, device=dev, dtype=torch.int32).repeat(N, 1).contiguous()
+        run = lambda: pkg.ops.field_forward_split(packed, frame, 1, pkg.ops.FIELD_RADIANCE, rays, xw, src=src, out=raw, precision=prec)
+    else:
+        run = lambda: pkg.ops.field_forward(packed, frame, 1, rays, z, precision=prec, out=raw)
     for _ in range(2):
-        pkg.ops.field_forward(packed, frame, 1, rays, z, precision=prec, out=raw)
+        run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        pkg.ops.field_forward(packed, frame, 1, rays, z, precision=prec, out=raw)
+        run()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
