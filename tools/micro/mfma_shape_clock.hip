@@ -1,5 +1,5 @@
-// Micro-benchmark 3: which bf16 MFMA shape sustains more FLOP/s on THIS chip under a realistic operand stream (random data, A operand
-// re-read from LDS every step, one wave per SIMD)?  v_mfma_f32_32x32x16_bf16 (what field_bf16w.hip uses) against
+// Micro-benchmark 3: which bf16 MFMA shape sustains more FLOP/s on THIS chip (random operands held in registers, one wave per SIMD,
+// every CU busy)?  v_mfma_f32_32x32x16_bf16 (what field_bf16w.hip uses) against
 // v_mfma_f32_16x16x32_bf16 (MI355X_MICROARCH.md: ~1.15x the sustained clock).  Same FLOPs per loop iteration in both kernels.
 //   hipcc --offload-arch=gfx950 -O3 -o mfma_shape_clock mfma_shape_clock.hip && ./mfma_shape_clock
 #include <hip/hip_runtime.h>
@@ -9,7 +9,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// 32x32x16: 8 MFMAs per iteration on 2 accumulators (2 x 16 regs), A fragment from LDS per MFMA
+// 32x32x16: 8 MFMAs per iteration on 2 accumulators (2 x 16 regs)
 __global__ void __launch_bounds__(256, 1) k32(const bf16x8 *__restrict__ g, float *out, int iters, unsigned long long *cyc, unsigned long long *rt)
 {
     __shared__ bf16x8 lds[8 * 64];
@@ -17,12 +17,15 @@ __global__ void __launch_bounds__(256, 1) k32(const bf16x8 *__restrict__ g, floa
     __syncthreads();
     const int lane = threadIdx.x & 63;
     bf16x8 b0 = g[512 + threadIdx.x], b1 = g[768 + threadIdx.x];
+    bf16x8 av[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) av[u] = lds[u * 64 + lane];
     f32x16 acc0 = {}, acc1 = {};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const bf16x8 a = lds[u * 64 + lane];
+            const bf16x8 a = av[u];
             if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
             else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
         }
@@ -32,7 +35,7 @@ __global__ void __launch_bounds__(256, 1) k32(const bf16x8 *__restrict__ g, floa
     if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; rt[blockIdx.x] = r1 - r0; }
 }
 
-// 16x16x32: 16 MFMAs per iteration (same FLOPs: 16 x 16384 = 8 x 32768) on 8 accumulators (8 x 4 regs)
+// 16x16x32: 16 MFMAs per iteration (same FLOPs: 16 x 16384 = 8 x 32768) on 16 accumulators (16 x 4 regs)
 __global__ void __launch_bounds__(256, 1) k16(const bf16x8 *__restrict__ g, float *out, int iters, unsigned long long *cyc, unsigned long long *rt)
 {
     __shared__ bf16x8 lds[8 * 64];
@@ -40,22 +43,25 @@ __global__ void __launch_bounds__(256, 1) k16(const bf16x8 *__restrict__ g, floa
     __syncthreads();
     const int lane = threadIdx.x & 63;
     bf16x8 b0 = g[512 + threadIdx.x], b1 = g[768 + threadIdx.x];
-    f32x4 acc[8];
+    bf16x8 av[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    for (int u = 0; u < 8; ++u) av[u] = lds[u * 64 + lane];
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const bf16x8 a = lds[u * 64 + lane];
-            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[u], 0, 0, 0);
-            acc[(u + 4) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[(u + 4) & 7], 0, 0, 0);
+            const bf16x8 a = av[u];
+            acc[2 * u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc[2 * u], 0, 0, 0);
+            acc[2 * u + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc[2 * u + 1], 0, 0, 0);
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0];
+    for (int i = 0; i < 16; ++i) s += acc[i][0];
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; rt[blockIdx.x] = r1 - r0; }
 }
