@@ -220,7 +220,12 @@ __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float
     if constexpr (T - DB >= 0 && T - DB < NV) {             // B(T-1)
         constexpr int U = T - DB, P = U >> 1, hh = P % NH, q = P / NH, e = U & 1;
         const float v = acc[hh][2 * q + e];
+#if defined(SAHS_X_MAX_UNUSED) && SAHS_MODEL == 0      // timing experiment (wrong results): the multiply and max are issued, the convert takes the raw value
+        { float dmy = fmaxf(v, ps.m2[P & 1][e]); asm volatile("" :: "v"(dmy)); }
+        ps.r[U & 3] = v;
+#else
         ps.r[U & 3] = slope == 1.0f ? v : (slope == 0.0f ? fmaxf(v, 0.0f) : fmaxf(v, ps.m2[P & 1][e]));
+#endif
     }
     if constexpr (T - DC >= 1 && T - DC < NV && ((T - DC) & 1)) {    // C(T-2): the pair (T-3, T-2) is complete
         constexpr int U = T - DC, P = U >> 1, hh = P % NH, q = P / NH, s = q >> 2, jp = q & 3;
