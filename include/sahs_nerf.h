@@ -29,6 +29,7 @@ extern "C" {
 #define SAHS_BF16 1
 #define SAHS_BF16X3 3    /* near-fp32 on the bf16 pipe (AudioFaceModel, split chain only): operands split into bf16 hi + lo, three MFMAs per product,
                           * fp32 accumulate, for the RADIANCE nets; the deformation nets run on the fp32 kernel (mixed, like SAHS_MODEL_NERFACE + SAHS_BF16) */
+#define SAHS_BF16_Q 4     /* SAHS_BF16's arithmetic on v_mfma_f32_16x16x32_bf16 (field_bf16q.hip; AudioFaceModel): the shape holds a higher clock */
 #define SAHS_BF16_2W 2   /* the same arithmetic and packed stream as SAHS_BF16 through the earlier 2-waves-per-SIMD kernel (A/B reference) */
 
 int sahs_abi_version(void);

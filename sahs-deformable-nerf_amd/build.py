@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsahs_nerf.so")
-SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "field_f32.hip", "field_bf16.hip", "field_bf16w.hip", "field_bf16x3.hip", "field_bwd.hip", "train_bwd.hip"]
+SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "field_f32.hip", "field_bf16.hip", "field_bf16w.hip", "field_bf16x3.hip", "field_bf16q.hip", "field_bwd.hip", "train_bwd.hip"]
 # sources built again for the NeRFaceModel architectures (csrc/sahs_model.hpp: -DSAHS_MODEL=1 / 2, symbols suffixed _nf / _ns)
 MODEL_SOURCES = ["pack.hip", "field_f32.hip", "field_bwd.hip"]
 MODEL1_SOURCES = ["field_bf16w.hip"]      # NeRFaceModel: the bf16 radiance nets (with deformation nets: those stay fp32; without: the whole net)
@@ -25,7 +25,8 @@ NO_SCRATCH = {"gemm_dma_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb0E": 0
 # field_bf16w.hip (one wave per SIMD, 512 registers): MFMA accumulators must live in ARCH VGPRs.  Left to its heuristics the compiler
 # puts them in AGPRs, and every accumulator value the activation code touches then costs a v_accvgpr_read -- which, unlike plain VALU
 # work, does NOT hide under the wave's own MFMAs (tools/micro/mfma_valu_overlap.hip: 2 reads per MFMA = 55 cycles per MFMA instead of 36).
-PER_FILE_FLAGS = {"field_bf16w.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "field_bf16x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+PER_FILE_FLAGS = {"field_bf16w.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "field_bf16x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+                  "field_bf16q.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-fno-math-errno", "-Wall", "-Wno-unused-function"]
 
 

@@ -79,6 +79,11 @@ int sahs_pack_weights_bf16_launch_nf(const float *flat, float *packed, hipStream
 int sahs_field_forward_bf16w_split_launch_nf(const float *packed, const float *frame, int level, int mode, long P, int S, const float *rays,
                                              int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
                                              int num_cu, hipStream_t stream);
+// AudioFaceModel, SAHS_BF16_Q: the bf16 kernel on the 16x16x32 MFMA shape (field_bf16q.hip)
+int sahs_pack_weights_bf16q_launch(const float *flat, float *packed, hipStream_t stream);
+int sahs_field_forward_bf16q_split_launch(const float *packed, const float *frame, int level, int mode, long P, int S, const float *rays,
+                                          int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
+                                          int num_cu, hipStream_t stream);
 // AudioFaceModel, SAHS_BF16X3: the radiance nets with operands split into bf16 hi + lo (field_bf16x3.hip); deformation nets fp32
 long sahs_layout_packed_words_bf16x3(void);
 int sahs_pack_weights_bf16x3_launch(const float *flat, float *packed, hipStream_t stream);
@@ -128,6 +133,7 @@ long sahs_param_count(void) { return kFlat.total; }
 long sahs_packed_words(int precision)
 {
     if (precision == SAHS_BF16X3) return sahs_layout_packed_words_bf16x3() + PACK_FLOATS;     // [hi/lo radiance streams | fp32 pack (deformation nets)]
+    if (precision == SAHS_BF16_Q) return hb::PACKH_WORDS;
     return precision == SAHS_F32 ? PACK_FLOATS : ((precision == SAHS_BF16 || precision == SAHS_BF16_2W) ? hb::PACKH_WORDS : -1);
 }
 long sahs_frame_words(void) { return FRAME_FLOATS; }
@@ -136,6 +142,10 @@ int sahs_pack_weights(const float *flat_params, void *packed, int precision, voi
 {
     REQUIRE(flat_params && packed, "sahs_pack_weights");
     REQUIRE(ALIGNED16(packed), "sahs_pack_weights(packed alignment)");
+    if (precision == SAHS_BF16_Q) {
+        int e = sahs_pack_weights_bf16q_launch(flat_params, (float *)packed, (hipStream_t)stream);
+        return e ? hip_fail("sahs_pack_weights", e) : 0;
+    }
     if (precision == SAHS_BF16X3) {
         int e = sahs_pack_weights_bf16x3_launch(flat_params, (float *)packed, (hipStream_t)stream);
         if (!e) e = sahs_pack_weights_f32_launch(flat_params, (float *)packed + sahs_layout_packed_words_bf16x3(), (hipStream_t)stream);
@@ -185,6 +195,12 @@ int sahs_field_forward(const void *packed, const float *frame, int level, long N
     REQUIRE(packed && frame && rays && z && raw, "sahs_field_forward");
     REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_field_forward(shape)");
     REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_field_forward(alignment)");
+    if (precision == SAHS_BF16_Q) {
+        REQUIRE(dbg == nullptr, "sahs_field_forward(SAHS_BF16_Q has no debug outputs)");
+        int e = sahs_field_forward_bf16q_split_launch((const float *)packed, frame, level, 0, N * S, S, rays, ray_stride, z, raw, nullptr, 0, 0, nullptr,
+                                                      num_cus(), (hipStream_t)stream);
+        return e ? hip_fail("sahs_field_forward", e) : 0;
+    }
     if (precision == SAHS_BF16X3)
         return fail(2, "sahs_field_forward: SAHS_BF16X3 runs through sahs_model_field_forward_split / sahs_model_render_rays_rows (it needs the xw "
                        "workspace)%s%ld", "", 0L);
@@ -389,7 +405,8 @@ long sahs_model_packed_words(int model, int precision)
 }
 long sahs_model_executed_macs_part(int model, int precision, int part)
 {
-    if (model < 0 || model > 2 || precision < SAHS_F32 || precision > SAHS_BF16X3 || part < 0 || part > 2) return -1;
+    if (model < 0 || model > 2 || precision < SAHS_F32 || precision > SAHS_BF16_Q || part < 0 || part > 2) return -1;
+    if (precision == SAHS_BF16_Q) precision = SAHS_BF16;      // the same MFMA work on another shape
     if (precision == SAHS_BF16X3)       // fp32 deformation nets + three bf16 MFMAs per product of the radiance nets
         return model != SAHS_MODEL_AUDIO ? -1 : (part != 2 ? sahs_layout_executed_macs(SAHS_F32, 1) : 0) + (part != 1 ? 3 * sahs_layout_executed_macs(SAHS_BF16, 2) : 0);
     if (model == SAHS_MODEL_NERFACE_STATIC && part != 0) return part == 2 ? sahs_layout_executed_macs_ns(precision == SAHS_F32 ? SAHS_F32 : SAHS_BF16, 0) : 0;
@@ -530,6 +547,11 @@ int sahs_model_field_forward_split(int model, const void *packed, const float *f
                                                               mode == 2 ? src : nullptr, num_cus(), (hipStream_t)stream);
         return e ? hip_fail("sahs_model_field_forward_split", e) : 0;
     }
+    if (precision == SAHS_BF16_Q && model == SAHS_MODEL_AUDIO) {
+        int e = sahs_field_forward_bf16q_split_launch((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0, src,
+                                                      num_cus(), (hipStream_t)stream);
+        return e ? hip_fail("sahs_model_field_forward_split", e) : 0;
+    }
     if (precision != SAHS_F32 && !(precision == SAHS_BF16 && model == SAHS_MODEL_AUDIO))
         return fail(4, "sahs_model_field_forward_split: precision %s%ld is not built for this model", "", (long)precision);
     int e = precision == SAHS_BF16
@@ -637,7 +659,8 @@ int sahs_model_render_rays_rows(int model, const void *packed, const float *fram
         REQUIRE(xw && src && z_new && nf > 0, "sahs_model_render_rays_rows(a mixed-precision model needs the xw / src / z_new workspace and nf > 0)");
         REQUIRE(precision != SAHS_BF16X3 || model == SAHS_MODEL_AUDIO, "sahs_model_render_rays_rows(SAHS_BF16X3 is built for SAHS_MODEL_AUDIO)");
     }
-    if (xw && src && z_new && nf > 0 && model != SAHS_MODEL_NERFACE_STATIC && (precision == SAHS_F32 || precision == SAHS_BF16 || precision == SAHS_BF16X3)) {
+    if (xw && src && z_new && nf > 0 && model != SAHS_MODEL_NERFACE_STATIC &&
+        (precision == SAHS_F32 || precision == SAHS_BF16 || precision == SAHS_BF16X3 || (precision == SAHS_BF16_Q && model == SAHS_MODEL_AUDIO))) {
         // the deformation nets are shared by the two levels and the fine depths contain the coarse ones: evaluate them once per depth
         const char *who = "sahs_model_render_rays_rows";
         REQUIRE(packed && frame && rays && z_c && z_f && raw && weights && Sc + nf <= 256, who);

@@ -273,6 +273,11 @@ __device__ __forceinline__ void dense_q_out(Ctx &cx, St &st, Blk *in0, f32x4 (&a
     auto step = [&]<int I>() {
         wait_lgkm<((TOTAL - 1 - I) < (AP - 1) ? (TOTAL - 1 - I) : (AP - 1))>();
         fence();
+        // An odd step's fragment (row tile 1: zero rows) feeds no MFMA -- but its read WAS issued, and a destination the compiler
+        // believes dead is handed out again while the LDS data is still on its way (found on the ISA: a DMA address computed into
+        // those registers two instructions after the ds_read, then overwritten by the landing data: garbage addresses, a memory
+        // fault).  This use, placed after the wait that retires the read, keeps the registers reserved until the data has landed.
+        if constexpr ((I & 1) == 1) asm volatile("" :: "v"(a[I % AP]));
         for_quarters([&](auto Q) {
             constexpr int qq = decltype(Q)::value;
             if constexpr ((I & 1) == 0) {

@@ -14,9 +14,10 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import SAHS_F32, SAHS_BF16, SAHS_BF16_2W, SAHS_BF16X3, check
+from ._lib import SAHS_F32, SAHS_BF16, SAHS_BF16_2W, SAHS_BF16X3, SAHS_BF16_Q, check
 
 PRECISIONS = {"fp32": SAHS_F32, "f32": SAHS_F32, "bf16": SAHS_BF16, "bf16_2w": SAHS_BF16_2W,      # bf16_2w: the round-1 kernel, A/B reference
+              "bf16q": SAHS_BF16_Q,     # bf16 on the 16x16x32 MFMA shape (the shape holds a higher clock under load)
               "bf16x3": SAHS_BF16X3}    # near-fp32 on the bf16 pipe: radiance nets with hi + lo bf16 operands (3 MFMAs per product), deformation nets fp32
 
 
@@ -297,7 +298,7 @@ def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=
     mixed = is_mixed(arch, precision)      # fp32 deformation nets + low-precision radiance nets: only the split chain exists
     if mixed and not (share_deformation and num_fine > 0):
         raise _lib.SahsError("a mixed-precision model renders through the split chain (share_deformation=True, num_fine > 0)")
-    if share_deformation and num_fine > 0 and arch != "nerface_static" and precision in (SAHS_F32, SAHS_BF16, SAHS_BF16X3):
+    if share_deformation and num_fine > 0 and arch != "nerface_static" and precision in (SAHS_F32, SAHS_BF16, SAHS_BF16X3, SAHS_BF16_Q):
         # extra workspace of the split evaluation: deformed points of every depth, the merge permutation, the new depths
         xw, z_new = buf("xw", N, Sf, 8), buf("z_new", N, num_fine)
         src = ws.get("src")

@@ -207,3 +207,37 @@ def test_bf16x3_frame_vs_fp32_within_4x_of_its_tolerance(weights_mod):
     for nm, a, b in zip(("rgb", "disp", "acc", "weights", "depth"), res["fp32"], res["bf16x3"]):
         a, b = a.reshape(N, -1), b.reshape(N, -1)
         assert bool(((a - b).abs() <= 4e-5 + 4e-4 * a.abs()).all()), (nm, float((a - b).abs().max()))
+
+
+def test_bf16q_matches_bf16_kernel(weights_mod):
+    """precision "bf16q" (the bf16 field kernel on v_mfma_f32_16x16x32_bf16, field_bf16q.hip) against the shipped bf16 kernel: same
+    products and roundings in another summation order -- the deformation outputs agree to fp32 rounding of the accumulations amplified by
+    bf16 re-rounding, the raw output to bf16 level; deterministic; whole-network entry point == split chain; the radiance launch follows a
+    merge permutation.  One workgroup first (a new kernel meets the GPU on a tiny case), then several, then a ragged size."""
+    ops = pkg("ops")
+    d = dev()
+    flat = T(weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 2.0, 30.0, hdr=True)))
+    rng = np.random.default_rng(0)
+    frame = ops.fold_conditioning(flat, T(rng.standard_normal((16, 29)).astype(np.float32)),
+                                  T(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32)))
+    packs = {k: ops.pack_weights(flat, ops.PRECISIONS[k]) for k in ("fp32", "bf16", "bf16q")}
+    for N, S in ((2, 64), (37, 128), (301, 77)):
+        g = torch.Generator(device=d).manual_seed(N * 1000 + S)
+        rays = torch.zeros(N, 8, device=d)
+        rays[:, 2] = 0.8
+        rays[:, 3:6] = torch.randn(N, 3, device=d, generator=g) * 0.15 + torch.tensor([0, 0, -1.0], device=d)
+        z = torch.sort(torch.rand(N, S, device=d, generator=g) * 0.6 + 0.48, dim=1).values
+        out, xws = {}, {}
+        for k in ("fp32", "bf16", "bf16q"):
+            xw = torch.zeros(N, S, 8, device=d)
+            out[k] = ops.field_forward_split(packs[k], frame, 1, ops.FIELD_ALL, rays, xw, z=z, precision=ops.PRECISIONS[k])
+            xws[k] = xw
+        assert bool(torch.isfinite(out["bf16q"]).all())
+        err_w, err_q = (out["bf16"] - out["fp32"]).abs(), (out["bf16q"] - out["fp32"]).abs()
+        assert float(err_q.max()) <= 1.5 * float(err_w.max()) + 1e-3 and float((err_q ** 2).mean().sqrt()) <= 1.3 * float((err_w ** 2).mean().sqrt()) + 1e-4
+        assert float((xws["bf16q"] - xws["fp32"]).abs().max()) <= 1.5 * float((xws["bf16"] - xws["fp32"]).abs().max()) + 1e-4
+        plain = ops.field_forward(packs["bf16q"], frame, 1, rays, z, precision=ops.PRECISIONS["bf16q"])
+        assert torch.equal(plain, out["bf16q"])                       # deterministic, and the plain entry point is the split chain's launch
+        src = torch.arange(S - 1, -1, -1, device=d, dtype=torch.int32).repeat(N, 1).contiguous()
+        rad = ops.field_forward_split(packs["bf16q"], frame, 1, ops.FIELD_RADIANCE, rays, xws["bf16q"], src=src, precision=ops.PRECISIONS["bf16q"])
+        assert torch.equal(rad, out["bf16q"].flip(1))
