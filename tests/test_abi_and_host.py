@@ -277,3 +277,29 @@ def test_host_helpers_vs_reference_vectors():
     ii, jj = H.meshgrid_xy(torch.arange(3.0), torch.arange(2.0))
     assert ii.shape == (2, 3) and torch.equal(ii[0], torch.arange(3.0)) and torch.equal(jj[:, 0], torch.arange(2.0))
     assert float(H.img2mse(torch.zeros(4), torch.ones(4))) == 1.0
+
+
+def test_hand_issued_lds_reads_are_not_touched_in_flight(tmp_path):
+    """The bf16 kernels read their A fragments and bias rows with `asm volatile ds_read_b128` far ahead of a counted `s_waitcnt lgkmcnt`: the
+    compiler does not know the data is still on its way, so a destination it believes dead is handed out again and later overwritten by
+    the landing data (the first 16x16x32 port faulted that way: DESIGN.md section 3.1b).  Static check on the ISA of every such kernel,
+    compiled here with the product's flags (no GPU): no instruction reads or overwrites a read's destination before a wait."""
+    import importlib
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    chk = importlib.import_module("check_lds_inflight")
+    b = importlib.import_module("sahs-deformable-nerf_amd.build")
+    jobs = [("field_bf16w.hip", 0, "field_forward_bf16w_kernel"), ("field_bf16w.hip", 1, "field_forward_bf16w_kernel"),
+            ("field_bf16w.hip", 2, "field_forward_bf16w_kernel"), ("field_bf16x3.hip", 0, "field_radiance_bf16x3_kernel"),
+            ("field_bf16q.hip", 0, "field_forward_bf16q_kernel")]
+    procs = []
+    for src, model, pat in jobs:
+        out = str(tmp_path / ("%s.m%d.s" % (src, model)))
+        cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + b.FLAGS + b.FIELD_FLAGS + b.PER_FILE_FLAGS.get(src, []) + \
+              (["-DSAHS_MODEL=%d" % model] if model else []) + ["--cuda-device-only", "-S", os.path.join(b.CSRC, src), "-o", out]
+        procs.append((src, model, pat, out, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
+    for src, model, pat, out, p in procs:
+        assert p.wait() == 0, (src, model)
+        total, bad = chk.check(open(out).read(), pat)
+        assert total > 500 and not bad, (src, model, total, bad[:3])
