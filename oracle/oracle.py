@@ -154,6 +154,21 @@ def composite(raw, z, rd, noise=None, bg=None, white_background=False):
     return rgb, disp, acc, wts, depth
 
 
+def aten_sum(x):
+    """torch.sum of a 1-D fp32 row in ATen's CPU summation order (sahs_oracle.c: aten_sum_f32)."""
+    x = _c(x)
+    f = lib().oracle_aten_sum_f32
+    f.restype = ctypes.c_float
+    return np.float32(f(_f(x), ctypes.c_int(x.size)))
+
+
+def linspace01(n):
+    """torch.linspace(0, 1, n), bit for bit (sahs_oracle.c: aten_linspace01)."""
+    out = np.empty(n, np.float32)
+    lib().oracle_linspace01(ctypes.c_int(n), _f(out))
+    return out
+
+
 def sample_pdf_2(bins, weights, num_samples, u=None):
     """nerf_helpers.py:454-497; u=None is det=True. Returns (samples, inds)."""
     bins, weights, u = _c(bins), _c(weights), _c(u)

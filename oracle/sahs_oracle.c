@@ -538,15 +538,26 @@ void oracle_ray_uniforms(uint64_t seed, int stream_id, long ray0, long N, int S,
 /* ------------------------------------------------------------------------------------------
  * Coarse depths: train_utils.py:93-113.  t=linspace(0,1,S); z=near*(1-t)+far*t (or lindisp);
  * perturb: mids, upper/lower, z = lower + (upper-lower)*t_rand.
- * torch.linspace(0,1,S): step=(1-0)/(S-1); i<S/2 ? start+step*i : end-step*(S-1-i).
+ * torch.linspace(0,1,S): step=(1-0)/(S-1); i<S/2 ? start+step*i : end-step*(S-1-i), the second half as ONE fused multiply-add (ATen's
+ * CPU kernel is compiled with contraction on; checked against torch.linspace for every S <= 300 in tests/test_oracle_vs_golden.py).
  * ---------------------------------------------------------------------------------------- */
+static float aten_linspace01(int i, int n, float step)
+{
+    if (n == 1) return 0.0f;   /* torch.linspace(0, 1, 1) = [start] */
+    return (i < n / 2) ? step * (float)i : fmaf(-step, (float)(n - 1 - i), 1.0f);
+}
+void oracle_linspace01(int n, float *out)
+{
+    const float step = (n > 1) ? 1.0f / (float)(n - 1) : 0.0f;
+    for (int i = 0; i < n; ++i) out[i] = aten_linspace01(i, n, step);
+}
+
 void oracle_stratified_depths(long N, int S, const float *near_, const float *far_, int lindisp,
                               const float *t_rand, float *z)
 {
     float *t = (float *)malloc(sizeof(float) * S);
     float step = (1.0f - 0.0f) / (float)(S - 1);
-    for (int i = 0; i < S; ++i) t[i] = (i < S / 2) ? (0.0f + step * (float)i) : (1.0f - step * (float)(S - 1 - i));
-    if (S == 1) t[0] = 0.0f;
+    for (int i = 0; i < S; ++i) t[i] = aten_linspace01(i, S, step);
 #pragma omp parallel for
     for (long r = 0; r < N; ++r) {
         float *zr = z + r * S;
@@ -640,21 +651,53 @@ void oracle_composite(long N, int S, float *raw, const float *z, const float *rd
  * u == NULL means det=True (u = linspace(0,1,ns)).  inds (N,ns) int64 optional output
  * (searchsorted(cdf, u, right=True)).
  * ---------------------------------------------------------------------------------------- */
+/* torch.sum of a contiguous float row as ATen's CPU kernel forms it (aten/src/ATen/native/cpu/SumKernel.cpp: vectorized_inner_sum ->
+ * row_sum -> multi_row_sum; the kernel is built for 8-lane vectors also where ATen reports AVX512): the row is read as n/8 vectors of 8
+ * lanes, accumulated into FOUR interleaved vector accumulators (vector 4i+k -> accumulator k; the vectors beyond the last full group of
+ * four -> accumulator 0), accumulators 1..3 are added to 0 in order, then one scalar takes the n%8 trailing elements in order followed by
+ * the eight lanes in order.  All in fp32.  (The cascade levels of multi_row_sum only engage from 16 groups of four = 512 elements; n < 512
+ * here.)  Rows shorter than one vector take the scalar variant of the same scheme (four scalar accumulators).  Restated here because a cdf
+ * knot that moves by an ulp moves a searchsorted index; checked against torch.sum itself for every n in tests/test_oracle_vs_golden.py. */
+static float aten_sum_f32(const float *x, int n)
+{
+    if (n < 8) {
+        float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int g = n / 4;
+        for (int i = 0; i < g; ++i) for (int k = 0; k < 4; ++k) p[k] += x[4 * i + k];
+        for (int i = 4 * g; i < n; ++i) p[0] += x[i];
+        p[0] += p[1]; p[0] += p[2]; p[0] += p[3];
+        return p[0];
+    }
+    const int vs = n / 8, g = vs / 4;
+    float acc = 0.0f;
+    for (int k = vs * 8; k < n; ++k) acc += x[k];
+    for (int l = 0; l < 8; ++l) {
+        float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < g; ++i) for (int k = 0; k < 4; ++k) p[k] += x[(4 * i + k) * 8 + l];
+        for (int i = 4 * g; i < vs; ++i) p[0] += x[i * 8 + l];
+        p[0] += p[1]; p[0] += p[2]; p[0] += p[3];
+        acc += p[0];
+    }
+    return acc;
+}
+float oracle_aten_sum_f32(const float *x, int n) { return aten_sum_f32(x, n); }
+
 void oracle_sample_pdf_2(long N, int nb, int ns, const float *bins, const float *weights,
                          const float *u_in, float *samples, int64_t *inds_out)
 {
     float *ulin = (float *)malloc(sizeof(float) * ns);
     float step = (ns > 1) ? (1.0f / (float)(ns - 1)) : 0.0f;
-    for (int i = 0; i < ns; ++i) ulin[i] = (i < ns / 2) ? step * (float)i : 1.0f - step * (float)(ns - 1 - i);
+    for (int i = 0; i < ns; ++i) ulin[i] = aten_linspace01(i, ns, step);
 #pragma omp parallel for
     for (long r = 0; r < N; ++r) {
         float cdf[512];
         const float *w = weights + r * (nb - 1);
-        float sum = 0.0f;
-        for (int i = 0; i < nb - 1; ++i) sum += (w[i] + 1e-5f);
+        float wp[512];
+        for (int i = 0; i < nb - 1; ++i) wp[i] = w[i] + 1e-5f;                      /* :459 */
+        const float sum = aten_sum_f32(wp, nb - 1);                                  /* torch.sum(weights, dim=-1), :460 */
         cdf[0] = 0.0f;
-        float c = 0.0f;
-        for (int i = 0; i < nb - 1; ++i) { c += (w[i] + 1e-5f) / sum; cdf[i + 1] = c; }
+        double c = 0.0;                                                              /* torch.cumsum(pdf, dim=-1), :461: ATen CPU accumulates */
+        for (int i = 0; i < nb - 1; ++i) { c += (double)(wp[i] / sum); cdf[i + 1] = (float)c; }   /* float in double and rounds every prefix */
         const float *b = bins + r * nb;
         for (int j = 0; j < ns; ++j) {
             float u = u_in ? u_in[r * ns + j] : ulin[j];

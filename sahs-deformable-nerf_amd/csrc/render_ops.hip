@@ -64,11 +64,11 @@ __global__ void ray_uniforms_kernel(unsigned long long seed, int stream_id, long
 }
 
 // ---- coarse depths: train_utils.py:93-113 ----------------------------------------------------
-__device__ __forceinline__ float linspace01(int i, int n)   // torch.linspace(0, 1, n)[i]
-{
+__device__ __forceinline__ float linspace01(int i, int n)   // torch.linspace(0, 1, n)[i], bit for bit: ATen's CPU kernel forms the second
+{                                                            // half `end - step * k` as one fused multiply-add (oracle: aten_linspace01)
     if (n == 1) return 0.0f;
     const float step = 1.0f / (float)(n - 1);
-    return (i < n / 2) ? step * (float)i : 1.0f - step * (float)(n - 1 - i);
+    return (i < n / 2) ? step * (float)i : __builtin_fmaf(-step, (float)(n - 1 - i), 1.0f);
 }
 
 __global__ void stratified_depths_kernel(long N, int S, const float *__restrict__ rays, int ray_stride, int lindisp,
@@ -208,6 +208,35 @@ __global__ void __launch_bounds__(256) composite_forward_kernel(long N, int S, c
 constexpr int RS_MAX = 256;           // S, nf <= 256
 constexpr int RS_WAVES = 4;
 
+// torch.sum of a contiguous fp32 row (n < 512) in the order ATen's CPU kernel adds it (SumKernel.cpp, vectorized_inner_sum / row_sum): n/8
+// vectors of 8 lanes into four interleaved vector accumulators (vector 4i+k -> k; those past the last full group of four -> 0), accumulators
+// 1..3 added to 0, then one scalar takes the n%8 trailing elements followed by the eight lanes, in order; rows shorter than a vector: the
+// same with four scalar accumulators.  = oracle/sahs_oracle.c: aten_sum_f32.
+__device__ inline float aten_row_sum(const float *x, int n)
+{
+    if (n < 8) {
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+        const int g = n >> 2;
+        for (int i = 0; i < g; ++i) { p0 += x[4 * i]; p1 += x[4 * i + 1]; p2 += x[4 * i + 2]; p3 += x[4 * i + 3]; }
+        for (int i = 4 * g; i < n; ++i) p0 += x[i];
+        p0 += p1; p0 += p2; p0 += p3;
+        return p0;
+    }
+    const int vs = n >> 3, g = vs >> 2;
+    float acc = 0.0f;
+    for (int k = vs * 8; k < n; ++k) acc += x[k];
+    for (int l = 0; l < 8; ++l) {
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+        for (int i = 0; i < g; ++i) {
+            p0 += x[(4 * i) * 8 + l]; p1 += x[(4 * i + 1) * 8 + l]; p2 += x[(4 * i + 2) * 8 + l]; p3 += x[(4 * i + 3) * 8 + l];
+        }
+        for (int i = 4 * g; i < vs; ++i) p0 += x[i * 8 + l];
+        p0 += p1; p0 += p2; p0 += p3;
+        acc += p0;
+    }
+    return acc;
+}
+
 // from_z = 1: z (N,S), weights (N,S) are the coarse depths / composite weights; bins = mids(z),
 //             pdf weights = weights[:, 1:-1]; z_out (N,S+nf) = sort(cat(z, samples)).
 // from_z = 0: plain sample_pdf_2 seam: z is bins (N,S-1 columns used as nb = S-1), weights is (N,nb-1); no merge.
@@ -233,16 +262,16 @@ __global__ void __launch_bounds__(RS_WAVES * 64) resample_kernel(long N, int S, 
             for (int i = lane; i < nb - 1; i += 64) cdf[i + 1] = wr[i] + 1e-5f;
         }
         __builtin_amdgcn_wave_barrier();      // LDS ops of one wave execute in order; this only pins the compiler
-        // sum and cumsum in index order (every lane redundantly; LDS broadcast reads)
-        float sum = 0.0f;
-        for (int i = 1; i < nb; ++i) sum += cdf[i];
-        float c = 0.0f;
+        // torch.sum in ATen's own summation order, torch.cumsum accumulated in double and rounded per prefix (ATen CPU's acc_type<float>):
+        // a cdf knot that moves by an ulp moves a searchsorted index (every lane redundantly; LDS broadcast reads)
+        const float sum = aten_row_sum(cdf + 1, nb - 1);
+        double c = 0.0;
         for (int base = 1; base < nb; base += 64) {
             const int cnt = (nb - base) < 64 ? (nb - base) : 64;
             float keep = 0.0f;
             for (int t = 0; t < cnt; ++t) {
-                c += cdf[base + t] / sum;
-                if (t == lane) keep = c;
+                c += (double)(cdf[base + t] / sum);
+                if (t == lane) keep = (float)c;
             }
             __builtin_amdgcn_wave_barrier();
             if (lane < cnt) cdf[base + lane] = keep;   // positions already consumed as w'
