@@ -29,8 +29,7 @@ extern "C" {
 #define SAHS_BF16 1
 #define SAHS_BF16X3 3    /* near-fp32 on the bf16 pipe (AudioFaceModel, split chain only): operands split into bf16 hi + lo, three MFMAs per product,
                           * fp32 accumulate, for the RADIANCE nets; the deformation nets run on the fp32 kernel (mixed, like SAHS_MODEL_NERFACE + SAHS_BF16) */
-#define SAHS_BF16_Q 4     /* SAHS_BF16's arithmetic on v_mfma_f32_16x16x32_bf16 (field_bf16q.hip; AudioFaceModel): the shape holds a higher clock */
-#define SAHS_BF16_2W 2   /* the same arithmetic and packed stream as SAHS_BF16 through the earlier 2-waves-per-SIMD kernel (A/B reference) */
+/* precision values 2 and 4 are reserved (A/B kernels of development builds, csrc/sahs_common.hpp; not in the shipped library) */
 
 int sahs_abi_version(void);
 const char *sahs_last_error(void);
@@ -153,8 +152,9 @@ int sahs_conditioning_backward(const float *flat_params, const float *audio, con
  * flat_params is that model's state_dict in order (2,775,633 / 2,311,140 / 2,066,976 values); `driving` is the (16,29) audio
  * window for the AudioFaceModel and the 76-d expression vector (models.py:368 `driving.repeat`) for the NeRFaceModels;
  * rays, depths and outputs are the same, and sahs_get_ray_bundle, sahs_ray_uniforms, sahs_stratified_depths,
- * sahs_composite_forward, sahs_resample, sahs_sample_pdf are model-independent.  The NeRFaceModels are built for SAHS_F32
- * (rendering and training). */
+ * sahs_composite_forward, sahs_resample, sahs_sample_pdf are model-independent.  Training is SAHS_F32 for every model; rendering
+ * additionally has SAHS_BF16 for all three (for SAHS_MODEL_NERFACE that means MIXED precision: fp32 deformation nets + bf16 radiance
+ * nets, see sahs_model_field_forward_split) and SAHS_BF16X3 for SAHS_MODEL_AUDIO. */
 #define SAHS_MODEL_AUDIO 0
 #define SAHS_MODEL_NERFACE 1
 #define SAHS_MODEL_NERFACE_STATIC 2
@@ -219,7 +219,9 @@ int sahs_resample_merge(long N, int S, int nf, const float *z, const float *weig
  * SAHS_BF16 for SAHS_MODEL_AUDIO (packed from sahs_pack_weights(..., SAHS_BF16, ...)) and for SAHS_MODEL_NERFACE, where it means MIXED
  * precision: mode 1 runs the fp32 deformation nets, mode 2 the bf16 radiance nets (src may then be NULL: sample s of a ray is column s
  * of xw), mode 0 both one after the other (xw_col0 must be 0); packed = sahs_model_pack_weights(SAHS_MODEL_NERFACE, ..., SAHS_BF16, ...) =
- * [bf16 radiance stream | fp32 pack].  SAHS_MODEL_NERFACE_STATIC has no deformation nets: its SAHS_BF16 path is sahs_model_field_forward. */
+ * [bf16 radiance stream | fp32 pack].  SAHS_MODEL_NERFACE_STATIC has no deformation nets: its SAHS_BF16 path is sahs_model_field_forward.
+ * PRECONDITION (not checked on the device): every src[ray][s] lies in [0, xw_row) -- it indexes xw's row of that ray (a permutation from
+ * sahs_resample_merge satisfies it; ops.field_forward_split validates a caller-made one). */
 int sahs_model_field_forward_split(int model, const void *packed, const float *frame, int precision, int level, int mode, long N, int S, const float *rays,
                                    int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src,
                                    void *stream);
@@ -250,6 +252,19 @@ int sahs_model_render_rays_rows(int model, const void *packed, const float *fram
                                 int ray_stride, int Sc, int nf, int lindisp, int white_background, const float *bg, const float *t_rand,
                                 const float *noise_c, const float *u, const float *noise_f, float *z_c, float *z_f, float *raw,
                                 float *weights, float *rows, int row_ld, float *xw, int32_t *src, float *z_new, void *stream);
+
+/* ---- launch probe (opt-in measurement aid; the one exception to "never synchronises") ----
+ * While armed on the calling thread, every FIELD-kernel launch the library makes (from any entry point above) is bracketed by two HIP
+ * events recorded on the launch stream, up to `capacity` launches (further ones are counted as dropped and run unprobed).
+ * sahs_probe_read(i) waits for launch i to finish and returns its duration, the number of sample evaluations it covered and
+ * kind = model << 16 | level << 12 | part << 8 | precision   (part: 0 whole network, 1 deformation nets, 2 radiance nets; precision = that
+ * of the KERNEL launched, e.g. SAHS_F32 for the deformation launches of a mixed-precision model).
+ * bench.py times the kernels of run_one_iter_of_nerf's own call chain with it.  Events belong to the device current at arm time. */
+int sahs_probe_arm(int capacity);
+int sahs_probe_disarm(void);
+int sahs_probe_count(void);
+int sahs_probe_dropped(void);
+int sahs_probe_read(int i, int *kind, long *samples, float *ms);
 
 #ifdef __cplusplus
 }

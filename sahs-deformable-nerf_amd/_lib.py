@@ -9,7 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAHS_NERF_LIB") or os.path.join(_HERE, "libsahs_nerf.so")   # override: ablation builds (tools/ablate.py)
-SAHS_F32, SAHS_BF16, SAHS_BF16_2W, SAHS_BF16X3, SAHS_BF16_Q = 0, 1, 2, 3, 4
+SAHS_F32, SAHS_BF16, SAHS_BF16X3 = 0, 1, 3
+SAHS_BF16_2W, SAHS_BF16_Q = 2, 4      # A/B kernels of development builds only (csrc/ab/, build(defines=["SAHS_AB_KERNELS"])): not in the shipped library
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -62,6 +63,11 @@ SIGNATURES = {
     "sahs_model_field_backward_workspace_words": (_L, [_I, _L]),
     "sahs_model_field_forward_save": (_I, [_I, _P, _P, _I, _L, _I, _P, _I, _P, _P, _P, _P]),
     "sahs_model_field_backward": (_I, [_I, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
+    "sahs_probe_arm": (_I, [_I]),
+    "sahs_probe_disarm": (_I, []),
+    "sahs_probe_count": (_I, []),
+    "sahs_probe_dropped": (_I, []),
+    "sahs_probe_read": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_L), ctypes.POINTER(_F)]),
 }
 
 _lib = None

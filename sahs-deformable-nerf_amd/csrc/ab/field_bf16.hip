@@ -13,8 +13,8 @@
 // Roofline: MFMA-bound against the dense bf16 peak (~2.5 PFLOP/s).
 #include <hip/hip_runtime.h>
 #include <utility>
-#include "sahs_common.hpp"
-#include "sahs_layout.hpp"
+#include "../sahs_common.hpp"
+#include "../sahs_layout.hpp"
 
 namespace sahs {
 namespace hb {

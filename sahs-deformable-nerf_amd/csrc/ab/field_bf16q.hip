@@ -15,8 +15,8 @@
 // differs (32 products per MFMA in another grouping), so results agree with it to fp32 rounding of the accumulations, not bit for bit.
 #include <hip/hip_runtime.h>
 #include <utility>
-#include "sahs_common.hpp"
-#include "sahs_layout.hpp"
+#include "../sahs_common.hpp"
+#include "../sahs_layout.hpp"
 
 #if SAHS_MODEL != 0
 #error "field_bf16q.hip is built for the AudioFaceModel only"

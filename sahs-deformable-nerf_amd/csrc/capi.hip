@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <vector>
 #include "../../include/sahs_nerf.h"
 #include "sahs_common.hpp"
 #include "sahs_layout.hpp"
@@ -26,8 +28,10 @@ int sahs_conditioning_backward_launch(const float *flat, const float *audio, con
                                       hipStream_t stream);
 int sahs_field_forward_bf16w_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                     const float *zvals, float *raw, float *dbg, int num_cu, hipStream_t stream);
+#ifdef SAHS_AB_KERNELS      // A/B builds only (tools/cmp_*.py): the round-1 two-waves-per-SIMD kernel, SAHS_BF16_2W
 int sahs_field_forward_bf16_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                    const float *zvals, float *raw, float *dbg, int num_cu, hipStream_t stream);
+#endif
 int sahs_field_forward_bf16w_split_launch(const float *packed, const float *frame, int level, int mode, long P, int S, const float *rays,
                                           int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
                                           int num_cu, hipStream_t stream);
@@ -79,11 +83,12 @@ int sahs_pack_weights_bf16_launch_nf(const float *flat, float *packed, hipStream
 int sahs_field_forward_bf16w_split_launch_nf(const float *packed, const float *frame, int level, int mode, long P, int S, const float *rays,
                                              int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
                                              int num_cu, hipStream_t stream);
-// AudioFaceModel, SAHS_BF16_Q: the bf16 kernel on the 16x16x32 MFMA shape (field_bf16q.hip)
+#ifdef SAHS_AB_KERNELS      // A/B builds only: SAHS_BF16_Q, the bf16 kernel on the 16x16x32 MFMA shape (field_bf16q.hip)
 int sahs_pack_weights_bf16q_launch(const float *flat, float *packed, hipStream_t stream);
 int sahs_field_forward_bf16q_split_launch(const float *packed, const float *frame, int level, int mode, long P, int S, const float *rays,
                                           int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
                                           int num_cu, hipStream_t stream);
+#endif
 // AudioFaceModel, SAHS_BF16X3: the radiance nets with operands split into bf16 hi + lo (field_bf16x3.hip); deformation nets fp32
 long sahs_layout_packed_words_bf16x3(void);
 int sahs_pack_weights_bf16x3_launch(const float *flat, float *packed, hipStream_t stream);
@@ -125,16 +130,75 @@ static int num_cus()     // of the CURRENT device (cached per device; the persis
     return n;
 }
 
+// ---- launch probe (sahs_probe_*): while armed on the calling thread, every FIELD-kernel launch the library makes is bracketed by two
+// HIP events recorded on the launch stream -- how bench.py times the kernels of the product's own call chain ----
+struct Probe {
+    bool armed = false;
+    int cap = 0, n = 0, dropped = 0;
+    std::vector<hipEvent_t> ev;      // two per launch
+    std::vector<int> kind;
+    std::vector<long> samples;
+};
+static thread_local Probe g_probe;
+static inline int probe_kind(int model, int precision, int level, int part) { return model << 16 | level << 12 | part << 8 | precision; }
+template <class F> static inline int probed(int kind, long samples, hipStream_t st, F &&launch)
+{
+    Probe &p = g_probe;
+    if (!p.armed) return launch();
+    if (p.n >= p.cap) { ++p.dropped; return launch(); }
+    (void)hipEventRecord(p.ev[2 * p.n], st);
+    const int e = launch();
+    (void)hipEventRecord(p.ev[2 * p.n + 1], st);
+    p.kind[p.n] = kind;
+    p.samples[p.n] = samples;
+    ++p.n;
+    return e;
+}
+
 extern "C" {
 
 int sahs_abi_version(void) { return SAHS_ABI_VERSION; }
+
+int sahs_probe_arm(int capacity)
+{
+    Probe &p = g_probe;
+    REQUIRE(capacity >= 1 && capacity <= 65536, "sahs_probe_arm(1 <= capacity <= 65536)");
+    while ((int)p.ev.size() < 2 * capacity) {
+        hipEvent_t e;
+        const hipError_t r = hipEventCreate(&e);
+        if (r != hipSuccess) return hip_fail("sahs_probe_arm", (int)r);
+        p.ev.push_back(e);
+    }
+    p.kind.assign(capacity, 0);
+    p.samples.assign(capacity, 0);
+    p.cap = capacity;
+    p.n = p.dropped = 0;
+    p.armed = true;
+    return 0;
+}
+int sahs_probe_disarm(void) { g_probe.armed = false; return 0; }
+int sahs_probe_count(void) { return g_probe.n; }
+int sahs_probe_dropped(void) { return g_probe.dropped; }
+int sahs_probe_read(int i, int *kind, long *samples, float *ms)
+{
+    Probe &p = g_probe;
+    REQUIRE(i >= 0 && i < p.n && kind && samples && ms, "sahs_probe_read");
+    hipError_t r = hipEventSynchronize(p.ev[2 * i + 1]);
+    if (r == hipSuccess) r = hipEventElapsedTime(ms, p.ev[2 * i], p.ev[2 * i + 1]);
+    if (r != hipSuccess) return hip_fail("sahs_probe_read", (int)r);
+    *kind = p.kind[i];
+    *samples = p.samples[i];
+    return 0;
+}
 const char *sahs_last_error(void) { return g_err; }
 long sahs_param_count(void) { return kFlat.total; }
 long sahs_packed_words(int precision)
 {
     if (precision == SAHS_BF16X3) return sahs_layout_packed_words_bf16x3() + PACK_FLOATS;     // [hi/lo radiance streams | fp32 pack (deformation nets)]
-    if (precision == SAHS_BF16_Q) return hb::PACKH_WORDS;
-    return precision == SAHS_F32 ? PACK_FLOATS : ((precision == SAHS_BF16 || precision == SAHS_BF16_2W) ? hb::PACKH_WORDS : -1);
+#ifdef SAHS_AB_KERNELS
+    if (precision == SAHS_BF16_Q || precision == SAHS_BF16_2W) return hb::PACKH_WORDS;
+#endif
+    return precision == SAHS_F32 ? PACK_FLOATS : (precision == SAHS_BF16 ? hb::PACKH_WORDS : -1);
 }
 long sahs_frame_words(void) { return FRAME_FLOATS; }
 
@@ -142,16 +206,19 @@ int sahs_pack_weights(const float *flat_params, void *packed, int precision, voi
 {
     REQUIRE(flat_params && packed, "sahs_pack_weights");
     REQUIRE(ALIGNED16(packed), "sahs_pack_weights(packed alignment)");
+#ifdef SAHS_AB_KERNELS
     if (precision == SAHS_BF16_Q) {
         int e = sahs_pack_weights_bf16q_launch(flat_params, (float *)packed, (hipStream_t)stream);
         return e ? hip_fail("sahs_pack_weights", e) : 0;
     }
+    if (precision == SAHS_BF16_2W) precision = SAHS_BF16;      // the same packed stream
+#endif
     if (precision == SAHS_BF16X3) {
         int e = sahs_pack_weights_bf16x3_launch(flat_params, (float *)packed, (hipStream_t)stream);
         if (!e) e = sahs_pack_weights_f32_launch(flat_params, (float *)packed + sahs_layout_packed_words_bf16x3(), (hipStream_t)stream);
         return e ? hip_fail("sahs_pack_weights", e) : 0;
     }
-    if (precision != SAHS_F32 && precision != SAHS_BF16 && precision != SAHS_BF16_2W) return fail(2, "sahs_pack_weights: unknown precision %s%ld", "", precision);
+    if (precision != SAHS_F32 && precision != SAHS_BF16) return fail(2, "sahs_pack_weights: unknown precision %s%ld", "", precision);
     int e = precision == SAHS_F32 ? sahs_pack_weights_f32_launch(flat_params, (float *)packed, (hipStream_t)stream)
                                   : sahs_pack_weights_bf16_launch(flat_params, (float *)packed, (hipStream_t)stream);
     return e ? hip_fail("sahs_pack_weights", e) : 0;
@@ -195,24 +262,28 @@ int sahs_field_forward(const void *packed, const float *frame, int level, long N
     REQUIRE(packed && frame && rays && z && raw, "sahs_field_forward");
     REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_field_forward(shape)");
     REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_field_forward(alignment)");
+    hipStream_t st = (hipStream_t)stream;
+#ifdef SAHS_AB_KERNELS
     if (precision == SAHS_BF16_Q) {
         REQUIRE(dbg == nullptr, "sahs_field_forward(SAHS_BF16_Q has no debug outputs)");
         int e = sahs_field_forward_bf16q_split_launch((const float *)packed, frame, level, 0, N * S, S, rays, ray_stride, z, raw, nullptr, 0, 0, nullptr,
-                                                      num_cus(), (hipStream_t)stream);
+                                                      num_cus(), st);
         return e ? hip_fail("sahs_field_forward", e) : 0;
     }
+    if (precision == SAHS_BF16_2W) {
+        int e = sahs_field_forward_bf16_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(), st);
+        return e ? hip_fail("sahs_field_forward", e) : 0;
+    }
+#endif
     if (precision == SAHS_BF16X3)
         return fail(2, "sahs_field_forward: SAHS_BF16X3 runs through sahs_model_field_forward_split / sahs_model_render_rays_rows (it needs the xw "
                        "workspace)%s%ld", "", 0L);
-    if (precision != SAHS_F32 && precision != SAHS_BF16 && precision != SAHS_BF16_2W) return fail(2, "sahs_field_forward: unknown precision %s%ld", "", precision);
-    int e = precision == SAHS_F32
-                ? sahs_field_forward_f32_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, nullptr, num_cus(),
-                                                (hipStream_t)stream)
-                : (precision == SAHS_BF16
-                       ? sahs_field_forward_bf16w_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(),
-                                                         (hipStream_t)stream)
-                       : sahs_field_forward_bf16_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(),
-                                                        (hipStream_t)stream));
+    if (precision != SAHS_F32 && precision != SAHS_BF16) return fail(2, "sahs_field_forward: unknown precision %s%ld", "", precision);
+    int e = probed(probe_kind(SAHS_MODEL_AUDIO, precision, level, 0), N * S, st, [&] {
+        return precision == SAHS_F32
+                   ? sahs_field_forward_f32_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, nullptr, num_cus(), st)
+                   : sahs_field_forward_bf16w_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(), st);
+    });
     return e ? hip_fail("sahs_field_forward", e) : 0;
 }
 
@@ -406,7 +477,7 @@ long sahs_model_packed_words(int model, int precision)
 long sahs_model_executed_macs_part(int model, int precision, int part)
 {
     if (model < 0 || model > 2 || precision < SAHS_F32 || precision > SAHS_BF16_Q || part < 0 || part > 2) return -1;
-    if (precision == SAHS_BF16_Q) precision = SAHS_BF16;      // the same MFMA work on another shape
+    if (precision == SAHS_BF16_Q || precision == SAHS_BF16_2W) precision = SAHS_BF16;      // A/B kernels: the same MFMA work
     if (precision == SAHS_BF16X3)       // fp32 deformation nets + three bf16 MFMAs per product of the radiance nets
         return model != SAHS_MODEL_AUDIO ? -1 : (part != 2 ? sahs_layout_executed_macs(SAHS_F32, 1) : 0) + (part != 1 ? 3 * sahs_layout_executed_macs(SAHS_BF16, 2) : 0);
     if (model == SAHS_MODEL_NERFACE_STATIC && part != 0) return part == 2 ? sahs_layout_executed_macs_ns(precision == SAHS_F32 ? SAHS_F32 : SAHS_BF16, 0) : 0;
@@ -457,13 +528,17 @@ static int field_forward_model(int model, const void *packed, const float *frame
     if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)
         return fail(2, "sahs_model_field_forward: the mixed-precision NeRFaceModel runs through sahs_model_field_forward_split / "
                        "sahs_model_render_rays_rows (it needs the xw workspace)%s%ld", "", 0L);
+    hipStream_t st = (hipStream_t)stream;
     if (model == SAHS_MODEL_NERFACE_STATIC && precision == SAHS_BF16) {
-        int e = sahs_field_forward_bf16w_launch_ns((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(), (hipStream_t)stream);
+        int e = probed(probe_kind(model, precision, level, 0), N * S, st, [&] {
+            return sahs_field_forward_bf16w_launch_ns((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(), st);
+        });
         return e ? hip_fail("sahs_model_field_forward", e) : 0;
     }
     if (precision != SAHS_F32) return fail(2, "sahs_model_field_forward: only SAHS_F32 is built for this model %s%ld", "", precision);
-    int e = kModels[model].field_f32((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, nullptr, num_cus(),
-                                     (hipStream_t)stream);
+    int e = probed(probe_kind(model, precision, level, 0), N * S, st, [&] {
+        return kModels[model].field_f32((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, nullptr, num_cus(), st);
+    });
     return e ? hip_fail("sahs_model_field_forward", e) : 0;
 }
 
@@ -531,37 +606,48 @@ int sahs_model_field_forward_split(int model, const void *packed, const float *f
     REQUIRE((mode == 1 || raw) && (mode == 2 || z) && (mode != 2 || src || mixed), "sahs_model_field_forward_split(buffers of the mode)");
     REQUIRE(xw_col0 >= 0 && xw_row >= xw_col0 + (mode == 2 ? 0 : S) && ALIGNED16(xw) && ALIGNED16(packed) && ALIGNED16(frame) && (!raw || ALIGNED16(raw)),
             "sahs_model_field_forward_split(xw layout / alignment)");
+    hipStream_t st = (hipStream_t)stream;
     if (mixed) {      // deformation nets by the fp32 kernel, radiance nets by the bf16 kernel; mode 0 = both, one after the other
         const float *pk16 = (const float *)packed, *pk32 = pk16 + (x3 ? sahs_layout_packed_words_bf16x3() : sahs_layout_packed_words_bf16_nf());
         REQUIRE(mode != 0 || xw_col0 == 0, "sahs_model_field_forward_split(mixed precision, mode 0: xw_col0 must be 0)");
         int e = 0;
         if (mode != 2)
-            e = x3 ? sahs_field_forward_f32_split_launch(pk32, frame, level, 1, N * S, S, rays, ray_stride, z, nullptr, xw, xw_row, xw_col0, nullptr, nullptr,
-                                                         num_cus(), (hipStream_t)stream)
-                   : sahs_field_forward_f32_split_launch_nf(pk32, frame, level, 1, N * S, S, rays, ray_stride, z, nullptr, xw, xw_row, xw_col0, nullptr,
-                                                            nullptr, num_cus(), (hipStream_t)stream);
+            e = probed(probe_kind(model, SAHS_F32, level, 1), N * S, st, [&] {
+                return x3 ? sahs_field_forward_f32_split_launch(pk32, frame, level, 1, N * S, S, rays, ray_stride, z, nullptr, xw, xw_row, xw_col0, nullptr,
+                                                                nullptr, num_cus(), st)
+                          : sahs_field_forward_f32_split_launch_nf(pk32, frame, level, 1, N * S, S, rays, ray_stride, z, nullptr, xw, xw_row, xw_col0, nullptr,
+                                                                   nullptr, num_cus(), st);
+            });
         if (!e && mode != 1)
-            e = x3 ? sahs_field_radiance_bf16x3_launch(pk16, frame, level, N * S, S, rays, ray_stride, raw, xw, xw_row, mode == 2 ? src : nullptr, num_cus(),
-                                                       (hipStream_t)stream)
-                   : sahs_field_forward_bf16w_split_launch_nf(pk16, frame, level, 2, N * S, S, rays, ray_stride, nullptr, raw, xw, xw_row, 0,
-                                                              mode == 2 ? src : nullptr, num_cus(), (hipStream_t)stream);
+            e = probed(probe_kind(model, precision, level, 2), N * S, st, [&] {
+                return x3 ? sahs_field_radiance_bf16x3_launch(pk16, frame, level, N * S, S, rays, ray_stride, raw, xw, xw_row, mode == 2 ? src : nullptr,
+                                                              num_cus(), st)
+                          : sahs_field_forward_bf16w_split_launch_nf(pk16, frame, level, 2, N * S, S, rays, ray_stride, nullptr, raw, xw, xw_row, 0,
+                                                                     mode == 2 ? src : nullptr, num_cus(), st);
+            });
         return e ? hip_fail("sahs_model_field_forward_split", e) : 0;
     }
+#ifdef SAHS_AB_KERNELS
     if (precision == SAHS_BF16_Q && model == SAHS_MODEL_AUDIO) {
-        int e = sahs_field_forward_bf16q_split_launch((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0, src,
-                                                      num_cus(), (hipStream_t)stream);
+        int e = probed(probe_kind(model, precision, level, mode), N * S, st, [&] {
+            return sahs_field_forward_bf16q_split_launch((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0,
+                                                         src, num_cus(), st);
+        });
         return e ? hip_fail("sahs_model_field_forward_split", e) : 0;
     }
+#endif
     if (precision != SAHS_F32 && !(precision == SAHS_BF16 && model == SAHS_MODEL_AUDIO))
         return fail(4, "sahs_model_field_forward_split: precision %s%ld is not built for this model", "", (long)precision);
-    int e = precision == SAHS_BF16
-                ? sahs_field_forward_bf16w_split_launch((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0,
-                                                        src, num_cus(), (hipStream_t)stream)
-            : model == SAHS_MODEL_AUDIO
-                ? sahs_field_forward_f32_split_launch((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0, src,
-                                                      nullptr, num_cus(), (hipStream_t)stream)
-                : sahs_field_forward_f32_split_launch_nf((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0,
-                                                         src, nullptr, num_cus(), (hipStream_t)stream);
+    int e = probed(probe_kind(model, precision, level, mode), N * S, st, [&] {
+        return precision == SAHS_BF16
+                   ? sahs_field_forward_bf16w_split_launch((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0,
+                                                           src, num_cus(), st)
+               : model == SAHS_MODEL_AUDIO
+                   ? sahs_field_forward_f32_split_launch((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0,
+                                                         src, nullptr, num_cus(), st)
+                   : sahs_field_forward_f32_split_launch_nf((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row,
+                                                            xw_col0, src, nullptr, num_cus(), st);
+    });
     return e ? hip_fail("sahs_model_field_forward_split", e) : 0;
 }
 
@@ -660,7 +746,11 @@ int sahs_model_render_rays_rows(int model, const void *packed, const float *fram
         REQUIRE(precision != SAHS_BF16X3 || model == SAHS_MODEL_AUDIO, "sahs_model_render_rays_rows(SAHS_BF16X3 is built for SAHS_MODEL_AUDIO)");
     }
     if (xw && src && z_new && nf > 0 && model != SAHS_MODEL_NERFACE_STATIC &&
-        (precision == SAHS_F32 || precision == SAHS_BF16 || precision == SAHS_BF16X3 || (precision == SAHS_BF16_Q && model == SAHS_MODEL_AUDIO))) {
+        (precision == SAHS_F32 || precision == SAHS_BF16 || precision == SAHS_BF16X3
+#ifdef SAHS_AB_KERNELS
+         || (precision == SAHS_BF16_Q && model == SAHS_MODEL_AUDIO)
+#endif
+         )) {
         // the deformation nets are shared by the two levels and the fine depths contain the coarse ones: evaluate them once per depth
         const char *who = "sahs_model_render_rays_rows";
         REQUIRE(packed && frame && rays && z_c && z_f && raw && weights && Sc + nf <= 256, who);

@@ -19,16 +19,12 @@
 #include <utility>
 #include "sahs_common.hpp"
 #include "sahs_layout.hpp"
+#include "bf16_pipe.hpp"
 
 namespace SAHS_NS {
 namespace hw {
 using namespace hb;      // the bf16 layer program, chunking and packed layout of sahs_layout.hpp
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+using namespace bfp;     // vector types, hand-issued LDS reads + retiring waits, bias helpers, the LDS-DMA chunk context (bf16_pipe.hpp)
 
 enum { FIELD_ALL = 0, FIELD_DEFORM = 1, FIELD_RADIANCE = 2 };
 constexpr int KX32 = (KB_XYZ + 1) / 2, KA32 = (KB_AMB + 1) / 2;     // 32-feature blocks of PE(x') and PE(w): 2, 1 | 3, 1 (NeRFaceModel)      // the kernel's MODE (same values as field_f32.hip / SAHS_FIELD_*)
@@ -51,27 +47,6 @@ constexpr int AP = 4;                                                  // A frag
 constexpr int PIECE_HW = W_THREADS * 8;                                // one LDS-DMA piece: 4 KB = 2048 halfwords (1 KB per wave)
 constexpr int DMA_PIECES = LDS_BUF_BYTES / (W_THREADS * 16);           // 16
 
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
-typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
-
-__device__ __forceinline__ uint32_t lds_addr_of(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p; }
-
-// ---- hand-issued LDS reads (volatile asm: they stay where they are written; destinations are unprotected until the counted wait) ----
-template <int OFF, class V>      // V: u32x4 (A fragments) or f32x4 (bias rows)
-__device__ __forceinline__ void lds_read16(V &dst, uint32_t addr)
-{
-    static_assert(sizeof(V) == 16, "one ds_read_b128");
-    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm()
-{
-    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
-}
-__device__ __forceinline__ void fence() { __builtin_amdgcn_sched_barrier(0); }
-
 // run f(integral_constant<int, q>) for q = 0 .. NH-1 with q a compile-time constant: per-half state lives in small arrays that must
 // only ever be indexed by constants (a run-time index sends them to scratch and turns tanhf into an out-of-line call)
 template <class F>
@@ -80,17 +55,17 @@ __device__ __forceinline__ void for_halves(F &&f)
     [&]<int... Qs>(std::integer_sequence<int, Qs...>) { (f(std::integral_constant<int, Qs>{}), ...); }(std::make_integer_sequence<int, NH>{});
 }
 
-
-struct Ctx {
-    const unsigned short *stream;   // this level's packed bf16 stream
-    char *lds;
-    int buf;
-    int lane, h, wave;
-    const f32x4 *nx_src; f32x4 *nx_dst;   // the chunk being prefetched: this lane's first source granule, the LDS buffer
-    uint32_t off;                   // halfword offset of the NEXT chunk to prefetch (uniform)
-    uint32_t wrap_at, wrap_to;      // the stream wraps for the next sample tile: whole network [0, STREAM_HW), deformation nets
-                                    // [0, T0), radiance nets [T0, STREAM_HW) (the kernel's MODE)
-    uint32_t bias_addr;             // LDS byte address of this lane's first bias row (+4h rows)
+#ifdef SAHS_ABLATE_NODMA        // timing-only ablations (tools/ablate.py): results are wrong by construction
+constexpr bool kNoDma = true;
+#else
+constexpr bool kNoDma = false;
+#endif
+#ifdef SAHS_X_NOBARRIER
+constexpr bool kNoBarrier = true;
+#else
+constexpr bool kNoBarrier = false;
+#endif
+struct Ctx : PipeCtx<W_THREADS, LDS_BUF_BYTES, LDS_BIAS_BYTE_OFF, kNoDma, kNoBarrier> {
 #ifdef SAHS_STAMP_W
     // diagnostic build only (tools/stamp_bf16w.py): s_memtime stamps of wave 0 of workgroup 0 for one sample tile, written to the dbg
     // buffer (which the normal dbg writes then leave alone); no output value is computed from them
@@ -102,65 +77,7 @@ struct Ctx {
 #else
     __device__ __forceinline__ void stamp() {}
 #endif
-
-    __device__ __forceinline__ void prepare(int hw, int b)
-    {
-        if (off >= wrap_at) off = wrap_to;
-        nx_src = reinterpret_cast<const f32x4 *>(stream + off) + lane;
-        nx_dst = reinterpret_cast<f32x4 *>(lds + b * LDS_BUF_BYTES);
-        off += (uint32_t)hw;
-    }
-    __device__ __forceinline__ void issue_piece(int p)
-    {
-#ifndef SAHS_ABLATE_NODMA       // timing-only ablations (tools/ablate.py): results are wrong by construction
-        // (A hand-issued scalar-base form -- global_load_lds_dwordx4 voffset, s[base:base+1], no VALU address arithmetic -- was measured
-        // and is not faster: 22.6 against 22.0 ms.)
-        const int base = p * W_THREADS + wave * WAVE;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(nx_src + base), (lds_ptr_t)(nx_dst + base), 16, 0, 0);
-#endif
-    }
-    __device__ __forceinline__ void begin_chunk(int next_hw) { prepare(next_hw, buf ^ 1); }
-    __device__ __forceinline__ void end_chunk()
-    {
-#ifdef SAHS_X_NOBARRIER             // timing-only experiment (results wrong by construction)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-        __syncthreads();            // vmcnt(0) (the next chunk has landed) + barrier (every wave is done with this one)
-#endif
-        buf ^= 1;
-    }
-    __device__ __forceinline__ uint32_t cur_addr() const { return lds_addr_of(lds + buf * LDS_BUF_BYTES) + 16 * lane; }
-    // re-materialised opaquely once per sample tile: keeps the ~140 per-tile bias addresses out of LICM (they would be hoisted and spilled)
-    __device__ __forceinline__ void refresh_bias_base()
-    {
-        uint32_t a = lds_addr_of(lds) + LDS_BIAS_BYTE_OFF + 16 * h;
-        asm volatile("" : "+v"(a));
-        bias_addr = a;
-    }
 };
-
-// this lane's 16 bias rows of a 32-row tile (accumulator register r <-> row (r&3) + 8(r>>2) + 4h): four ds_read_b128 at +32 B steps.
-// The raw destinations are turned into the MFMA's C operand only AFTER the wait that retires them (bias_as_c): nothing the compiler
-// might insert next to the reads (copies into an aligned 16-register block, moves to AGPRs) may see them in flight.
-template <int OFF>
-__device__ __forceinline__ void bias_read(f32x4 (&t)[4], uint32_t addr)
-{
-    lds_read16<OFF>(t[0], addr);
-    lds_read16<OFF + 32>(t[1], addr);
-    lds_read16<OFF + 64>(t[2], addr);
-    lds_read16<OFF + 96>(t[3], addr);
-}
-// (float-typed reads, plain element copies: __builtin_bit_cast applied to an ELEMENT of an ext_vector reads element 0 for every index
-// with this compiler -- found on the ISA; whole-vector bit_casts are fine)
-__device__ __forceinline__ f32x16 bias_as_c(const f32x4 (&t)[4])
-{
-    f32x16 b;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b[4 * g + r] = t[g][r];
-    return b;
-}
 
 // ---- activation + bf16 conversion of a finished accumulator tile, software-pipelined -------------------------------------------------
 // Beside a wave's own MFMAs, INDEPENDENT VALU instructions are nearly free (about six per MFMA), but a dependent chain is not: v_mul ->
@@ -172,7 +89,6 @@ __device__ __forceinline__ f32x16 bias_as_c(const f32x4 (&t)[4])
 //             C(T-2)  dword = cvt_pk_bf16(r_{T-3}, r_{T-2})   when T-2 is odd
 // 36 ticks convert a tile; they are dealt out over the MFMA slots of the following tile.
 struct PackState { f32x2 m2[2]; float r[4]; uint32_t d[2]; };
-typedef short s16x2 __attribute__((ext_vector_type(2)));
 // value U (0..31): pair P = U>>1 (half P&1, accumulator registers 2(P>>1) + (U&1)) -> dword (P>>1)&3 of fragment [half][(P>>1)>>2]
 // ReLU layers (slope 0) take a shorter route: round first, clamp after -- bf16(max(v,0)) == max(bf16(v),0), and on bf16 BIT PATTERNS
 // max(.,0) is a signed 16-bit integer max (negative floats are negative integers), so one v_pk_max_i16 clamps a converted PAIR:
@@ -239,8 +155,6 @@ __device__ __forceinline__ void pack_ticks(const f32x16 (&acc)[NH], Blk &o, floa
     [&]<int... Is>(std::integer_sequence<int, Is...>) { (pack_tick<LO + Is>(acc, o, slope, ps), ...); }(std::make_integer_sequence<int, HI - LO>{});
 }
 
-__device__ __forceinline__ bf16x8 frag(const u32x4 &v) { return __builtin_bit_cast(bf16x8, v); }
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // hidden layer: NT32 output tiles of 32 rows for both halves.  Per chunk: TOTAL = G*STEPS A fragments, two MFMAs each.
 // LGKM bookkeeping (all reads are asm, in issue order): step I issues  [wait] [2 MFMAs] [bias batch of the next tile: 4 reads, when I
@@ -303,10 +217,12 @@ __device__ __forceinline__ void dense_w(Ctx &cx, St &st, Blk *in0, const Blk *in
         auto step = [&]<int I>() {
             constexpr int g = I / STEPS, k = I % STEPS, b = k >> 1, st_ = k & 1, t = T0 + g, set = t & 1;
             const Blk &x = (b < K0) ? in0[b] : ((b < K0 + K1) ? in1[b - K0] : in2[b - K0 - K1]);
-            wait_lgkm<S::cnt(I)>();
+            // retires A(I) and, at a tile's first step, the tile's bias batch (issued before A(I): Sched)
+            if constexpr (k == 0) wait_retire<S::cnt(I)>(a[I % AP], braw[set]);
+            else wait_retire<S::cnt(I)>(a[I % AP]);
             fence();
             f32x16 cb;
-            if constexpr (k == 0) cb = bias_as_c(braw[set]);      // the tile's chains start from its bias (landed: retired by the wait above)
+            if constexpr (k == 0) cb = bias_as_c(braw[set]);      // the tile's chains start from its bias
             for_halves([&](auto Q) {
                 constexpr int hh = decltype(Q)::value;
                 if constexpr (k == 0) st.acc[set][hh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(a[I % AP]), frag(x.s[hh][st_]), cb, 0, 0, 0);
@@ -358,7 +274,7 @@ __device__ __forceinline__ void dense_w_out(Ctx &cx, St &st, Blk *in0, f32x16 (&
         f32x4 t0, t1;
         lds_read16<0>(t0, baddr);
         lds_read16<32>(t1, baddr);
-        wait_lgkm<0>();
+        wait_retire<0>(t0, t1);
         fence();
         for_halves([&](auto Q) {
             constexpr int hh = decltype(Q)::value;
@@ -372,7 +288,7 @@ __device__ __forceinline__ void dense_w_out(Ctx &cx, St &st, Blk *in0, f32x16 (&
     [&]<int... Is>(std::integer_sequence<int, Is...>) { (lds_read16<Is * 1024>(a[Is], abase), ...); }(std::make_integer_sequence<int, (AP < TOTAL ? AP : TOTAL)>{});
     fence();
     auto step = [&]<int I>() {
-        wait_lgkm<((TOTAL - 1 - I) < (AP - 1) ? (TOTAL - 1 - I) : (AP - 1))>();
+        wait_retire<((TOTAL - 1 - I) < (AP - 1) ? (TOTAL - 1 - I) : (AP - 1))>(a[I % AP]);
         fence();
         for_halves([&](auto Q) {
             constexpr int hh = decltype(Q)::value;

@@ -15,6 +15,7 @@
 #include <utility>
 #include "sahs_common.hpp"
 #include "sahs_layout.hpp"
+#include "bf16_pipe.hpp"
 
 #if SAHS_MODEL != 0
 #error "field_bf16x3.hip is built for the AudioFaceModel only"
@@ -23,12 +24,7 @@
 namespace sahs {
 namespace hx3 {
 using namespace hb;      // the bf16 layer program of sahs_layout.hpp (layers, blocks, bias offsets); offsets of the doubled stream derived below
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+using namespace bfp;     // vector types, hand-issued LDS reads + retiring waits, bias helpers, the LDS-DMA chunk context (bf16_pipe.hpp)
 
 struct Blk { u32x4 s[2]; u32x4 l[2]; };            // 32 features of this lane's sample: hi (s) and lo (l) bf16x8 fragments per k-step (as dwords)
 
@@ -58,87 +54,17 @@ constexpr int pick_GX(int KB32, int NT32)
 constexpr long STREAM_HWX = 2 * STREAM_HW;                             // halfwords per level; layer i starts at 2 * kProgH.layer[i].stream_off
 static_assert(11 * 2048 * 2 <= LDS_BUF_BYTES, "one tile of the widest layer (11 k-blocks) must fit a buffer");
 
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
-typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
-
-__device__ __forceinline__ uint32_t lds_addr_of(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p; }
-
-// hand-issued LDS reads (volatile asm: they stay where they are written; destinations are unprotected until the counted wait)
-template <int OFF, class V>
-__device__ __forceinline__ void lds_read16(V &dst, uint32_t addr)
-{
-    static_assert(sizeof(V) == 16, "one ds_read_b128");
-    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm()
-{
-    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
-}
-__device__ __forceinline__ void fence() { __builtin_amdgcn_sched_barrier(0); }
-
-struct Ctx {
-    const unsigned short *stream;   // this level's packed hi/lo stream
-    char *lds;
-    int buf;
-    int lane, h, wave;
-    const f32x4 *nx_src; f32x4 *nx_dst;
-    uint32_t off;                   // halfword offset of the NEXT chunk to prefetch (uniform)
-    uint32_t wrap_at, wrap_to;      // the radiance nets' range of the stream
-    uint32_t bias_addr;             // LDS byte address of this lane's first bias row (+4h rows)
-
-    __device__ __forceinline__ void prepare(int hw, int b)
-    {
-        if (off >= wrap_at) off = wrap_to;
-        nx_src = reinterpret_cast<const f32x4 *>(stream + off) + lane;
-        nx_dst = reinterpret_cast<f32x4 *>(lds + b * LDS_BUF_BYTES);
-        off += (uint32_t)hw;
-    }
-    __device__ __forceinline__ void issue_piece(int p)
-    {
-#ifndef SAHS_X3_NODMA           // timing-only experiments (tools/ablate.py x3*): results wrong by construction
-        const int base = p * X_THREADS + wave * WAVE;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(nx_src + base), (lds_ptr_t)(nx_dst + base), 16, 0, 0);
-#endif
-    }
-    __device__ __forceinline__ void begin_chunk(int next_hw) { prepare(next_hw, buf ^ 1); }
-    __device__ __forceinline__ void end_chunk()
-    {
-#ifdef SAHS_X3_NOBARRIER
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SAHS_X3_NODMA            // timing-only experiments (tools/ablate.py x3*): results wrong by construction
+constexpr bool kNoDma = true;
 #else
-        __syncthreads();            // vmcnt(0) (the next chunk has landed) + barrier (every wave is done with this one)
+constexpr bool kNoDma = false;
 #endif
-        buf ^= 1;
-    }
-    __device__ __forceinline__ uint32_t cur_addr() const { return lds_addr_of(lds + buf * LDS_BUF_BYTES) + 16 * lane; }
-    __device__ __forceinline__ void refresh_bias_base()
-    {
-        uint32_t a = lds_addr_of(lds) + LDS_BIAS_BYTE_OFF + 16 * h;
-        asm volatile("" : "+v"(a));
-        bias_addr = a;
-    }
-};
-
-template <int OFF>
-__device__ __forceinline__ void bias_read(f32x4 (&t)[4], uint32_t addr)
-{
-    lds_read16<OFF>(t[0], addr);
-    lds_read16<OFF + 32>(t[1], addr);
-    lds_read16<OFF + 64>(t[2], addr);
-    lds_read16<OFF + 96>(t[3], addr);
-}
-__device__ __forceinline__ f32x16 bias_as_c(const f32x4 (&t)[4])
-{
-    f32x16 b;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b[4 * g + r] = t[g][r];
-    return b;
-}
+#ifdef SAHS_X3_NOBARRIER
+constexpr bool kNoBarrier = true;
+#else
+constexpr bool kNoBarrier = false;
+#endif
+typedef PipeCtx<X_THREADS, LDS_BUF_BYTES, LDS_BIAS_BYTE_OFF, kNoDma, kNoBarrier> Ctx;
 
 // hi/lo split of a pair of fp32 values: hi = bf16 pair (RNE), lo = bf16 pair of the remainders
 __device__ __forceinline__ uint32_t cvt_pair(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2)); }
@@ -189,8 +115,6 @@ __device__ __forceinline__ void pack_ticks(const f32x16 &acc, Blk &o, float slop
 {
     [&]<int... Is>(std::integer_sequence<int, Is...>) { (pack_tick<LO + Is>(acc, o, slope, ps), ...); }(std::make_integer_sequence<int, HI - LO>{});
 }
-
-__device__ __forceinline__ bf16x8 frag(const u32x4 &v) { return __builtin_bit_cast(bf16x8, v); }
 
 // LGKM bookkeeping as in field_bf16w.hip (Sched), with TWO A reads (hi, lo) per k-step: step I issues [wait] [3 MFMAs] [bias batch of the
 // next tile: 4 reads, when I starts a tile that has a successor] [A reads of step I+AP: hi then lo]; the wait of step I allows exactly
@@ -251,7 +175,9 @@ __device__ __forceinline__ void dense_x(Ctx &cx, St &st, Blk *in0, const Blk *in
         auto step = [&]<int I>() {
             constexpr int g = I / STEPS, k = I % STEPS, b = k >> 1, st_ = k & 1, t = T0 + g, set = t & 1;
             const Blk &x = (b < K0) ? in0[b] : ((b < K0 + K1) ? in1[b - K0] : in2[b - K0 - K1]);
-            wait_lgkm<S::cnt(I)>();
+            // retires A_hi(I), A_lo(I) and, at a tile's first step, the tile's bias batch (bf16_pipe.hpp: wait_retire)
+            if constexpr (k == 0) wait_retire<S::cnt(I)>(ah[I % AP], al[I % AP], braw[set]);
+            else wait_retire<S::cnt(I)>(ah[I % AP], al[I % AP]);
             fence();
             f32x16 cb;
             if constexpr (k == 0) cb = bias_as_c(braw[set]);
@@ -315,7 +241,7 @@ __device__ __forceinline__ void dense_x_out(Ctx &cx, St &st, Blk *in0, f32x16 &a
         f32x4 t0, t1;
         lds_read16<0>(t0, baddr);
         lds_read16<32>(t1, baddr);
-        wait_lgkm<0>();
+        wait_retire<0>(t0, t1);
         fence();
 #pragma unroll
         for (int r = 0; r < 4; ++r) { acc[r] = t0[r]; acc[4 + r] = t1[r]; }
@@ -328,7 +254,7 @@ __device__ __forceinline__ void dense_x_out(Ctx &cx, St &st, Blk *in0, f32x16 &a
     }(std::make_integer_sequence<int, (AP < TOTAL ? AP : TOTAL)>{});
     fence();
     auto step = [&]<int I>() {
-        wait_lgkm<2 * ((TOTAL - 1 - I) < (AP - 1) ? (TOTAL - 1 - I) : (AP - 1))>();
+        wait_retire<2 * ((TOTAL - 1 - I) < (AP - 1) ? (TOTAL - 1 - I) : (AP - 1))>(ah[I % AP], al[I % AP]);
         fence();
         const Blk &x = in0[I >> 1];
         auto ticks = [&]<int J>() {      // the previous layer's last tile -> in0[K0-1], before step 2 (K0 - 1) reads it

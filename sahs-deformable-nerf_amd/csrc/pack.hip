@@ -119,6 +119,7 @@ __global__ void pack_stream_bf16_kernel(const float *__restrict__ flat, float *_
     }
 }
 
+#ifdef SAHS_AB_KERNELS
 // ---- bf16 stream for field_bf16q.hip (v_mfma_f32_16x16x32_bf16): same sizes and chunking as the bf16 stream, another order inside a tile:
 // fragment 2b + rt of a tile = rows 16 rt .. + 15 x k-block b; lane l holds row l & 15, element j <-> feature 32 b + 16 (j >> 2) + 4 (l >> 4) + (j & 3)
 __global__ void pack_stream_bf16q_kernel(const float *__restrict__ flat, float *__restrict__ packed)
@@ -160,6 +161,7 @@ __global__ void pack_stream_bf16q_kernel(const float *__restrict__ flat, float *
         *reinterpret_cast<uint4 *>(out + hw) = q;
     }
 }
+#endif
 
 // ---- bf16x3 stream (field_bf16x3.hip): the bf16 stream with every fragment followed by the fragment of the remainders w - bf16(w) ----
 __global__ void pack_stream_bf16x3_kernel(const float *__restrict__ flat, float *__restrict__ packed)
@@ -333,6 +335,7 @@ extern "C" int SAHS_SYM(sahs_pack_weights_bf16_launch)(const float *flat, float 
     return (int)hipGetLastError();
 }
 
+#ifdef SAHS_AB_KERNELS
 extern "C" int SAHS_SYM(sahs_pack_weights_bf16q_launch)(const float *flat, float *packed, hipStream_t stream)
 {
     pack_stream_bf16q_kernel<<<1024, 256, 0, stream>>>(flat, packed);
@@ -340,6 +343,7 @@ extern "C" int SAHS_SYM(sahs_pack_weights_bf16q_launch)(const float *flat, float
     pack_table_bf16_kernel<<<1, 64, 0, stream>>>(packed);
     return (int)hipGetLastError();
 }
+#endif
 
 // [grid fp32 channel-last][hi/lo streams of both levels] for field_bf16x3.hip
 extern "C" int SAHS_SYM(sahs_pack_weights_bf16x3_launch)(const float *flat, float *packed, hipStream_t stream)

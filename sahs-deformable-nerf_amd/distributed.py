@@ -48,6 +48,37 @@ def all_gather_rows(rows, num_rays, group=None):
     return torch.cat([full[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
 
 
+def all_gather_rows_inplace(full, num_rays, group=None):
+    """``full`` is the (num_rays, C) frame buffer of which THIS rank has filled rows [lo, hi) = shard_bounds(...): one all-gather
+    completes it on every rank.  Equal shards: the send buffer is the rank's own slice of the receive buffer (the in-place form NCCL /
+    RCCL document -- sendbuff == recvbuff + rank * sendcount -- and gloo accepts), so no staging copy exists; ragged shards go through
+    the padded gather of all_gather_rows."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return full
+    rank = dist.get_rank(group)
+    lo, hi = shard_bounds(num_rays, world, rank)
+    if num_rays % world == 0 and full.is_contiguous():
+        dist.all_gather_into_tensor(full, full[lo:hi], group=group)
+        return full
+    full.copy_(all_gather_rows(full[lo:hi].contiguous(), num_rays, group))
+    return full
+
+
+def render_rows_sharded(render_block, num_rays, device, group=None, columns=OUT_COLUMNS):
+    """The ray-sharded frame: allocate the (num_rays, columns) frame buffer, let ``render_block(lo, hi, rows)`` fill
+    THIS rank's contiguous ray block [lo, hi) in place (``rows`` = the buffer's row slice; draws must be keyed by global ray index so
+    the frame does not depend on the number of ranks), then one all-gather.  Without an initialised process group: one block, no
+    collective.  train_utils.run_one_iter_of_nerf(_shard=...) and bench.py's N > 1 step are this function."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_bounds(num_rays, world, rank)
+    full = torch.empty(num_rays, columns, dtype=torch.float32, device=device)
+    if hi > lo:
+        render_block(lo, hi, full[lo:hi])
+    return all_gather_rows_inplace(full, num_rays, group)
+
+
 def render_sharded(render_fn, num_rays, group=None):
     """render_fn(lo, hi) -> 8-tuple for rays [lo, hi); returns the full-frame 8-tuple on every rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1

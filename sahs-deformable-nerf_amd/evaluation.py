@@ -4,6 +4,7 @@
 (:526-545, ``nerf/utils.py:112-140``), running mean seconds per image (:554).  Dataset readers (cv2/imageio, no data offline)
 are out of scope: frames are handed in as dicts of tensors.
 """
+import contextlib
 import os
 import time
 
@@ -11,7 +12,7 @@ import numpy as np
 import torch
 
 from .nerf_helpers import get_ray_bundle
-from .train_utils import run_one_iter_of_nerf
+from .train_utils import partition_invariant_rng, run_one_iter_of_nerf
 
 # class index -> colour as written to disk (nerf/utils.py:122-135 reverses each RGB triple before use)
 SEG_COLOURS = [(0, 0, 0), (0, 0, 204), (0, 153, 76), (0, 204, 204), (255, 51, 51), (255, 255, 0), (0, 51, 102), (0, 204, 102),
@@ -78,17 +79,24 @@ def _save_png(path, arr):
     Image.fromarray(arr).save(path)
 
 
-def render_frames(model, cfg, frames, hwf, background=None, pose_c=None, savedir=None, save_disparity=False, log=print):
+def render_frames(model, cfg, frames, hwf, background=None, pose_c=None, savedir=None, save_disparity=False, log=print, shard=None):
     """frames: iterable of dict(pose (3|4,4), audio (16,29) [AudioFaceModel] or expression (76,) [NeRFaceModel], mask (H,W,12)
     optional, name optional).
-    hwf = (H, W, intrinsics[fx, fy, cx, cy]).  Returns the list of per-frame outputs (dicts of tensors)."""
+    hwf = (H, W, intrinsics[fx, fy, cx, cy]).  Returns the list of per-frame outputs (dicts of tensors).
+    shard (True | process group): the node renders each frame together -- every rank (one process per GPU, torch.distributed
+    initialised, the same frames on every rank) renders its block of the frame's rays and one RCCL all-gather assembles the frame on
+    all of them (run_one_iter_of_nerf(_shard=...)); rank 0 writes the images.  The draws of frame i are keyed by (randomseed + i, global
+    ray index), so the images do not depend on the number of GPUs; shard=None keeps the reference's torch.rand stream."""
     H, W, focal = hwf
     results, times = [], []
     dev = next(model.parameters()).device
     bg = background.reshape(-1, 15).to(dev) if background is not None else None
+    sharded = shard is not None and shard is not False
+    writer = not (sharded and torch.distributed.is_initialized() and torch.distributed.get_rank(None if shard is True else shard) != 0)
     for i, fr in enumerate(frames):
         t0 = time.time()
-        with torch.no_grad():
+        keyed = partition_invariant_rng(int(cfg.experiment.randomseed) + i) if sharded else contextlib.nullcontext()
+        with torch.no_grad(), keyed:
             pose = torch.as_tensor(fr["pose"], dtype=torch.float32, device=dev)[:3, :4].contiguous()
             audio = torch.as_tensor(fr["audio"] if "audio" in fr else fr["expression"], dtype=torch.float32, device=dev)
             mask = fr.get("mask")
@@ -96,12 +104,12 @@ def render_frames(model, cfg, frames, hwf, background=None, pose_c=None, savedir
             ro, rd = get_ray_bundle(H, W, focal, pose)
             rgb_c, disp_c, _, rgb_f, disp_f, _, w_bg, depth_f = run_one_iter_of_nerf(
                 H, W, focal, model, ro, rd, cfg, mode="validation", driving=audio, pose=pose, pose_c=pose_c, background_prior=bg,
-                latent_code=None, inHead=mask)
+                latent_code=None, inHead=mask, _shard=shard if sharded else None)
             rgb = rgb_f if rgb_f is not None else rgb_c
             normals = normal_map(disp_f, focal, w_bg, clean=True)
         torch.cuda.synchronize() if dev.type == "cuda" else None
         times.append(time.time() - t0)
-        if savedir:
+        if savedir and writer:
             name = str(fr.get("name", "f_%04d.png" % i)).split("/")[-1].split(".")[0] + ".png"
             _save_png(os.path.join(savedir, name), cast_to_image(rgb[..., :3]))
             _save_png(os.path.join(savedir, "masks", name), cast_to_image(label2color(rgb[..., 3:])))

@@ -16,9 +16,9 @@ import torch
 from . import _lib
 from ._lib import SAHS_F32, SAHS_BF16, SAHS_BF16_2W, SAHS_BF16X3, SAHS_BF16_Q, check
 
-PRECISIONS = {"fp32": SAHS_F32, "f32": SAHS_F32, "bf16": SAHS_BF16, "bf16_2w": SAHS_BF16_2W,      # bf16_2w: the round-1 kernel, A/B reference
-              "bf16q": SAHS_BF16_Q,     # bf16 on the 16x16x32 MFMA shape (the shape holds a higher clock under load)
+PRECISIONS = {"fp32": SAHS_F32, "f32": SAHS_F32, "bf16": SAHS_BF16,
               "bf16x3": SAHS_BF16X3}    # near-fp32 on the bf16 pipe: radiance nets with hi + lo bf16 operands (3 MFMAs per product), deformation nets fp32
+AB_PRECISIONS = {"bf16_2w": SAHS_BF16_2W, "bf16q": SAHS_BF16_Q}    # development A/B builds only (tools/cmp_*.py); the shipped library rejects them
 
 
 def is_mixed(arch, precision):
@@ -183,10 +183,12 @@ def resample_merge(z, weights, num_fine, u=None):
 FIELD_ALL, FIELD_DEFORM, FIELD_RADIANCE = 0, 1, 2
 
 
-def field_forward_split(packed, frame, level, mode, rays, xw, z=None, src=None, xw_col0=0, out=None, arch="audio", precision=SAHS_F32):
+def field_forward_split(packed, frame, level, mode, rays, xw, z=None, src=None, xw_col0=0, out=None, arch="audio", precision=SAHS_F32,
+                        validate_src=False):
     """The field in parts (include/sahs_nerf.h: sahs_model_field_forward_split).  xw: (N, row, 8) fp32 buffer of deformed points.
     FIELD_ALL: raw (N,S,16) for depths z, x'/w of its samples written to xw[:, xw_col0:xw_col0+S]; FIELD_DEFORM: only x'/w for depths z;
-    FIELD_RADIANCE: raw for the samples xw[ray, src[ray, s]] (src (N,S) int32)."""
+    FIELD_RADIANCE: raw for the samples xw[ray, src[ray, s]] (src (N,S) int32).  The kernel does not range-check src (precondition of the
+    C ABI: 0 <= src < xw.shape[1]); validate_src=True checks a caller-made permutation here (one device reduction + sync)."""
     packed, frame, rays, z = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays"), _req(z, "z")
     src = _req(src, "src", torch.int32)
     xw = _req(xw, "xw")
@@ -194,6 +196,10 @@ def field_forward_split(packed, frame, level, mode, rays, xw, z=None, src=None, 
     S = src.shape[1] if mode == FIELD_RADIANCE else z.shape[1]
     if xw.dim() != 3 or xw.shape[0] != N or xw.shape[2] != 8:
         raise _lib.SahsError("xw must be (N, row, 8)")
+    if src is not None and (src.dim() != 2 or src.shape[0] != N):
+        raise _lib.SahsError("src must be (N, S)")
+    if validate_src and src is not None and src.numel() and not (0 <= int(src.min()) and int(src.max()) < xw.shape[1]):
+        raise _lib.SahsError("src indexes outside xw's %d slots per ray" % xw.shape[1])
     raw = None
     if mode != FIELD_DEFORM:
         raw = out if out is not None else torch.empty(N, S, 16, dtype=torch.float32, device=rays.device)
@@ -298,7 +304,7 @@ def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=
     mixed = is_mixed(arch, precision)      # fp32 deformation nets + low-precision radiance nets: only the split chain exists
     if mixed and not (share_deformation and num_fine > 0):
         raise _lib.SahsError("a mixed-precision model renders through the split chain (share_deformation=True, num_fine > 0)")
-    if share_deformation and num_fine > 0 and arch != "nerface_static" and precision in (SAHS_F32, SAHS_BF16, SAHS_BF16X3, SAHS_BF16_Q):
+    if share_deformation and num_fine > 0 and arch != "nerface_static" and precision in (SAHS_F32, SAHS_BF16, SAHS_BF16X3, SAHS_BF16_Q):      # (_Q: A/B builds)
         # extra workspace of the split evaluation: deformed points of every depth, the merge permutation, the new depths
         xw, z_new = buf("xw", N, Sf, 8), buf("z_new", N, num_fine)
         src = ws.get("src")
@@ -309,6 +315,37 @@ def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=
             int(bool(lindisp)), int(bool(white_background)), _p(bg), _p(t_rand), _p(noise_c), _p(u), _p(noise_f),
             _p(z_c), _p(z_f), _p(raw), _p(weights), _p(rows), int(rows.stride(0)), _p(xw), _p(src), _p(z_new), _stream()), name)
     return rows
+
+
+class LaunchProbe:
+    """HIP events around every FIELD-kernel launch the library makes on this thread while the block is open (include/sahs_nerf.h:
+    sahs_probe_*), recorded on the launch stream: per-kernel times of the product's own call chain (bench.py's roofline).
+    ``records()`` -> list of dict(model, level, part (0 whole network | 1 deformation nets | 2 radiance nets), precision (of the kernel
+    launched), samples, ms); it waits for the probed launches to finish."""
+
+    def __init__(self, capacity=4096):
+        self.capacity = int(capacity)
+
+    def __enter__(self):
+        check(_lib.lib().sahs_probe_arm(self.capacity), "sahs_probe_arm")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().sahs_probe_disarm()
+        return False
+
+    @staticmethod
+    def records():
+        L = _lib.lib()
+        if L.sahs_probe_dropped():
+            raise _lib.SahsError("launch probe overflow: %d launches were not recorded" % L.sahs_probe_dropped())
+        out = []
+        kind, samples, ms = ctypes.c_int(), ctypes.c_long(), ctypes.c_float()
+        for i in range(L.sahs_probe_count()):
+            check(L.sahs_probe_read(i, ctypes.byref(kind), ctypes.byref(samples), ctypes.byref(ms)), "sahs_probe_read")
+            k = kind.value
+            out.append(dict(model=ARCHS[k >> 16], level=(k >> 12) & 15, part=(k >> 8) & 15, precision=k & 255, samples=samples.value, ms=ms.value))
+        return out
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -352,9 +389,10 @@ def field_forward_split_save(packed, frame, level, mode, rays, xw, z=None, src=N
     return raw, act
 
 
-def field_backward_split(flat, frame, level, part, act, grad_flat, grad_cond, d_raw=None, xw_grad_in=None, want_xw_grad=False, arch="audio"):
+def field_backward_split(flat, frame, level, part, act, grad_flat, grad_cond, d_raw=None, xw_grad_in=None, arch="audio"):
     """Backward of `part` (FIELD_DEFORM, FIELD_RADIANCE, or 3 = everything) of the field over activations saved by the forward of that
-    part.  The seam is d loss / d (x', w), (P,8): FIELD_RADIANCE returns it, FIELD_DEFORM starts from xw_grad_in, 3 adds xw_grad_in."""
+    part.  The seam is d loss / d (x', w), (P,8): FIELD_RADIANCE returns it (the only part that writes one), FIELD_DEFORM starts from
+    xw_grad_in, 3 adds xw_grad_in."""
     flat, frame, act = _req(flat, "flat_params"), _req(frame, "frame"), _req(act, "act")
     d_raw, xw_grad_in = _req(d_raw, "d_raw"), _req(xw_grad_in, "xw_grad_in")
     P = act.shape[0]
@@ -362,7 +400,7 @@ def field_backward_split(flat, frame, level, part, act, grad_flat, grad_cond, d_
         raise _lib.SahsError("field_backward_split: the activations were not saved by a forward of part %d" % part)
     if xw_grad_in is not None and xw_grad_in.numel() != P * 8:
         raise _lib.SahsError("field_backward_split: xw_grad_in must hold (P,8)")
-    out = torch.empty(P, 8, dtype=torch.float32, device=act.device) if (part == FIELD_RADIANCE or want_xw_grad) else None
+    out = torch.empty(P, 8, dtype=torch.float32, device=act.device) if part == FIELD_RADIANCE else None
     ws = torch.empty(_fn("field_backward_workspace_words", arch)[0](P), dtype=torch.float32, device=act.device)
     f, name = _fn("field_backward_split", arch)
     check(f(_p(flat), _p(frame), int(level), int(part), P, _p(act), _p(d_raw), _p(xw_grad_in), _p(out), _p(grad_flat), _p(grad_cond), _p(ws), _stream()), name)

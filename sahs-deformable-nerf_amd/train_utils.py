@@ -103,11 +103,16 @@ def predict_and_render_radiance(ray_batch, model, options, mode="train", driving
 
 def run_one_iter_of_nerf(height, width, focal_length, model, ray_origins, ray_directions, options, mode="train", driving=None,
                          pose=None, pose_c=None, background_prior=None, latent_code=None, ray_directions_ablation=None,
-                         spatial_embeddings=None, inHead=None, _loss=None):
+                         spatial_embeddings=None, inHead=None, _loss=None, _shard=None):
     """train_utils.py:209-321.  height/width/focal_length are unused when dataset.no_ndc is True (as there).
     _loss (not in the reference): (target, mask, class_weights) of the Stage-I objective for a training batch that fits one ray
     chunk -> the 8-tuple is followed by (loss, stats), and the loss's gradient is formed inside the HIP backward
-    (training.train_step uses it; stats layout: ops.LOSS_STATS_WORDS)."""
+    (training.train_step uses it; stats layout: ops.LOSS_STATS_WORDS).
+    _shard (not in the reference; no-grad calls): True or a torch.distributed process group -- every rank is handed the SAME full frame and
+    renders only its contiguous block of the flattened ray list into its rows of the (R, 36) buffer, one in-place all-gather (RCCL on
+    GPUs) completes the buffer on every rank (distributed.render_rows_sharded), and every rank returns the full frame.  Draws are then
+    keyed by global ray index (partition_invariant_rng; entered with options.experiment.randomseed unless the caller already did), so
+    the frame is bit-identical for any number of ranks.  Without an initialised process group it is the single-process render."""
     if options.dataset.no_ndc is False:
         raise NotImplementedError("NDC rays: the reference's own no_ndc=False branch is dead (NameError at train_utils.py:263)")
     ro = ray_origins.reshape((-1, 3))
@@ -125,6 +130,8 @@ def run_one_iter_of_nerf(height, width, focal_length, model, ray_origins, ray_di
     # once per call (the reference recomputes it per point-chunk); the differentiable op folds the conditioning itself
     frame = None if needs_grad else model.frame(driving, pose)
     workspace = {}
+    if _shard is not None and _shard is not False and needs_grad:
+        raise ValueError("_shard is the inference path's ray sharding; a differentiable call shards its batch (training.train_step)")
     if _loss is not None:
         if not needs_grad or len(batches) != 1:
             raise ValueError("_loss needs a differentiable call whose rays fit one chunk (nerf.%s.chunksize)" % mode)
@@ -138,6 +145,27 @@ def run_one_iter_of_nerf(height, width, focal_length, model, ray_origins, ray_di
                                             _ray0=i * chunk)
                 for i, b in enumerate(batches)]
         images = [torch.cat(im, dim=0) if im[0] is not None else None for im in zip(*pred)]
+    elif _shard is not None and _shard is not False:
+        from . import distributed as D
+        if float(getattr(options.nerf, mode).radiance_field_noise_std) > 0.0:
+            raise NotImplementedError("ray sharding with radiance noise: the noise is torch.randn over a chunk (not keyed by ray); "
+                                      "training shards the batch instead (training.train_step)")
+        group = None if _shard is True else _shard
+
+        def render_block(lo, hi, rows):      # this rank's rays [lo, hi) in chunks of nerf.<mode>.chunksize, written in place
+            for s0 in range(lo, hi, chunk):
+                e0 = min(hi, s0 + chunk)
+                predict_and_render_radiance(rays[s0:e0], model, options, mode, driving=driving, pose=pose, pose_c=pose_c,
+                                            background_prior=background_prior[s0:e0] if background_prior is not None else None,
+                                            latent_code=latent_code, _frame=frame, _workspace=workspace if e0 - s0 == chunk or hi - lo <= chunk else None,
+                                            _ray0=s0, _rows=rows[s0 - lo:e0 - lo])
+
+        keyed = contextlib.nullcontext() if _RAY_RNG is not None else partition_invariant_rng(int(options.experiment.randomseed))
+        with keyed:
+            rows = D.render_rows_sharded(render_block, rays.shape[0], rays.device, group, ops.ROW_COLUMNS)
+        images = [c.contiguous() for c in unpack_rows(rows)]
+        if int(getattr(options.nerf, mode).num_fine) == 0:
+            images[3] = images[4] = images[5] = None
     else:
         # every chunk writes its rays' 8-tuples straight into its row block of ONE (R, 36) buffer (the reference concatenates
         # eight lists of per-chunk tensors, train_utils.py:298-301)

@@ -28,9 +28,9 @@ def psnr(a, b):
     return 99.0 if mse == 0 else -10.0 * np.log10(mse)
 
 
-# per-variant bounds on the bf16 field error against the fp32 oracle: ~3x the observed values (gpurun_out/bf16_field_stats.json,
-# printed by the test): dx max, rgb/seg logit rms, density logit rms relative to its mean magnitude
-BF16_BOUNDS = {"boosted": dict(dx_max=2e-3, col_rms=3e-4, sig_rel=5e-3), "hdr": dict(dx_max=2e-3, col_rms=1.5e-1, sig_rel=6e-2)}
+# per-variant bounds on the bf16 field error against the fp32 oracle: 3x the observed values (printed by the test; round 2, hdr: colour
+# logit rms 0.027, density rms 0.19 on a mean magnitude of ~10): dx max, rgb/seg logit rms, density logit rms relative to its mean magnitude
+BF16_BOUNDS = {"boosted": dict(dx_max=2e-3, col_rms=3e-4, sig_rel=5e-3), "hdr": dict(dx_max=2e-3, col_rms=8.1e-2, sig_rel=6e-2)}
 
 
 @pytest.mark.parametrize("variant", ["boosted", "hdr"])
@@ -65,8 +65,6 @@ def test_bf16_field_vs_oracle(flat_weights, variant):
                             grid_max=float(np.abs(grid.view(-1, 32).cpu().numpy() - rgrid).max()))
         stats[level]["col_scale"] = float(np.sqrt((ref[:, :15] ** 2).mean()))
         assert np.isfinite(raw).all()
-    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-    json.dump(stats, open(os.path.join(REPO, "gpurun_out", "bf16_field_stats_%s.json" % variant), "w"), indent=1)
     print(variant, json.dumps(stats))
     b = BF16_BOUNDS[variant]
     for level in (0, 1):
@@ -103,10 +101,8 @@ def test_bf16_full_frame_psnr(weights_mod):
                max_abs_rgb=float((rgb16 - rgb32).abs().max()), seg_max_abs=float((o16[3][..., 3:] - o32[3][..., 3:]).abs().max()),
                depth_max_abs=float((o16[7] - o32[7]).abs().max()), acc_max_abs=float((o16[5] - o32[5]).abs().max()))
     res["delta_psnr"] = abs(res["psnr_bf16_vs_target"] - res["psnr_fp32_vs_target"])
-    json.dump(res, open(os.path.join(REPO, "gpurun_out", "bf16_psnr.json"), "w"), indent=1)
     print(json.dumps(res))
     res["w_bg_mean"] = float(o32[6].mean())
-    json.dump(res, open(os.path.join(REPO, "gpurun_out", "bf16_psnr.json"), "w"), indent=1)
     assert 0.02 < res["w_bg_mean"] < 0.9, "the volume must be semi-transparent for the protocol to mean anything"
     assert res["delta_psnr"] <= 0.05, res      # north_star: PSNR within 0.05 dB of the reference
     assert res["psnr_bf16_vs_fp32"] > 35.0, res
@@ -146,7 +142,6 @@ def test_bf16x3_field_vs_oracle(flat_weights, variant):
                             col_scale=float(np.sqrt((ref[:, :15] ** 2).mean())), sig_max=float(e_sig.max()),
                             sig_rms=float(np.sqrt((e_sig ** 2).mean())), sig_scale=float(np.abs(ref[:, 15]).mean()))
         assert np.isfinite(raw).all()
-    json.dump(stats, open(os.path.join(REPO, "gpurun_out", "bf16x3_field_stats_%s.json" % variant), "w"), indent=1)
     print(variant, json.dumps(stats))
     for level in (0, 1):
         st = stats[level]
@@ -207,37 +202,3 @@ def test_bf16x3_frame_vs_fp32_within_4x_of_its_tolerance(weights_mod):
     for nm, a, b in zip(("rgb", "disp", "acc", "weights", "depth"), res["fp32"], res["bf16x3"]):
         a, b = a.reshape(N, -1), b.reshape(N, -1)
         assert bool(((a - b).abs() <= 4e-5 + 4e-4 * a.abs()).all()), (nm, float((a - b).abs().max()))
-
-
-def test_bf16q_matches_bf16_kernel(weights_mod):
-    """precision "bf16q" (the bf16 field kernel on v_mfma_f32_16x16x32_bf16, field_bf16q.hip) against the shipped bf16 kernel: same
-    products and roundings in another summation order -- the deformation outputs agree to fp32 rounding of the accumulations amplified by
-    bf16 re-rounding, the raw output to bf16 level; deterministic; whole-network entry point == split chain; the radiance launch follows a
-    merge permutation.  One workgroup first (a new kernel meets the GPU on a tiny case), then several, then a ragged size."""
-    ops = pkg("ops")
-    d = dev()
-    flat = T(weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 2.0, 30.0, hdr=True)))
-    rng = np.random.default_rng(0)
-    frame = ops.fold_conditioning(flat, T(rng.standard_normal((16, 29)).astype(np.float32)),
-                                  T(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32)))
-    packs = {k: ops.pack_weights(flat, ops.PRECISIONS[k]) for k in ("fp32", "bf16", "bf16q")}
-    for N, S in ((2, 64), (37, 128), (301, 77)):
-        g = torch.Generator(device=d).manual_seed(N * 1000 + S)
-        rays = torch.zeros(N, 8, device=d)
-        rays[:, 2] = 0.8
-        rays[:, 3:6] = torch.randn(N, 3, device=d, generator=g) * 0.15 + torch.tensor([0, 0, -1.0], device=d)
-        z = torch.sort(torch.rand(N, S, device=d, generator=g) * 0.6 + 0.48, dim=1).values
-        out, xws = {}, {}
-        for k in ("fp32", "bf16", "bf16q"):
-            xw = torch.zeros(N, S, 8, device=d)
-            out[k] = ops.field_forward_split(packs[k], frame, 1, ops.FIELD_ALL, rays, xw, z=z, precision=ops.PRECISIONS[k])
-            xws[k] = xw
-        assert bool(torch.isfinite(out["bf16q"]).all())
-        err_w, err_q = (out["bf16"] - out["fp32"]).abs(), (out["bf16q"] - out["fp32"]).abs()
-        assert float(err_q.max()) <= 1.5 * float(err_w.max()) + 1e-3 and float((err_q ** 2).mean().sqrt()) <= 1.3 * float((err_w ** 2).mean().sqrt()) + 1e-4
-        assert float((xws["bf16q"] - xws["fp32"]).abs().max()) <= 1.5 * float((xws["bf16"] - xws["fp32"]).abs().max()) + 1e-4
-        plain = ops.field_forward(packs["bf16q"], frame, 1, rays, z, precision=ops.PRECISIONS["bf16q"])
-        assert torch.equal(plain, out["bf16q"])                       # deterministic, and the plain entry point is the split chain's launch
-        src = torch.arange(S - 1, -1, -1, device=d, dtype=torch.int32).repeat(N, 1).contiguous()
-        rad = ops.field_forward_split(packs["bf16q"], frame, 1, ops.FIELD_RADIANCE, rays, xws["bf16q"], src=src, precision=ops.PRECISIONS["bf16q"])
-        assert torch.equal(rad, out["bf16q"].flip(1))

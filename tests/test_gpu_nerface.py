@@ -43,8 +43,10 @@ def test_sizes_and_errors(ops):
     assert ops.param_count("nerface") == 2_311_140 and ops.param_count() == 2_775_633 and ops.param_count("nerface_static") == 2_066_976
     with pytest.raises(Exception):
         ops.pack_weights(torch.zeros(2_775_633, device=dev()), arch="nerface")        # the audio model's buffer
-    with pytest.raises(Exception):      # no round-1 bf16 kernel for these models
-        ops.pack_weights(torch.zeros(2_066_976, device=dev()), precision=ops.SAHS_BF16_2W, arch="nerface_static")
+    with pytest.raises(Exception):      # the A/B precision ids (development builds) are not in the shipped library
+        ops.pack_weights(torch.zeros(2_066_976, device=dev()), precision=2, arch="nerface_static")
+    with pytest.raises(Exception):
+        ops.pack_weights(torch.zeros(2_775_633, device=dev()), precision=4)
     with pytest.raises(Exception):      # the mixed-precision model's whole-network entry point needs the split chain's workspace
         ops.field_forward(ops.pack_weights(torch.zeros(2_311_140, device=dev()), precision=ops.SAHS_BF16, arch="nerface"),
                           torch.zeros(16384, device=dev()), 0,
@@ -163,7 +165,7 @@ def test_model_seam_and_config_guard(nf):
     close(raw[:, :15], g["boosted_raw_coarse"][:, :15], 2e-3, 2e-3, "model(...) seam")
     with pytest.raises(NotImplementedError):
         sahs.NeRFaceModel(sahs.default_config("audio"))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises((NotImplementedError, KeyError)):
         sahs.NeRFaceModel(cfg, precision="bf16_2w")
     assert sahs.NeRFaceModel(cfg, precision="bf16").precision == pkg("ops").SAHS_BF16
 

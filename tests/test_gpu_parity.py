@@ -194,6 +194,11 @@ def test_resample_bit_exact_vs_oracle(ops, tag):
     assert np.array_equal(ginds.cpu().numpy(), inds)
     assert np.array_equal(gzs.cpu().numpy(), zs)
     assert np.array_equal(z_out.cpu().numpy(), zsorted)
+    # ... and against the REFERENCE itself (ATen's searchsorted / cumsum / sum / linspace on the same inputs): indices, samples and merged
+    # depths bit for bit in both modes (north_star: "bit-exact for sample indices"; det=True puts u = 1.0 on the last cdf knot of every ray)
+    assert np.array_equal(ginds.cpu().numpy(), g[tag + "_inds"])
+    assert np.array_equal(gzs.cpu().numpy(), g[tag + "_samples"])
+    assert np.array_equal(z_out.cpu().numpy(), g[tag + "_z_sorted"])
     # and the plain sample_pdf_2 seam
     bins = 0.5 * (g["z"][:, 1:] + g["z"][:, :-1])
     s2, i2 = ops.sample_pdf(T(bins), T(g["weights"][:, 1:-1].copy()), 64, u=None if u is None else T(u), want_inds=True)
@@ -281,8 +286,10 @@ def test_model_seam_matches_driver(flat_weights):
     assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(k, tuple(s)) for k, s in W.canonical_spec()]
 
 
-def test_full_frame_properties(flat_weights):
-    """BASELINE size (512x512, 64+128): size-independent properties + a sampled oracle check.
+@pytest.mark.parametrize("variant", ["hdr", "boosted"])
+def test_full_frame_properties(flat_weights, variant):
+    """BASELINE size (512x512, 64+128): size-independent properties + a sampled oracle check at SURVEY.md section 8d's tolerance
+    (rtol 1e-4 / atol 1e-5) on the high-dynamic-range network (the one on which parity bites) and the density-boosted one.
 
     (1) partition invariance: rendering a contiguous 1/8 slice of the rays alone gives bit-identical
         results to the same rays inside the full frame (the multi-GPU sharding relies on it);
@@ -293,7 +300,7 @@ def test_full_frame_properties(flat_weights):
     ops = pkg("ops")
     cfg = sahs.default_config()
     H = W = 512
-    fw = flat_weights(density_bias=8.0, density_gain=30.0)
+    fw = flat_weights(**VARIANT_KW[variant])
     model = sahs.AudioFaceModel(cfg).to(dev())
     model.load_flat(fw)
     rng = np.random.default_rng(5)
@@ -325,8 +332,18 @@ def test_full_frame_properties(flat_weights):
     sel = np.linspace(0, R - 1, 48).astype(np.int64)
     ref = oracle.render_rays(fw, rays[sel].cpu().numpy(), 64, 64, oracle.audionet(fw, audio), oracle.pose_encoding(pose),
                              bg=bg[sel].cpu().numpy(), t_rand=t_rand[sel].cpu().numpy(), u=u[sel].cpu().numpy())
-    for nm, o in zip(["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"], full):
-        close(o[sel], ref[nm], 2e-3, 2e-4, "full-frame sample:" + nm)
+    # HIP and oracle share the summation order, so they agree far inside the fp32 tolerance; on the hdr network a ray may still place one
+    # resampled depth on the other side of a cdf knot (sin/cos of the device vs libm: 1e-7 in raw -> 1e-5 in a coarse weight), which moves
+    # that ray's fine outputs by ~1e-3: at most 1 of the 48 rays may do so, the coarse outputs of every ray must agree
+    names = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"]
+    bad = np.zeros(len(sel), bool)
+    for nm, o in zip(names, full):
+        a, b = o[sel].cpu().numpy().reshape(len(sel), -1).astype(np.float64), ref[nm].reshape(len(sel), -1).astype(np.float64)
+        ok = (np.abs(a - b) <= 1e-5 + 1e-4 * np.abs(b)).all(axis=1)
+        assert nm.endswith("_f") or nm in ("w_bg",) or ok.all(), ("full-frame sample: coarse output " + nm, float(np.abs(a - b).max()))
+        bad |= ~ok
+    assert bad.sum() <= (1 if variant == "hdr" else 0), ("full-frame sample: rays outside rtol 1e-4 / atol 1e-5", int(bad.sum()))
+    assert float(full[6].mean()) < 0.5, "the workload must spread its weight over the samples (mean background weight %.3f)" % float(full[6].mean())
 
 
 def test_gradients_vs_golden(flat_weights, weights_mod):
@@ -415,6 +432,37 @@ def test_partition_invariant_render(flat_weights):
         assert torch.equal(a, chunked[i].reshape(144, -1)), i
         assert torch.equal(a, torch.cat([p[i].reshape(p[i].shape[0] if p[i].dim() else 1, -1) for p in parts], 0).reshape(144, -1)), i
     assert not torch.equal(full[3], other[3])
+
+
+def test_sharded_driver_and_launch_probe(flat_weights):
+    """run_one_iter_of_nerf(_shard=True) without a process group is the single-process render under keyed draws (the function every
+    rank of a multi-GPU run executes on its block: tests/test_gpu_sharded.py runs it on two ranks); the launch probe sees its field
+    launches: per chunk whole network (coarse), deformation nets (new depths), radiance nets (all fine samples), on the launch stream."""
+    sahs, ops, TU = pkg(), pkg("ops"), pkg("train_utils")
+    cfg = sahs.default_config()
+    cfg.nerf.validation.chunksize = 100
+    model = sahs.AudioFaceModel(cfg).to(dev()).load_flat(flat_weights(**VARIANT_KW["hdr"]))
+    g = load_golden("e2e_boosted_val")
+    pose = T(g["pose"])
+    H, Wd = 12, 12
+    ro, rd = sahs.get_ray_bundle(H, Wd, g["intrinsics"], pose)
+    kw = dict(mode="validation", driving=T(g["audio"]), pose=pose, background_prior=T(g["bg"]))
+    with torch.no_grad():
+        with TU.partition_invariant_rng(int(cfg.experiment.randomseed)):
+            plain = sahs.run_one_iter_of_nerf(H, Wd, g["intrinsics"], model, ro, rd, cfg, **kw)
+        with ops.LaunchProbe(64) as probe:
+            shard = sahs.run_one_iter_of_nerf(H, Wd, g["intrinsics"], model, ro, rd, cfg, _shard=True, **kw)     # enters the keyed draws itself
+            recs = probe.records()
+        ops.field_forward(model.packed()[0], model.frame(T(g["audio"]), pose), 0, torch.zeros(4, 8, device=dev()), torch.zeros(4, 1, device=dev()))
+        assert len(ops.LaunchProbe.records()) == len(recs), "a disarmed probe records nothing"
+    for a, b in zip(plain, shard):
+        assert torch.equal(a, b)
+    assert [(r["part"], r["level"], r["samples"]) for r in recs] == [(0, 0, 100 * 64), (1, 1, 100 * 64), (2, 1, 100 * 128),
+                                                                     (0, 0, 44 * 64), (1, 1, 44 * 64), (2, 1, 44 * 128)]
+    assert all(r["model"] == "audio" and r["precision"] == ops.SAHS_F32 and 0.0 < r["ms"] < 1000.0 for r in recs)
+    model.train()
+    with pytest.raises(ValueError):       # a differentiable call does not shard rays (training shards its batch)
+        sahs.run_one_iter_of_nerf(H, Wd, g["intrinsics"], model, ro, rd, cfg, _shard=True, **dict(kw, mode="train"))
 
 
 @pytest.mark.parametrize("arch,N,nf,precision", [("audio", 300, 64, "fp32"), ("audio", 77, 128, "fp32"), ("nerface", 130, 64, "fp32"),

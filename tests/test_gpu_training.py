@@ -79,8 +79,6 @@ def test_train_step_2048_rays_vs_eager_autograd(weights_mod):
         assert err <= 2e-2, "%s: %.3e of scale" % (k, err)
     res = dict(rays=R, hip_step_s=t_hip, eager_step_s=t_eager, hip_rays_per_s=R / t_hip, eager_rays_per_s=R / t_eager,
                speedup=t_eager / t_hip, worst_grad_err_rel_scale=worst)
-    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-    json.dump(res, open(os.path.join(REPO, "gpurun_out", "train_step.json"), "w"), indent=1)
     print(json.dumps(res))
 
 
@@ -158,8 +156,6 @@ def test_train_step_vs_reference_fixture(flat_weights, fused):
                grad_norm_err=worst_norm, grad_norm_err_ref=ref_norm_err, grad_entry_err=worst_entry, grad_entry_err_ref=ref_entry,
                grad_audio_err=e_audio, grad_audio_err_ref=ref_audio)
     print(json.dumps(res))
-    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-    json.dump(res, open(os.path.join(REPO, "gpurun_out", "train_step_vs_reference%s.json" % ("_fused" if fused else "")), "w"), indent=1)
     assert worst_norm <= 2.0 * ref_norm_err + 1e-4, res
     assert worst_entry <= 2.0 * ref_entry + 1e-4, res
     assert e_audio <= 2.0 * ref_audio + 1e-4, res

@@ -1,16 +1,16 @@
 """On the MI355X: the HIP path against the plain PyTorch-ROCm eager restatement of the reference
 (oracle/torch_eager.py, pinned to the reference by test_torch_eager_vs_golden.py) on the full W512
-frame: image agreement (PSNR protocol of SURVEY.md section 8d) and the speed ratio that
-BASELINE.json's north_star targets.  Numbers are written to gpurun_out/eager_vs_hip.json."""
+frame on the HIGH-DYNAMIC-RANGE weights (mean background weight ~0.2: the rays spread their weight over
+the samples, so agreement is not vacuous): per-ray agreement of all 8 outputs, the PSNR protocol of
+SURVEY.md section 8d, and the speed ratio that BASELINE.json's north_star targets.  Numbers are printed."""
 import json
-import os
 import time
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, pkg
+from conftest import VARIANT_KW, pkg
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +27,7 @@ def test_full_frame_against_eager_pytorch(weights_mod):
     cfg = sahs.default_config()
     H = W = 512
     R = H * W
-    sd_np = weights_mod.hash_state_dict(0, 8.0, 30.0)
+    sd_np = weights_mod.hash_state_dict(**VARIANT_KW["hdr"])
     model = sahs.AudioFaceModel(cfg).to(dev).load_flat(weights_mod.flatten_state_dict(sd_np))
     field = TE.EagerField({k: torch.from_numpy(v).to(dev) for k, v in sd_np.items()})
     rng = np.random.default_rng(42)
@@ -74,10 +74,19 @@ def test_full_frame_against_eager_pytorch(weights_mod):
     res = dict(rays=R, hip_s=t_hip, eager_s=t_eager, hip_rays_per_s=R / t_hip, eager_rays_per_s=R / t_eager, speedup=t_eager / t_hip,
                psnr_hip_vs_eager=psnr(rgb_h, rgb_e), psnr_hip_vs_target=psnr(rgb_h, tgt), psnr_eager_vs_target=psnr(rgb_e, tgt),
                max_abs_rgb_diff=float((rgb_h - rgb_e).abs().max()), w_bg_mean=float(o_eager[6].mean()))
-    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(REPO, "gpurun_out", "eager_vs_hip.json"), "w") as f:
-        json.dump(res, f, indent=1)
+    # per-ray agreement on all 8 outputs.  The two fp32 implementations differ by ~1e-5 in the coarse weights; a resampled depth that
+    # thereby lands on the other side of a cdf knot moves that ray's fine outputs by up to a few 1e-2 on this network -- for the
+    # reference's own fp32 run against its float64 run as well (conftest.yardstick: outlier_rays) -- so the criterion is the one
+    # bench.py's cpu_baseline leg asserts: >= 99 % of the rays within 1e-3 on every output, none beyond 0.1, coarse outputs 1e-4.
+    worst, frac_ok = {}, 1.0
+    for nm, a, b in zip(["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"], o_hip, o_eager):
+        d = (a.reshape(R, -1) - b.reshape(R, -1)).abs().max(dim=1).values
+        worst[nm] = float(d.max())
+        frac_ok = min(frac_ok, float((d <= 1e-3).float().mean()))
+    res.update(rays_within_1e3=frac_ok, worst_abs_diff=worst)
     print(json.dumps(res))
+    assert frac_ok >= 0.99 and max(worst.values()) <= 0.1, res
+    assert max(worst[k] for k in ("rgb_c", "acc_c")) <= 1e-4, res
     assert res["psnr_hip_vs_eager"] > 60.0, res
     assert abs(res["psnr_hip_vs_target"] - res["psnr_eager_vs_target"]) <= 0.05, res
     assert res["w_bg_mean"] < 0.5, "workload must terminate rays before the background sample"

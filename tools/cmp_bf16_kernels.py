@@ -7,9 +7,16 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+# the A/B kernels (csrc/ab/) are not in the shipped library: this tool runs against a development build that has them
+AB_LIB = os.path.join(REPO, "sahs-deformable-nerf_amd", "build", "libsahs_ab.so")
+if not os.path.exists(AB_LIB):
+    importlib.import_module("sahs-deformable-nerf_amd.build").build(defines=["SAHS_AB_KERNELS"], out=AB_LIB)
+os.environ["SAHS_NERF_LIB"] = AB_LIB
 pkg = importlib.import_module("sahs-deformable-nerf_amd")
 ops, W = pkg.ops, pkg.weights
+ops.PRECISIONS = dict(ops.PRECISIONS, **ops.AB_PRECISIONS)
 dev = torch.device("cuda:0")
 flat = torch.from_numpy(W.flatten_state_dict(W.hash_state_dict(0, 2.0, 30.0, hdr=True))).to(dev)
 rng = np.random.default_rng(0)
