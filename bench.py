@@ -192,6 +192,7 @@ class ProductRenderer:
                  "launches": len(recs), "field_ms_per_step": field_ms / max(1, self.steps_timed), "field_time_share": field_ms * 1e-3 / dt,
                  "flop_per_sample": self.flop_per_sample, "flop_per_sample_executed": self.exec_flop_per_sample, "shared_deformation": self.split}
         if self.mixed:
+            chain["frac_executed"] = None       # two pipes at two rates: no single peak to price the executed work against
             chain["mixed_precision"] = ("fp32 deformation launches + low-precision radiance launches: the chain figures price both against the "
                                         "low-precision peak and are NOT a kernel roofline")
         rad = [r for r in recs if r["part"] == 2] or [r for r in recs if r["part"] == 0 and r["level"] == 1]

@@ -116,6 +116,12 @@ int sahs_field_forward_save(const void *packed, const float *frame, int level, l
  * grid) and grad_cond (+=: [0:76] d driving, [80:116] d pose encoding).  P = N*S samples, P <= 4e6 per call. */
 int sahs_field_backward(const float *flat_params, const float *frame, int level, long P, const float *act_in, const float *d_raw,
                         float *grad_flat, float *grad_cond, float *workspace, void *stream);
+/* Arithmetic of the backward's dense-layer GEMMs (dW = dY^T X, dX = dY W; every model).  SAHS_BF16X3 (default): operands split into bf16
+ * hi + lo on their way to the matrix pipe, three bf16 MFMAs per product, fp32 accumulation -- gradients within ~1e-5 of their scale of the
+ * f32 form, far inside what two correct fp32 forwards differ by at the (leaky-)ReLU kinks; SAHS_F32: f32 MFMAs, exact
+ * products (the A/B reference; SAHS_BWD_GEMM=f32 in the environment selects it at start-up).  precision < 0 queries.  Returns the
+ * setting in force, -1 for an unknown value.  Process-wide. */
+int sahs_backward_gemm_precision(int precision);
 /* backward of sahs_composite_forward: any of d_rgb (N,15), d_disp, d_acc, d_depth, d_wlast (N: gradient of weights[:, -1], the
  * driver's 7th output), d_weights (N,S: gradient of the whole weights output, for the volume_render_radiance_field seam) may
  * be NULL -> d_raw (N,S,16). */

@@ -62,6 +62,7 @@ int sahs_route_xw_grad_launch(long N, int Sc, int nf, const int *src, const floa
     int sahs_field_backward_split_launch##sfx(const float *flat, const float *frame, int level, int part, long P, const float *actbuf, \
                                               const float *d_raw, const float *xwg_in, float *xwg_out, float *grad_flat,            \
                                               float *grad_cond, float *ws, hipStream_t stream);                                     \
+    int sahs_bwd_gemm_precision_state##sfx(int set);                                                                                 \
     int sahs_field_backward_launch##sfx(const float *flat, const float *frame, int level, long P, const float *actbuf,              \
                                         const float *d_raw, float *grad_flat, float *grad_cond, float *ws, hipStream_t stream);     \
     int sahs_pack_weights_f32_launch##sfx(const float *flat, float *packed, hipStream_t stream);                                   \
@@ -327,6 +328,17 @@ int sahs_sample_pdf(long N, int nb, int ns, const float *bins, const float *weig
     REQUIRE(N >= 0 && nb >= 2 && nb < 256 && ns >= 1 && ns <= 256, "sahs_sample_pdf(shape: 2 <= nb < 256, 1 <= ns <= 256)");
     int e = sahs_resample_launch(N, nb + 1, ns, 0, bins, weights, u, samples, nullptr, (long long *)inds, nullptr, (hipStream_t)stream);
     return e ? hip_fail("sahs_sample_pdf", e) : 0;
+}
+
+int sahs_backward_gemm_precision(int precision)
+{
+    if (precision < 0) return sahs_bwd_gemm_precision_state(-1) ? SAHS_BF16X3 : SAHS_F32;
+    if (precision != SAHS_F32 && precision != SAHS_BF16X3) return -1;
+    const int v = precision == SAHS_BF16X3 ? 3 : 0;
+    sahs_bwd_gemm_precision_state(v);
+    sahs_bwd_gemm_precision_state_nf(v);
+    sahs_bwd_gemm_precision_state_ns(v);
+    return precision;
 }
 
 long sahs_act_words_per_sample(void) { return act::STRIDE; }

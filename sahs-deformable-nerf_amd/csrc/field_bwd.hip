@@ -196,12 +196,43 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(int M, int N, int K, cons
 // K-major tiles are XOR-swizzled by 16 floats on alternate rows (TA: k&1, !TA: (k>>2)&1 -- either way q&1 on the MFMA
 // side), so the four q groups of a ds_read_b32 hit two disjoint bank sets.
 // ------------------------------------------------------------------------------------------------
+// X3: the products on the bf16 matrix pipe at near-fp32 accuracy (the operand split of field_bf16x3.hip): every fp32 operand value is
+// split on its way from LDS to the MFMA into x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16-17 significant bits together) and a product
+// is three v_mfma_f32_32x32x16_bf16 with fp32 accumulation, a b ~= a_hi b_hi + a_hi b_lo + a_lo b_hi (the dropped a_lo b_lo term is ~2^-18
+// of the product).  One 16-sample (TA) / 16-feature (!TA) K-step of the LDS ring is exactly one MFMA k-depth; a wave's 64 x 64 block is
+// 2 x 2 tiles of 32 x 32, 12 MFMAs per K-step (384 matrix-pipe cycles against the 2048 of the 64 f32 MFMAs it replaces), so these GEMMs
+// turn from matrix-bound into HBM-bound; the ~100 VALU instructions of the splits per K-step ride in the slack.  Same tiles, ring,
+// epilogues and arguments as the f32 form (X3 = false), which stays selectable (SAHS_BWD_GEMM=f32) as the exact A/B reference.
 typedef __attribute__((address_space(3))) void *lds_void_t;
 typedef const __attribute__((address_space(1))) void *gbl_void_t;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int DST = 3;                        // ring depth
 constexpr int DTILE = GK * GT;                // floats per operand tile (8 KB)
 
-template <bool TA>
+// eight fp32 values (this lane's k = 8h .. 8h+7 of one row/column) -> the bf16x8 MFMA fragments of their hi and lo parts
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4_t &hi, u32x4_t &lo)
+{
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{x[2 * p], x[2 * p + 1]}, bf16x2_t));
+        hi[p] = h;
+        lo[p] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{x[2 * p] - __builtin_bit_cast(float, h << 16),
+                                                                             x[2 * p + 1] - __builtin_bit_cast(float, h & 0xffff0000u)}, bf16x2_t));
+    }
+}
+__device__ __forceinline__ f32x16_t mfma3(const u32x4_t &ah, const u32x4_t &al, const u32x4_t &bh, const u32x4_t &bl, f32x16_t c)
+{
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bl), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, bh), c, 0, 0, 0);
+    return c;
+}
+
+template <bool TA, bool X3>
 __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, const float *__restrict__ A, long lda,
                                                        const float *__restrict__ B, long ldb, float *__restrict__ C, long ldc, int mode,
                                                        const float *__restrict__ mask, long ldm, float slope, int kslab,
@@ -269,11 +300,34 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, cons
         colA[i] = TA ? ((((m >> 2) ^ ((q & 1) << 2)) << 2) + (m & 3)) : (m * GK + 4 * q);
         colB[i] = (((n >> 2) ^ ((q & 1) << 2)) << 2) + (n & 3);
     }
+    // X3: lane (r32, h) of a 32x32x16 MFMA supplies k = 8h .. 8h+7 of row/column r32 of a 32-wide tile.  K-major tiles are swizzled on
+    // alternate rows (TA: k & 1, !TA: (k >> 2) & 1), so a lane's eight k sit in two column positions: x3c[t][0] where the swizzle bit is
+    // clear, x3c[t][1] where it is set.  (Row-major A of !TA: the eight k are 32 contiguous bytes of row m.)
+    const int r32 = lane & 31;
+    int x3a[2][2], x3b[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = 64 * wm + 32 * t + r32, n = 64 * wn + 32 * t + r32;
+        x3a[t][0] = TA ? (((m >> 2) << 2) + (m & 3)) : (m * GK + 8 * h);
+        x3a[t][1] = TA ? ((((m >> 2) ^ 4) << 2) + (m & 3)) : 0;
+        x3b[t][0] = ((n >> 2) << 2) + (n & 3);
+        x3b[t][1] = (((n >> 2) ^ 4) << 2) + (n & 3);
+    }
     f32x4 acc[4][4];
+    f32x16_t acx[2][2];
+    if constexpr (X3) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acx[i][j][e] = 0.0f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
     float cs = 0.0f;
 
     // vmcnt accounting of the K loop (audited on the ISA, tools/check_isa.py; the build fails if this kernel gets scratch): the only
@@ -287,7 +341,37 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, cons
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (t + 2 < T) issue(t + 2);          // into the buffer every wave finished reading before the barrier above
         const float *As = &smem[t % DST][0][0], *Bs = &smem[t % DST][1][0];
-        if (TA) {
+        if constexpr (X3) {
+            u32x4_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float x[8];
+                if (TA) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = As[(8 * h + j) * GT + x3a[i][j & 1]];
+                } else {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(As + x3a[i][0]), v1 = *reinterpret_cast<const f32x4 *>(As + x3a[i][0] + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { x[j] = v0[j]; x[4 + j] = v1[j]; }
+                }
+                split8(x, ah[i], al[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = Bs[(8 * h + j) * GT + x3b[i][TA ? (j & 1) : (j >> 2)]];
+                split8(x, bh[i], bl[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acx[i][j] = mfma3(ah[i], al[i], bh[j], bl[j], acx[i][j]);
+            if (TA && do_sum && tid < GT) {
+#pragma unroll
+                for (int k = 0; k < GK; ++k) cs += As[k * GT + ((((tid >> 2) ^ ((k & 1) << 2)) << 2) + (tid & 3))];
+            }
+        } else if (TA) {
 #pragma unroll
             for (int s4 = 0; s4 < GK / 4; ++s4) {
                 float a[4], b[4];
@@ -320,6 +404,13 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, cons
             }
         }
     }
+    // one accessor for both accumulator layouts: value of row `row` (0..63 of this wave's block, as enumerated below) x column
+    // f32 form: tile (i, j) register r  -> row 16 i + 4 q + r,                       column 16 j + c16
+    // X3 form : tile (i, j) register e  -> row 32 i + (e & 3) + 8 (e >> 2) + 4 h,    column 32 j + r32
+    constexpr int NI = X3 ? 2 : 4, NR = X3 ? 16 : 4;
+    auto row_of = [&](int i, int e) { return X3 ? 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h : 16 * i + 4 * q + e; };
+    auto col_of = [&](int j) { return X3 ? 32 * j + r32 : 16 * j + c16; };
+    auto val_of = [&](int i, int j, int e) -> float { if constexpr (X3) return acx[i][j][e]; else return acc[i][j][e]; };
     if (!TA && mode != 2 && ((reinterpret_cast<uintptr_t>(C) | (mask ? reinterpret_cast<uintptr_t>(mask) : 0)) & 15) == 0 && ldc % 4 == 0 &&
         (mask == nullptr || ldm % 4 == 0)) {
         // Data-gradient epilogue through LDS: the accumulator layout gives 64-byte row segments per store instruction (64 mask loads
@@ -331,11 +422,11 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, cons
         for (int half = 0; half < 2; ++half) {
             if (wm == half) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NI; ++j)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) stage[(16 * i + 4 * q + r) * SLD + 64 * wn + 16 * j + c16] = acc[i][j][r];
+                        for (int r = 0; r < NR; ++r) stage[row_of(i, r) * SLD + 64 * wn + col_of(j)] = val_of(i, j, r);
             }
             __syncthreads();
 #pragma unroll
@@ -378,11 +469,11 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, cons
         for (int half = 0; half < 2; ++half) {
             if (wm == half) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NI; ++j)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) stage[(16 * i + 4 * q + r) * SLD + 64 * wn + 16 * j + c16] = acc[i][j][r];
+                        for (int r = 0; r < NR; ++r) stage[row_of(i, r) * SLD + 64 * wn + col_of(j)] = val_of(i, j, r);
             }
             __syncthreads();
 #pragma unroll 4
@@ -398,15 +489,15 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, cons
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long m = m0 + 64 * wm + 16 * i + 4 * q + r;
-                const int n = n0 + 64 * wn + 16 * j + c16;
+            for (int r = 0; r < NR; ++r) {
+                const long m = m0 + 64 * wm + row_of(i, r);
+                const int n = n0 + 64 * wn + col_of(j);
                 if (m < M && n < N) {
-                    float v = acc[i][j][r];
+                    float v = val_of(i, j, r);
                     if (mask != nullptr) v *= (mask[m * ldm + n] > 0.0f) ? 1.0f : slope;
                     float *dst = C + m * ldc + n;
                     if (mode == 0) *dst = v;
@@ -668,6 +759,22 @@ __global__ void __launch_bounds__(256) axpy_batch_kernel(AxpyBatch b)
 
 using namespace SAHS_NS;
 
+// Precision of the backward GEMMs of this model build: 0 = f32 MFMA (exact products), 3 = bf16 pipe with split operands (default;
+// SAHS_BWD_GEMM=f32 in the environment selects 0 at first use).  set < 0 queries.  Process-wide (one atomic), set through
+// sahs_backward_gemm_precision() of the C ABI.
+extern "C" int SAHS_SYM(sahs_bwd_gemm_precision_state)(int set)
+{
+    static std::atomic<int> state{-1};
+    int cur = state.load(std::memory_order_relaxed);
+    if (cur < 0) {
+        const char *e = getenv("SAHS_BWD_GEMM");
+        cur = (e != nullptr && e[0] == 'f') ? 0 : 3;
+        state.store(cur, std::memory_order_relaxed);
+    }
+    if (set >= 0) { state.store(set ? 3 : 0, std::memory_order_relaxed); cur = set ? 3 : 0; }
+    return cur;
+}
+
 namespace {
 
 struct Bwd {
@@ -693,6 +800,7 @@ struct Bwd {
         if (naxpy > 0) { axpy_batch_kernel<<<dim3(1, naxpy), 256, 0, st>>>(axpys); check(); }
         nconst = naxpy = 0;
     }
+    static bool x3() { return SAHS_SYM(sahs_bwd_gemm_precision_state)(-1) != 0; }
     static bool al(const void *p, long ld)
     {
         static const bool nodma = getenv("SAHS_BWD_NODMA") != nullptr;     // diagnostic: route every GEMM to the register-staged kernel
@@ -724,7 +832,8 @@ struct Bwd {
                 W = dst; ldw = ldb;
             }
             if (dry) return;
-            gemm_dma_kernel<false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn, zero);
+            if (x3()) gemm_dma_kernel<false, true><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn, zero);
+            else gemm_dma_kernel<false, false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn, zero);
         } else {
             if (dry) return;
             gemm_f32_kernel<false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn);
@@ -744,7 +853,8 @@ struct Bwd {
         kslab = kslab < 512 ? 512 : (kslab > 8192 ? 8192 : kslab);
         dim3 g((N + GT - 1) / GT, (M + GT - 1) / GT, (unsigned)((P + kslab - 1) / kslab));
         if (al(dY, ldy) && al(X, ldx))
-            gemm_dma_kernel<true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0, zero);
+            if (x3()) gemm_dma_kernel<true, true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0, zero);
+            else gemm_dma_kernel<true, false><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0, zero);
         else
             gemm_f32_kernel<true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0);
         check();

@@ -418,6 +418,18 @@ def route_xw_grad(src, g_fine, num_coarse):
     return g_c, g_n
 
 
+def backward_gemm_precision(precision=None):
+    """Arithmetic of the backward's dense-layer GEMMs: "bf16x3" (default: split operands on the bf16 matrix pipe, ~1e-5 of scale) or "fp32"
+    (f32 MFMAs, the exact A/B reference).  None queries.  Process-wide (include/sahs_nerf.h: sahs_backward_gemm_precision)."""
+    names = {SAHS_F32: "fp32", SAHS_BF16X3: "bf16x3"}
+    if precision is None:
+        return names[_lib.lib().sahs_backward_gemm_precision(-1)]
+    code = PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+    if _lib.lib().sahs_backward_gemm_precision(code) != code:
+        raise _lib.SahsError("backward GEMM precision must be 'fp32' or 'bf16x3'")
+    return names[code]
+
+
 LOSS_STATS_WORDS = 64      # include/sahs_nerf.h: [0] loss, [1] last level's mse, [2:14] new sample_prob, [14:26] class counts, [26] rays
 
 

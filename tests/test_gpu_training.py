@@ -511,3 +511,57 @@ def test_coarse_only_training_gradients(weights_mod):
             assert p.grad is None or not bool(p.grad.any()), k     # the fine net is never evaluated
             continue
         assert float((p.grad - r).abs().max()) <= 2e-2 * float(r.abs().max()) + 1e-9, k
+
+
+@pytest.mark.parametrize("arch", ["audio", "nerface", "nerface_static"])
+def test_backward_gemms_bf16x3_vs_f32(arch, weights_mod):
+    """The backward's dense-layer GEMMs on the bf16 matrix pipe with split operands (the default, include/sahs_nerf.h:
+    sahs_backward_gemm_precision) against the same kernels' f32-MFMA form on the same saved activations and upstream gradient: every
+    parameter gradient, the seam gradient and the conditioning gradient within 1e-4 of the tensor's largest entry (observed values are
+    printed; products carry ~1e-5 relative error, sums of them less) -- two orders below the ReLU-kink noise between two correct fp32
+    forwards (1e-2, test_gradients_vs_golden).  Every level and part of the split walk, ragged sample count."""
+    ops = pkg("ops")
+    W = weights_mod
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(7)
+    model_kw = {} if arch == "audio" else dict(model=arch)
+    flat = torch.from_numpy(W.flatten_state_dict(W.hash_state_dict(0, 2.0, 30.0, hdr=True, **model_kw), **model_kw)).to(dev)
+    packed = ops.pack_weights(flat, arch=arch)
+    driving = torch.randn(16, 29, device=dev, generator=gen) if arch == "audio" else torch.randn(76, device=dev, generator=gen) * 0.5
+    near, far, cam = (0.48, 1.08, 0.8) if arch == "audio" else (0.2, 0.8, 0.5)
+    pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [cam]]], 1).astype(np.float32)).to(dev)
+    frame = ops.fold_conditioning(flat, driving, pose, arch=arch)
+    N, S = 37, 77                 # 2849 samples: ragged against the 128-row tiles and the 512-sample slabs
+    rays = torch.zeros(N, 8, device=dev)
+    rays[:, 2] = cam
+    rays[:, 3:6] = torch.randn(N, 3, device=dev, generator=gen) * 0.15 + torch.tensor([0, 0, -1.0], device=dev)
+    z = torch.sort(torch.rand(N, S, device=dev, generator=gen) * (far - near) + near, dim=1).values
+    d_raw = torch.randn(N * S, 16, device=dev, generator=gen)
+    assert ops.backward_gemm_precision() == "bf16x3"
+    worst = {}
+    try:
+        for level in (0, 1):
+            raw, act = ops.field_forward_save(packed, frame, level, rays, z, arch)
+            res = {}
+            for prec in ("fp32", "bf16x3"):
+                ops.backward_gemm_precision(prec)
+                gf, gc = torch.zeros_like(flat), torch.zeros(128, device=dev)
+                ops.field_backward(flat, frame, level, act, d_raw, gf, gc, arch)
+                res[prec] = (gf, gc)
+            off = W.canonical_offsets(arch)
+            for k, (o, shape) in off.items():
+                n = int(np.prod(shape))
+                a, b = res["fp32"][0][o:o + n], res["bf16x3"][0][o:o + n]
+                scale = float(a.abs().max())
+                if scale == 0.0:
+                    assert float(b.abs().max()) == 0.0, k
+                    continue
+                err = float((a - b).abs().max()) / scale
+                worst[k] = max(worst.get(k, 0.0), err)
+            cs = float(res["fp32"][1].abs().max()) + 1e-30
+            worst["grad_cond"] = max(worst.get("grad_cond", 0.0), float((res["fp32"][1] - res["bf16x3"][1]).abs().max()) / cs)
+    finally:
+        ops.backward_gemm_precision("bf16x3")
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print(arch, "bf16x3 vs f32 backward GEMMs, worst |delta| / scale:", ", ".join("%s %.2e" % kv for kv in top))
+    assert top[0][1] <= 1e-4, top
