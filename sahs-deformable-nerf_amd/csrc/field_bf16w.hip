@@ -108,6 +108,34 @@ __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float
 #ifdef SAHS_X_EXTRAVALU
     if constexpr (T >= 0 && T < NV) { float dmy; asm volatile("v_max_f32 %0, %1, %1" : "=v"(dmy) : "v"(acc[0][T & 15])); }
 #endif
+#ifdef SAHS_BF16W_PATTERN_LEAKY
+    // EXPERIMENT (tools/ablate.py "wleaky"; not the shipped arithmetic): LeakyReLU on the packed bf16 BIT PATTERNS after rounding -- 1.5
+    // VALU instructions per value instead of 2.5.  A negative bf16 value has its sign bit set, i.e. it is a negative int16 whose low 15 bits
+    // grow with the magnitude; subtracting K = round(128 log2(1/slope)) from the pattern (saturating at -0.0 = int16 min) scales the
+    // magnitude by 2^-(K/128) read piecewise-linearly over the mantissa: x 0.0095 .. 0.0106 where the exact slope is 0.01 (an error of
+    // <= 6e-4 |x|, below the 2e-3 |x| rounding step of bf16 itself, but a systematic one).  Positive values pass unchanged:
+    //   tick T:  C'(T-2) d = cvt_pk_bf16(v_{T-3}, v_{T-2});  D'(T-3) s = d >> 15 (arithmetic, per half: 0 | -1);  E'(T-4) dword = sat_i16(s * K + d)
+    if (slope != 0.0f && slope != 1.0f) {
+        if constexpr (T - 2 >= 1 && T - 2 < NV && ((T - 2) & 1)) {
+            constexpr int U = T - 2, P = U >> 1, hh = P % NH, q = P / NH;
+            ps.d[P & 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{acc[hh][2 * q], acc[hh][2 * q + 1]}, bf16x2));
+        }
+        if constexpr (T - 3 >= 1 && T - 3 < NV && ((T - 3) & 1)) {
+            constexpr int U = T - 3, P = U >> 1;
+            uint32_t sg;
+            asm("v_pk_ashrrev_i16 %0, 15, %1" : "=v"(sg) : "v"(ps.d[P & 1]));
+            ps.r[P & 1] = __builtin_bit_cast(float, sg);
+        }
+        if constexpr (T - 4 >= 1 && T - 4 < NV && ((T - 4) & 1)) {
+            constexpr int U = T - 4, P = U >> 1, hh = P % NH, q = P / NH, s = q >> 2, jp = q & 3;
+            const uint32_t kk = 0x03520352u;      // K = 850 = round(128 * log2(100)) in both halves
+            uint32_t o_;
+            asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(o_) : "v"(__builtin_bit_cast(uint32_t, ps.r[P & 1])), "s"(kk), "v"(ps.d[P & 1]));
+            o.s[hh][s][jp] = o_;
+        }
+        return;
+    }
+#endif
 #ifndef SAHS_BF16W_FP32_RELU
     if (slope == 0.0f) {
         if constexpr (T - 2 >= 1 && T - 2 < NV && ((T - 2) & 1)) {

@@ -242,15 +242,26 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c16 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
     int bx = blockIdx.x, by = blockIdx.y;
+    long bz = blockIdx.z;
     if (nbn > 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         bx = slot % nbn;
         by = (slot / nbn) * 8 + xcd;
         if ((long)by * GT >= M) return;
+    } else if (nbn < 0) {
+        // weight-gradient GEMM, 1-D grid: the nx x ny output tiles of ONE sample slab read the same dY and X rows -- they run on the same
+        // XCD (workgroup ids congruent mod 8, consecutive slots), so that XCD's L2 fetches the slab from HBM once instead of once per tile
+        const int nx = -nbn, ny = (M + GT - 1) / GT, tiles = nx * ny;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int tile = slot % tiles;
+        bz = (long)(slot / tiles) * 8 + xcd;
+        bx = tile % nx;
+        by = tile / nx;
+        if (bz * kslab >= K) return;
     }
     const long m0 = (long)by * GT;
     const int n0 = bx * GT;
-    const long k_lo = (long)blockIdx.z * kslab;
+    const long k_lo = bz * kslab;
     const long k_hi = (k_lo + kslab < K) ? k_lo + kslab : K;
     const int T = (int)((k_hi - k_lo + GK - 1) / GK);
     const bool do_sum = TA && rowsum != nullptr && bx == 0;
@@ -852,10 +863,12 @@ struct Bwd {
         long kslab = (P * tiles / 512 + 15) / 16 * 16;
         kslab = kslab < 512 ? 512 : (kslab > 8192 ? 8192 : kslab);
         dim3 g((N + GT - 1) / GT, (M + GT - 1) / GT, (unsigned)((P + kslab - 1) / kslab));
-        if (al(dY, ldy) && al(X, ldx))
-            if (x3()) gemm_dma_kernel<true, true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0, zero);
-            else gemm_dma_kernel<true, false><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0, zero);
-        else
+        if (al(dY, ldy) && al(X, ldx)) {
+            const int nx = (N + GT - 1) / GT, slabs = (int)((P + kslab - 1) / kslab);
+            const dim3 g1((unsigned)((slabs + 7) / 8 * 8 * tiles), 1, 1);        // XCD-aware 1-D grid (kernel: nbn < 0)
+            if (x3()) gemm_dma_kernel<true, true><<<g1, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, -nx, zero);
+            else gemm_dma_kernel<true, false><<<g1, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, -nx, zero);
+        } else
             gemm_f32_kernel<true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0);
         check();
     }

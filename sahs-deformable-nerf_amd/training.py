@@ -105,8 +105,8 @@ def train_step(model, optimizer, cfg, step, image, mask, pose, intrinsics, audio
         stats /= dist.get_world_size(group)
         new_prob, loss, fine_mse = stats[:-2] / stats[:-2].sum(), stats[-2], stats[-1]
     optimizer.step()
-    for group in optimizer.param_groups:
-        group["lr"] = learning_rate(cfg, step)
+    for param_group in optimizer.param_groups:
+        param_group["lr"] = learning_rate(cfg, step)
     return dict(loss=float(loss.detach()), psnr=mse2psnr(float(fine_mse.detach())), sample_prob=new_prob)
 
 
