@@ -233,11 +233,16 @@ __device__ __forceinline__ f32x16_t mfma3(const u32x4_t &ah, const u32x4_t &al, 
 }
 
 template <bool TA, bool X3>
-__global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, const float *__restrict__ A, long lda,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA && X3) ? 2 : 3, 3))) gemm_dma_kernel(int M, int N, int K, const float *__restrict__ A, long lda,
                                                        const float *__restrict__ B, long ldb, float *__restrict__ C, long ldc, int mode,
                                                        const float *__restrict__ mask, long ldm, float slope, int kslab,
-                                                       float *__restrict__ rowsum, int nbn, const float *__restrict__ zero)
+                                                       float *__restrict__ rowsum, int nbn, const float *__restrict__ zero,
+                                                       unsigned char *__restrict__ bits)
 {
+    // bits (optional): the sign pattern of an activation matrix as a bit matrix, row r = N/8 bytes, bit (n & 7) of byte n >> 3 set where
+    // X[r][n] > 0.  The weight-gradient GEMM (TA) WRITES it for its B operand X from the tiles it stages anyway (the m-block-0 workgroups);
+    // the data-gradient GEMM of the same layer, which follows it and whose (leaky-)ReLU mask is that same X, READS it instead of the fp32
+    // matrix -- 1/32 of the bytes of what was a third of its HBM traffic.
     __shared__ __attribute__((aligned(16))) float smem[DST][2][DTILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c16 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
@@ -352,6 +357,18 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, cons
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         if (t + 2 < T) issue(t + 2);          // into the buffer every wave finished reading before the barrier above
         const float *As = &smem[t % DST][0][0], *Bs = &smem[t % DST][1][0];
+        if (TA && bits != nullptr && by == 0) {      // thread (kk, g): the 8 columns 8g .. 8g+7 of sample row kk of the X tile -> one byte
+            const int kk = tid >> 4, g = tid & 15;
+            const long k = k_lo + (long)t * GK + kk;
+            if (k < k_hi && n0 + 8 * g < N) {
+                const float *px = Bs + kk * GT + 4 * ((2 * g) ^ ((kk & 1) << 2));     // chunks 2g, 2g+1 stay adjacent under the swizzle
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(px), v1 = *reinterpret_cast<const f32x4 *>(px + 4);
+                unsigned b8 = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b8 |= (v0[i] > 0.0f ? 1u : 0u) << i | (v1[i] > 0.0f ? 1u : 0u) << (4 + i);
+                bits[k * (N >> 3) + (n0 >> 3) + g] = (unsigned char)b8;
+            }
+        }
         if constexpr (X3) {
             u32x4_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -448,7 +465,11 @@ __global__ void __launch_bounds__(256) gemm_dma_kernel(int M, int N, int K, cons
                 if (m < M && n < N) {
                     f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * SLD + 4 * c4);
                     if (n + 3 < N) {
-                        if (mask != nullptr) {
+                        if (mask != nullptr && bits != nullptr) {
+                            const unsigned nib = bits[m * (N >> 3) + (n >> 3)] >> (n & 4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] *= ((nib >> k) & 1u) ? 1.0f : slope;
+                        } else if (mask != nullptr) {
                             const f32x4 mk = *reinterpret_cast<const f32x4 *>(mask + m * ldm + n);
 #pragma unroll
                             for (int k = 0; k < 4; ++k) v[k] *= (mk[k] > 0.0f) ? 1.0f : slope;
@@ -796,6 +817,9 @@ struct Bwd {
     long wal_cap = 0;
     long walo = 0;
     int err = 0;
+    unsigned char *sign_bits = nullptr;      // P x 32 bytes: the bit matrix of the activation the last tn() staged as its X operand ...
+    const float *bits_of = nullptr;          // ... which is this matrix, N = bits_n columns (null: none)
+    int bits_n = 0;
     bool dry = false;      // the collecting pass: nothing is launched, nn() records the aligned copies it will need
     CopyBatch copies; int ncopy = 0;
     ConstBatch consts; int nconst = 0, const_maxcols = 0;
@@ -843,8 +867,10 @@ struct Bwd {
                 W = dst; ldw = ldb;
             }
             if (dry) return;
-            if (x3()) gemm_dma_kernel<false, true><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn, zero);
-            else gemm_dma_kernel<false, false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn, zero);
+            // the layer's weight-gradient GEMM has just staged this very mask matrix and left its sign bits (tn)
+            unsigned char *mb = (mask != nullptr && mask == bits_of && N == bits_n && N % 8 == 0) ? sign_bits : nullptr;
+            if (x3()) gemm_dma_kernel<false, true><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn, zero, mb);
+            else gemm_dma_kernel<false, false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn, zero, mb);
         } else {
             if (dry) return;
             gemm_f32_kernel<false><<<g, 256, 0, st>>>((int)P, N, K, dY, ldy, W, ldw, dX, ldx, mode, mask, ldm, slope, K, nullptr, nbn);
@@ -866,10 +892,16 @@ struct Bwd {
         if (al(dY, ldy) && al(X, ldx)) {
             const int nx = (N + GT - 1) / GT, slabs = (int)((P + kslab - 1) / kslab);
             const dim3 g1((unsigned)((slabs + 7) / 8 * 8 * tiles), 1, 1);        // XCD-aware 1-D grid (kernel: nbn < 0)
-            if (x3()) gemm_dma_kernel<true, true><<<g1, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, -nx, zero);
-            else gemm_dma_kernel<true, false><<<g1, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, -nx, zero);
+            unsigned char *mb = (sign_bits != nullptr && N % 8 == 0 && N <= 256) ? sign_bits : nullptr;
+            if (x3()) gemm_dma_kernel<true, true><<<g1, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, -nx, zero, mb);
+            else gemm_dma_kernel<true, false><<<g1, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, -nx, zero, mb);
+            bits_of = mb ? X : nullptr;
+            bits_n = N;
         } else
+        {
             gemm_f32_kernel<true><<<g, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, 0);
+            bits_of = nullptr;
+        }
         check();
     }
     void copy(const float *src, long lds_, int N, float *dst, long ldd, int mode)
@@ -886,7 +918,11 @@ struct Bwd {
 // channel-last copies of the feature grid and of its gradient accumulator
 constexpr int DB_SCRATCH = 8192;   // per-call bias-gradient scratch (all layers of one level: ~5.3 K floats)
 constexpr long WAL_FLOATS = 2L << 20;   // aligned weight sub-matrix copies of one level (< 1.8 M floats)
-extern "C" long SAHS_SYM(sahs_field_backward_ws_words)(long P) { return P * (256L * 3 + DIN_LD + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS + WAL_FLOATS; }
+// the three output heads as 16-row matrices over the whole d_raw row [drgb3 | dseg12 | dsigma]: zero-padded weights W16 and their gradients
+constexpr int HEAD_W_SEG = 0, HEAD_W_RGB = 16 * 128, HEAD_W_ALPHA = 2 * 16 * 128, HEAD_G_SEG = HEAD_W_ALPHA + 16 * 256, HEAD_G_RGB = HEAD_G_SEG + 16 * 128,
+              HEAD_G_ALPHA = HEAD_G_RGB + 16 * 128, HEAD_DB = HEAD_G_ALPHA + 16 * 256;
+constexpr long HEAD_FLOATS = HEAD_DB + 64;
+extern "C" long SAHS_SYM(sahs_field_backward_ws_words)(long P) { return P * (256L * 3 + DIN_LD + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS + WAL_FLOATS + P * 8 + HEAD_FLOATS; }
 
 // grad_cond: [0:76] d_driving, [80:116] d_pose36 (accumulated).  grad_flat: accumulated.  d_raw: (P,16).
 // part (bit 1: deformation nets, bit 2: radiance nets; 0 = 3 = everything) cuts the walk at its seam, the gradient w.r.t. the deformed
@@ -916,6 +952,9 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
     b.zero = ws + P * (256L * 3 + DIN_LD + 32 + 12) + DB_SCRATCH - 64;   // tail of the (zeroed) bias-gradient scratch, never written
     b.wal = ws + P * (256L * 3 + DIN_LD + 32 + 12) + DB_SCRATCH + 2 * GRID_FLOATS;
     b.wal_cap = WAL_FLOATS;
+    float *heads = b.wal + WAL_FLOATS + P * 8;
+    if (hipMemsetAsync(heads, 0, sizeof(float) * HEAD_FLOATS, stream) != hipSuccess) return (int)hipGetLastError();
+    b.sign_bits = getenv("SAHS_BWD_NOBITS") ? nullptr : reinterpret_cast<unsigned char *>(b.wal + WAL_FLOATS);     // P x 32 bytes (<= 256 columns)
     const FlatOffsets &F = kFlat;
     const FlatOffsets::Lvl &Lv = F.lvl[level];
     float *gA = ws, *gB = gA + P * 256, *dfeat = gB + P * 256, *din = dfeat + P * 256, *dgridf = din + P * DIN_LD, *dxw = dgridf + P * 32,
@@ -964,15 +1003,36 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
         (void)boff; (void)dbl;
     };
 
+    // rows of a head's weights into its zero-padded 16-row copy (collected in the dry pass, one batched launch with the aligned weight
+    // copies); rows of a head's gradient scratch added to the flat gradient (deferred to the end of the walk, batched)
+    auto head_copy = [&](const float *src, float *dst, int rows, int cols) {
+        if (!b.dry) return;
+        if (b.ncopy < MAX_COPY_JOBS) b.copies.j[b.ncopy] = CopyJob{src, dst, cols, cols, rows, cols};
+        else b.err = (int)hipErrorOutOfMemory;
+        ++b.ncopy;
+    };
+    auto head_add = [&](const float *src, float *dst, int n) {
+        if (b.dry) return;
+        if (b.naxpy < MAX_AXPY_JOBS) { b.axpys.j[b.naxpy++] = AxpyJob{src, dst, n}; return; }
+        axpy_kernel<<<(n + 255) / 256, 256, 0, stream>>>(n, src, dst); b.check();
+    };
     const float *A = actbuf;
     if (do_rad) {
     // ================= seg branch: seg = fc_seg(s3), s_i = lrelu(layers_seg[i](.)) (modules.py:289-294) =================
     {
-        const float *dseg = d_raw + 3;   // (P,12), ld 16
-        float *dbl = newdb(N_SEG, Lv.segout_b);
-        b.tn(dseg, 16, N_SEG, A + (long)(act::S + 384) * P, BR_H, BR_H, G(Lv.segout_w), BR_H, dbl);
-        add_bias(dbl, Lv.segout_b, N_SEG);
-        b.nn(dseg, 16, N_SEG, W(Lv.segout_w), BR_H, BR_H, gA, BR_H, 0, A + (long)(act::S + 384) * P, BR_H, 0.01f);
+        // the output heads read the whole 16-float d_raw row ([drgb3 | dseg12 | dsigma], 16-byte aligned, K = 16 = one LDS-DMA K-step)
+        // against 16-row zero-padded copies of their weights, instead of its unaligned 3/12/1-column slices through the register-staged
+        // GEMM: dW16 = d_raw^T X lands in scratch, rows 3..14 of it are fc_seg's gradient; its column sums are the three bias gradients
+        static_assert(BR_H == 128 && TR_H == 256 && N_SEG == 12, "head scratch layout");
+        head_copy(W(Lv.segout_w), heads + HEAD_W_SEG + 3 * BR_H, N_SEG, BR_H);
+        head_copy(W(Lv.rgb_w), heads + HEAD_W_RGB, 3, BR_H);
+        head_copy(W(Lv.alpha_w), heads + HEAD_W_ALPHA + 15 * TR_H, 1, TR_H);
+        b.tn(d_raw, 16, 16, A + (long)(act::S + 384) * P, BR_H, BR_H, heads + HEAD_G_SEG, BR_H, heads + HEAD_DB);
+        head_add(heads + HEAD_G_SEG + 3 * BR_H, G(Lv.segout_w), N_SEG * BR_H);
+        head_add(heads + HEAD_DB + 3, G(Lv.segout_b), N_SEG);
+        head_add(heads + HEAD_DB, G(Lv.rgb_b), 3);
+        head_add(heads + HEAD_DB + 15, G(Lv.alpha_b), 1);
+        b.nn(d_raw, 16, 16, heads + HEAD_W_SEG, BR_H, BR_H, gA, BR_H, 0, A + (long)(act::S + 384) * P, BR_H, 0.01f);
         float *cur = gA, *nxt = gB;
         for (int i = 3; i >= 1; --i) {   // layers_seg[i]: s_{i-1} (128) -> s_i
             float *d = newdb(BR_H, Lv.seg_b[i]);
@@ -988,11 +1048,9 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
     }
     // ================= colour branch (modules.py:276-287) =================
     {
-        const float *drgb = d_raw;   // (P,3), ld 16
-        float *dbl = newdb(4, Lv.rgb_b);
-        b.tn(drgb, 16, 3, A + (long)(act::C + 384) * P, BR_H, BR_H, G(Lv.rgb_w), BR_H, dbl);
-        add_bias(dbl, Lv.rgb_b, 3);
-        b.nn(drgb, 16, 3, W(Lv.rgb_w), BR_H, BR_H, gA, BR_H, 0, A + (long)(act::C + 384) * P, BR_H, 0.01f);
+        b.tn(d_raw, 16, 16, A + (long)(act::C + 384) * P, BR_H, BR_H, heads + HEAD_G_RGB, BR_H);
+        head_add(heads + HEAD_G_RGB, G(Lv.rgb_w), 3 * BR_H);
+        b.nn(d_raw, 16, 16, heads + HEAD_W_RGB, BR_H, BR_H, gA, BR_H, 0, A + (long)(act::C + 384) * P, BR_H, 0.01f);
         float *cur = gA, *nxt = gB;
         for (int i = 3; i >= 1; --i) {
             float *d = newdb(BR_H, Lv.dir_b[i]);
@@ -1012,11 +1070,9 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
     }
     // ================= sigma = fc_alpha(feat) (modules.py:275) =================
     {
-        const float *dsig = d_raw + 15;  // (P,1), ld 16
-        float *dbl = newdb(4, Lv.alpha_b);
-        b.tn(dsig, 16, 1, A + (long)(act::FEAT) * P, TR_H, TR_H, G(Lv.alpha_w), TR_H, dbl);
-        add_bias(dbl, Lv.alpha_b, 1);
-        if (!b.dry) { rank1_add_kernel<<<2048, 256, 0, stream>>>(P, TR_H, dsig, 16, W(Lv.alpha_w), dfeat, 256); b.check(); }
+        b.tn(d_raw, 16, 16, A + (long)(act::FEAT) * P, TR_H, TR_H, heads + HEAD_G_ALPHA, TR_H);
+        head_add(heads + HEAD_G_ALPHA + 15 * TR_H, G(Lv.alpha_w), TR_H);
+        b.nn(d_raw, 16, 16, heads + HEAD_W_ALPHA, TR_H, TR_H, dfeat, 256, 1);          // d feat += d sigma (x) w_alpha
     }
     // ================= trunk (modules.py:267-274) =================
     {

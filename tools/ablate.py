@@ -20,7 +20,7 @@ VARIANTS = {"base": [],  "nope": ["SAHS_ABLATE_NOPE"], "nobarrier": ["SAHS_ABLAT
             # (wnopack: INVALID as an MFMA-only time -- without the conversions the compiler deletes 45 % of the MFMAs, DESIGN.md section 3.1b;
             #  wall-time ablations of this kernel also move the clock the chip holds: use tools/stamp_bf16w.py, which counts cycles)
             "wnopack": ["SAHS_ABLATE_NOPACK"], "wagpr": ["SAHS_NOTHING"], "wnodma": ["SAHS_ABLATE_NODMA"],
-            "wfp32relu": ["SAHS_BF16W_FP32_RELU"], "wpkmul": ["SAHS_BF16W_PKMUL"], "wleaky": ["SAHS_BF16W_PATTERN_LEAKY"],
+            "wfp32relu": ["SAHS_BF16W_FP32_RELU"], "wpkmul": ["SAHS_BF16W_PKMUL"], "wexact": ["SAHS_BF16W_EXACT_LEAKY"],
             "x3nodma": ["SAHS_X3_NODMA"], "x3nobar": ["SAHS_X3_NOBARRIER"], "x3noaread": ["SAHS_X3_NOAREAD"], "x3floor": ["SAHS_X3_NODMA", "SAHS_X3_NOBARRIER", "SAHS_X3_NOAREAD"],
             "w4": ["SAHS_BF16_WAVES=4"], "w4apf6": ["SAHS_BF16_WAVES=4", "SAHS_BF16_APF=6"]}
 
