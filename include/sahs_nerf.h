@@ -259,6 +259,15 @@ int sahs_model_render_rays_rows(int model, const void *packed, const float *fram
                                 const float *noise_c, const float *u, const float *noise_f, float *z_c, float *z_f, float *raw,
                                 float *weights, float *rows, int row_ld, float *xw, int32_t *src, float *z_new, void *stream);
 
+/* ---- Stage-II refiner building block ----
+ * The elementwise core of SPADELayer.forward followed by its SPADEBlock's LeakyReLU (nerf/_init_spade.py:130-139, :262-279):
+ *   out = lrelu_slope( InstanceNorm2d(x; eps, biased variance, no affine) * (1 + gamma) + beta )
+ * over `planes` = N*C contiguous planes of `hw` = H*W floats each (NCHW); gamma, beta, out have x's shape; slope 1 = no activation;
+ * stats: 2 * planes floats of workspace (mean, 1/sqrt(var + eps) per plane).  The convolutions that produce gamma / beta stay library
+ * calls (MIOpen through PyTorch): sahs-deformable-nerf_amd/spade.py. */
+int sahs_spade_modulate(long planes, long hw, const float *x, const float *gamma, const float *beta, float eps, float slope, float *out,
+                        float *stats, void *stream);
+
 /* ---- launch probe (opt-in measurement aid; the one exception to "never synchronises") ----
  * While armed on the calling thread, every FIELD-kernel launch the library makes (from any entry point above) is bracketed by two HIP
  * events recorded on the launch stream, up to `capacity` launches (further ones are counted as dropped and run unprobed).

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsahs_nerf.so")
-SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "field_f32.hip", "field_bf16w.hip", "field_bf16x3.hip", "field_bwd.hip", "train_bwd.hip"]
+SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "spade_ops.hip", "field_f32.hip", "field_bf16w.hip", "field_bf16x3.hip", "field_bwd.hip", "train_bwd.hip"]
 # A/B kernels (the round-1 bf16 kernel and the 16x16x32 port, both slower than the shipped one): only in development builds made with
 # build(defines=["SAHS_AB_KERNELS"], out=...) by tools/cmp_*.py -- never in libsahs_nerf.so or the public header
 AB_SOURCES = ["ab/field_bf16.hip", "ab/field_bf16q.hip"]

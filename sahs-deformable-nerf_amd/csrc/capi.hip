@@ -49,6 +49,8 @@ int sahs_resample_launch(long N, int S, int nf, int from_z, const float *z, cons
                          float *z_out, long long *inds, int *src, hipStream_t stream);
 int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, long N, int S, float *out, hipStream_t stream);
 int sahs_route_xw_grad_launch(long N, int Sc, int nf, const int *src, const float *g_fine, float *g_coarse, float *g_new, hipStream_t stream);
+int sahs_spade_modulate_launch(long planes, long hw, const float *x, const float *gamma, const float *beta, float eps, float slope, float *out,
+                               float *stats, hipStream_t stream);
 // the NeRFaceModel builds of pack.hip / field_f32.hip (sahs_model.hpp: SAHS_MODEL=1 suffix _nf, SAHS_MODEL=2 suffix _ns)
 #define SAHS_DECLARE_MODEL(sfx)                                                                                                      \
     long sahs_layout_param_count##sfx(void);                                                                                        \
@@ -728,6 +730,15 @@ int sahs_route_xw_grad(long N, int Sc, int nf, const int32_t *src, const float *
             "sahs_route_xw_grad");
     int e = sahs_route_xw_grad_launch(N, Sc, nf, src, g_fine, g_coarse, g_new, (hipStream_t)stream);
     return e ? hip_fail("sahs_route_xw_grad", e) : 0;
+}
+
+int sahs_spade_modulate(long planes, long hw, const float *x, const float *gamma, const float *beta, float eps, float slope, float *out,
+                        float *stats, void *stream)
+{
+    if (planes == 0 || hw == 0) return 0;
+    REQUIRE(planes > 0 && planes <= 2147483647L && hw > 0 && x && gamma && beta && out && stats && eps > 0.0f, "sahs_spade_modulate");
+    int e = sahs_spade_modulate_launch(planes, hw, x, gamma, beta, eps, slope, out, stats, (hipStream_t)stream);
+    return e ? hip_fail("sahs_spade_modulate", e) : 0;
 }
 
 int sahs_composite_forward_rows(long N, int S, const float *raw, const float *z, const float *rays, int ray_stride, const float *noise,

@@ -127,7 +127,7 @@ __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float
         if constexpr (T - 3 >= 1 && T - 3 < NV && ((T - 3) & 1)) {
             constexpr int U = T - 3, P = U >> 1;
             uint32_t sg;
-            asm("v_pk_ashrrev_i16 %0, 15, %1" : "=v"(sg) : "v"(ps.d[P & 1]));
+            asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(sg) : "v"(ps.d[P & 1]));      // (the inline constant sits in the low half only)
             ps.r[P & 1] = __builtin_bit_cast(float, sg);
         }
         if constexpr (T - 4 >= 1 && T - 4 < NV && ((T - 4) & 1)) {

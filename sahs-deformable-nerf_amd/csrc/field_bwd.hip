@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
                 const int idx = tid + 256 * e, row = idx >> 7, col = idx & 127;
                 const long m = m0 + 64 * half + row;
                 const int n = n0 + col;
-                if (m < M && n < N) atomicAdd(C + m * ldc + n, stage[row * SLD + col]);
+                if (m < M && n < N && ldc > 0) atomicAdd(C + m * ldc + n, stage[row * SLD + col]);
             }
             __syncthreads();
         }
@@ -893,6 +893,8 @@ struct Bwd {
             const int nx = (N + GT - 1) / GT, slabs = (int)((P + kslab - 1) / kslab);
             const dim3 g1((unsigned)((slabs + 7) / 8 * 8 * tiles), 1, 1);        // XCD-aware 1-D grid (kernel: nbn < 0)
             unsigned char *mb = (sign_bits != nullptr && N % 8 == 0 && N <= 256) ? sign_bits : nullptr;
+            static const bool dbg_noatomic = getenv("SAHS_BWD_DBG_NOATOMIC") != nullptr;      // timing experiment: results wrong
+            if (dbg_noatomic) ldw = 0;
             if (x3()) gemm_dma_kernel<true, true><<<g1, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, -nx, zero, mb);
             else gemm_dma_kernel<true, false><<<g1, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, -nx, zero, mb);
             bits_of = mb ? X : nullptr;

@@ -317,6 +317,18 @@ def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=
     return rows
 
 
+def spade_modulate(x, gamma, beta, eps=1e-5, slope=1.0):
+    """lrelu_slope(InstanceNorm2d(x) * (1 + gamma) + beta) for NCHW tensors of one shape, fused (include/sahs_nerf.h: sahs_spade_modulate)."""
+    x, gamma, beta = _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
+    if x.dim() != 4 or gamma.shape != x.shape or beta.shape != x.shape:
+        raise _lib.SahsError("spade_modulate: x, gamma, beta must be NCHW tensors of one shape, got %s %s %s" % (tuple(x.shape), tuple(gamma.shape), tuple(beta.shape)))
+    planes, hw = x.shape[0] * x.shape[1], x.shape[2] * x.shape[3]
+    out = torch.empty_like(x)
+    stats = torch.empty(2 * planes, dtype=torch.float32, device=x.device)
+    check(_lib.lib().sahs_spade_modulate(planes, hw, _p(x), _p(gamma), _p(beta), float(eps), float(slope), _p(out), _p(stats), _stream()), "sahs_spade_modulate")
+    return out
+
+
 class LaunchProbe:
     """HIP events around every FIELD-kernel launch the library makes on this thread while the block is open (include/sahs_nerf.h:
     sahs_probe_*), recorded on the launch stream: per-kernel times of the product's own call chain (bench.py's roofline).

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Golden vectors for the Stage-II SPADE refiner's building blocks from the REAL reference:
+``SPADELayer`` and ``SPADEBlock`` of /root/reference/nerf-pytorch/nerf/_init_spade.py (:114-160, :235-282), imported unmodified through
+the same harness shim as make_golden.py (plus an empty ``torchvision`` stub: the file imports torchvision.models for its VGG loss class,
+which is off this path; torchvision is not installed here).  Runs only in the build container.  Stores, per case, the module's
+state_dict (random init under a fixed seed -- small channel counts keep the file small), the inputs and the outputs in eval mode
+(spectral_norm then uses its stored u, v without a power iteration).  Data only: no reference text.
+
+usage:  python tests/golden/make_golden_spade.py            (writes tests/golden/spade.npz)
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/nerf-pytorch"
+
+
+def import_spade():
+    if not os.path.isdir(REF + "/nerf"):
+        raise SystemExit("reference not present at %s: golden vectors can only be regenerated in the build container" % REF)
+    pkg = types.ModuleType("nerf")
+    pkg.__path__ = [REF + "/nerf"]
+    sys.modules["nerf"] = pkg
+    tv = types.ModuleType("torchvision")
+    tv.models = types.ModuleType("torchvision.models")
+    sys.modules["torchvision"], sys.modules["torchvision.models"] = tv, tv.models
+    return importlib.import_module("nerf._init_spade")
+
+
+def main():
+    S = import_spade()
+    out = {}
+    torch.manual_seed(1234)
+    cases = {"layer": dict(norm_nc=6, label_nc=5, N=2, H=12, W=10, fh=6, fw=5),          # F_id at half resolution: nearest upsampling
+             "block": dict(cin=6, cout=8, fid=4, N=2, H=8, W=8, fh=8, fw=8, down=False, up=False),
+             "block_down": dict(cin=6, cout=6, fid=4, N=1, H=8, W=12, fh=4, fw=6, down=True, up=False),
+             "block_up": dict(cin=8, cout=4, fid=3, N=1, H=6, W=6, fh=12, fw=12, down=False, up=True)}
+    for name, c in cases.items():
+        if name == "layer":
+            m = S.SPADELayer(c["norm_nc"], c["label_nc"]).eval()
+            x = torch.randn(c["N"], c["norm_nc"], c["H"], c["W"]) * 2.0 + 0.5
+            fid = torch.randn(c["N"], c["label_nc"], c["fh"], c["fw"])
+        else:
+            m = S.SPADEBlock(c["cin"], c["cout"], c["fid"], downsample=c["down"], upsample=c["up"]).eval()
+            x = torch.randn(c["N"], c["cin"], c["H"], c["W"]) * 2.0 + 0.5
+            fid = torch.randn(c["N"], c["fid"], c["fh"], c["fw"])
+        with torch.no_grad():
+            y = m(x, fid)
+        out[name + ":x"], out[name + ":fid"], out[name + ":y"] = x.numpy(), fid.numpy(), y.numpy()
+        out[name + ":cfg"] = np.array([int(v) for v in c.values()], np.int64)
+        for k, v in m.state_dict().items():
+            out[name + ":sd:" + k] = v.detach().numpy()
+        print(name, tuple(x.shape), "->", tuple(y.shape), "state_dict keys:", len(m.state_dict()))
+    np.savez_compressed(os.path.join(HERE, "spade.npz"), **out)
+    print("wrote", os.path.join(HERE, "spade.npz"), os.path.getsize(os.path.join(HERE, "spade.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

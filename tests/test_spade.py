@@ -1,0 +1,75 @@
+"""Stage-II SPADE building blocks: the CPU restatement against the reference's own outputs (fixtures from the
+imported reference, tests/golden/make_golden_spade.py), the drop-in modules' state_dict ABI, and -- on the GPU -- the drop-in modules
+(MIOpen convolutions + the fused HIP modulation kernel through the C ABI) against the same fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, pkg
+
+CASES = {"block": (False, False), "block_down": (True, False), "block_up": (False, True)}
+
+
+def _sd(g, name, device="cpu"):
+    pre = name + ":sd:"
+    return {k[len(pre):]: torch.from_numpy(g[k]).to(device) for k in g if k.startswith(pre)}
+
+
+def test_spade_restatement_vs_reference():
+    from oracle import spade_eager as SE
+    g = load_golden("spade")
+    sd = {"L." + k: v for k, v in _sd(g, "layer").items()}
+    y = SE.spade_layer(sd, "L.", torch.from_numpy(g["layer:x"]), torch.from_numpy(g["layer:fid"]))
+    assert np.abs(y.numpy() - g["layer:y"]).max() <= 2e-6 * np.abs(g["layer:y"]).max()
+    for name, (down, up) in CASES.items():
+        y = SE.spade_block(_sd(g, name), torch.from_numpy(g[name + ":x"]), torch.from_numpy(g[name + ":fid"]), downsample=down, upsample=up)
+        assert y.shape == g[name + ":y"].shape
+        assert np.abs(y.numpy() - g[name + ":y"]).max() <= 5e-6 * np.abs(g[name + ":y"]).max(), name
+
+
+def test_spade_modules_have_the_reference_state_dict():
+    S = pkg("spade")
+    g = load_golden("spade")
+    for name, (down, up) in CASES.items():
+        cin, cout, fid = [int(v) for v in g[name + ":cfg"][:3]]
+        m = S.SPADEBlock(cin, cout, fid, downsample=down, upsample=up)
+        want = _sd(g, name)
+        have = m.state_dict()
+        assert list(have.keys()) == list(want.keys()), name           # same keys in the same order (incl. conv1 / conv1_sn duplicates)
+        assert all(tuple(have[k].shape) == tuple(want[k].shape) for k in want), name
+        m.load_state_dict(want)                                       # strict
+    with pytest.raises(Exception):                                    # the fused modulation has no CPU path
+        with torch.no_grad():
+            S.SPADELayer(6, 5)(torch.zeros(1, 6, 4, 4), torch.zeros(1, 5, 4, 4))
+
+
+@pytest.mark.gpu
+def test_spade_modules_vs_reference_on_gpu():
+    S, ops = pkg("spade"), pkg("ops")
+    dev = torch.device("cuda:0")
+    g = load_golden("spade")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    norm_nc, label_nc = [int(v) for v in g["layer:cfg"][:2]]
+    layer = S.SPADELayer(norm_nc, label_nc).to(dev).eval()
+    layer.load_state_dict(_sd(g, "layer", dev))
+    with torch.no_grad():
+        y = layer(T(g["layer:x"]), T(g["layer:fid"]))
+    scale = float(np.abs(g["layer:y"]).max())
+    assert float((y.cpu() - torch.from_numpy(g["layer:y"])).abs().max()) <= 1e-5 * scale        # MIOpen's convolution order vs the CPU's
+    for name, (down, up) in CASES.items():
+        cin, cout, fid = [int(v) for v in g[name + ":cfg"][:3]]
+        m = S.SPADEBlock(cin, cout, fid, downsample=down, upsample=up).to(dev).eval()
+        m.load_state_dict(_sd(g, name, dev))
+        with torch.no_grad():
+            y = m(T(g[name + ":x"]), T(g[name + ":fid"]))
+        ref = g[name + ":y"]
+        assert tuple(y.shape) == ref.shape
+        assert float((y.cpu() - torch.from_numpy(ref)).abs().max()) <= 2e-5 * float(np.abs(ref).max()), name
+    # the fused kernel alone against the formula, incl. a ragged plane size and a constant plane (variance 0)
+    x = torch.randn(3, 5, 7, 9, device=dev) * 3 + 1
+    x[1, 2] = 0.25
+    ga, be = torch.randn_like(x), torch.randn_like(x)
+    want = torch.nn.functional.leaky_relu(torch.nn.functional.instance_norm(x, eps=1e-5) * (1 + ga) + be, 0.2)
+    assert float((ops.spade_modulate(x, ga, be, slope=0.2) - want).abs().max()) <= 2e-5
+    with pytest.raises(Exception):
+        ops.spade_modulate(x, ga[:, :4], be)
