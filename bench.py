@@ -57,12 +57,17 @@ HDR = dict(seed=0, density_bias=2.0, density_gain=30.0, hdr=True)      # = VARIA
 # (WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction for 16 B/lane streaming reads).  STATIC: bench.py cannot collect PMCs itself; the
 # numbers are read from the summary that tools/profile_r2.sh wrote under profiles/.
 def _static_traffic():
-    try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r2_pmc_summary.json")))
-        return {"fp32": (d["f32_radiance"]["traffic_bytes"], "profiles/r2_pmc_summary.json:f32_radiance"),
-                "bf16": (d["bf16_radiance"]["traffic_bytes"], "profiles/r2_pmc_summary.json:bf16_radiance")}
-    except (OSError, KeyError, ValueError):
-        return {}
+    for name in ("r3_pmc_summary.json", "r2_pmc_summary.json"):
+        try:
+            d = json.load(open(os.path.join(REPO, "profiles", name)))
+            out = {"fp32": (d["f32_radiance"]["traffic_bytes"], "profiles/%s:f32_radiance" % name),
+                   "bf16": (d["bf16_radiance"]["traffic_bytes"], "profiles/%s:bf16_radiance" % name)}
+            if "bf16x3_radiance" in d:
+                out["bf16x3"] = (d["bf16x3_radiance"]["traffic_bytes"], "profiles/%s:bf16x3_radiance" % name)
+            return out
+        except (OSError, KeyError, ValueError):
+            continue
+    return {}
 
 
 TRAFFIC = _static_traffic()
@@ -514,6 +519,8 @@ def main(argv=None):
     ap.add_argument("--size", type=int, default=512, help="frame is size x size rays")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="fp32 = configs[1] (exact, headline); bf16 = configs[2] (bf16 MFMA operands, fp32 accumulate)")
+    ap.add_argument("--arch", default="audio", choices=["audio", "nerface"], help="audio = AudioFaceModel (the headline); nerface = the "
+                    "expression-driven NeRFaceModel of config/expression/person_2.yml (profiling of that leg; fp32 or bf16 = mixed precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the torch_gpu_baseline / cpu_baseline legs")
     ap.add_argument("--no-secondary", action="store_true", help="headline only (no bf16 / NeRFace / num_fine128 / training legs)")
     args = ap.parse_args(argv)
@@ -550,8 +557,8 @@ def main(argv=None):
         result["rehearsal"] = "control flow only (CPU, %s, injected renderer): not a measurement" % backend
     else:
         pkg = importlib.import_module("sahs-deformable-nerf_amd")
-        result, out, rend = measure(pkg, dev, args.size, args.precision, args.steps, args.warmup, world=world, dist=dist)
-        if args.precision == "fp32" and world == 1:
+        result, out, rend = measure(pkg, dev, args.size, args.precision, args.steps, args.warmup, arch=args.arch, world=world, dist=dist)
+        if args.precision == "fp32" and world == 1 and args.arch == "audio":
             if not args.no_secondary:
                 add_secondary_legs(result, pkg, dev, args)
             if not args.no_cpu_baseline:

@@ -210,7 +210,10 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-constexpr int DST = 3;                        // ring depth
+// ring depth: 3 for the data-gradient GEMM (48 KB of LDS, three workgroups per CU, 16-step K loops), 4 for the weight-gradient GEMM (64 KB,
+// two workgroups per CU by its registers anyway, K loops of 32..512 steps: three K-steps = 48 KB per workgroup in flight -- the
+// kernel is HBM-bound and at depth 3 it reached 3.7 TB/s with 64 KB per CU in flight)
+template <bool TA> constexpr int ring_depth() { return TA ? 4 : 3; }
 constexpr int DTILE = GK * GT;                // floats per operand tile (8 KB)
 
 // eight fp32 values (this lane's k = 8h .. 8h+7 of one row/column) -> the bf16x8 MFMA fragments of their hi and lo parts
@@ -243,6 +246,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
     // X[r][n] > 0.  The weight-gradient GEMM (TA) WRITES it for its B operand X from the tiles it stages anyway (the m-block-0 workgroups);
     // the data-gradient GEMM of the same layer, which follows it and whose (leaky-)ReLU mask is that same X, READS it instead of the fp32
     // matrix -- 1/32 of the bytes of what was a third of its HBM traffic.
+    constexpr int DST = ring_depth<TA>();
     __shared__ __attribute__((aligned(16))) float smem[DST][2][DTILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c16 = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
@@ -277,7 +281,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int rp = (wave & 1) * 4 + u;                 // 0..7: which 1-KB eighth of the tile
-        if (wave < 2 && !TA) {                               // A, row-major [128 m][16 k]: 4 chunks per row
+        if (X3 && !TA && wave >= 2) {                        // B = pre-split, fragment-ordered weight pieces: a linear 8 KB copy per K-step
+            src[u] = B + ((k_lo / GK) * (long)nbn + bx) * (GK * GT) + (rp * 64 + lane) * 4;
+            step[u] = (long)nbn * (GK * GT);
+            krow[u] = 0;
+            colok[u] = true;
+        } else if (wave < 2 && !TA) {                        // A, row-major [128 m][16 k]: 4 chunks per row
             const int chunk = rp * 64 + lane, m = chunk >> 2, kc = chunk & 3;
             src[u] = A + (m0 + m) * lda + k_lo + 4 * kc;
             step[u] = GK;
@@ -350,12 +359,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
     // vector-memory instructions a wave executes between kernel entry and the end of the loop are its 4 LDS-DMA instructions per
     // issue(); they complete in issue order, so "vmcnt(4)" at step t means step t has landed while step t+1 may still be in flight --
     // and any further VMEM instruction the compiler might ever add there could only make that wait stricter, never weaker.
+    // (depth DST: steps t+1 .. t+DST-2 may be in flight at step t's wait -- 4 DMA instructions each -- and step t+DST-1 is issued after it)
     if (T > 0) issue(0);      // an empty K slab (k_lo >= K) issues nothing and falls through to a zero contribution
     if (T > 1) issue(1);
+    if (DST > 3 && T > 2) issue(2);
     for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        if (DST > 3 && t + 2 < T) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t + 2 < T) issue(t + 2);          // into the buffer every wave finished reading before the barrier above
+        if (t + DST - 1 < T) issue(t + DST - 1);          // into the buffer every wave finished reading before the barrier above
         const float *As = &smem[t % DST][0][0], *Bs = &smem[t % DST][1][0];
         if (TA && bits != nullptr && by == 0) {      // thread (kk, g): the 8 columns 8g .. 8g+7 of sample row kk of the X tile -> one byte
             const int kk = tid >> 4, g = tid & 15;
@@ -386,10 +398,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                float x[8];
+                if constexpr (TA) {
+                    float x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = Bs[(8 * h + j) * GT + x3b[i][TA ? (j & 1) : (j >> 2)]];
-                split8(x, bh[i], bl[i]);
+                    for (int j = 0; j < 8; ++j) x[j] = Bs[(8 * h + j) * GT + x3b[i][j & 1]];
+                    split8(x, bh[i], bl[i]);
+                } else {      // weights arrive split and in fragment order (CopyJob pack): n-tile 2 wn + i, hi then lo
+                    bh[i] = *reinterpret_cast<const u32x4_t *>(Bs + ((2 * wn + i) * 64 + lane) * 4);
+                    bl[i] = *reinterpret_cast<const u32x4_t *>(Bs + GK * GT / 2 + ((2 * wn + i) * 64 + lane) * 4);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -743,7 +760,11 @@ __global__ void axpy_kernel(int n, const float *__restrict__ x, float *__restric
 // (1) 16-byte aligned copies of the weight sub-matrices the data-gradient GEMMs stream by LDS-DMA: all of a walk's copies in ONE launch
 //     in front of it (the walk is run once dry to collect them); (2) the per-frame-constant columns and (3) the bias gradients that went
 //     through scratch: their results are read by nothing inside the walk, so they are deferred to one launch each at its end.
-struct CopyJob { const float *src; float *dst; long lds_, ldd; int K, N; };
+struct CopyJob { const float *src; float *dst; long lds_, ldd; int K, N; int pack; };
+// pack = 1: dst is not a plain copy but the weight sub-matrix W[K x N] (K a multiple of 16) as the data-gradient GEMM's B operand, split and
+// in MFMA fragment order: per (16-row K-step, 128-column block) one 8 KB piece [hi: 4 n-tiles x 64 lanes x 8 bf16 | lo: the same], lane
+// (r, h) of n-tile t holding W[16 step + 8h + j][128 block + 32 t + r], j = 0..7 -- so the kernel's B tile is a linear 8 KB copy and a
+// fragment is one ds_read_b128, with no conversion work in the GEMM (columns past N are zero).  Pieces in (step, block) order.
 struct ConstJob { const float *W; float *dW; const float *db, *c; float *dc; long ld; int rows, cols, col0; };
 struct AxpyJob { const float *x; float *y; int n; };
 constexpr int MAX_COPY_JOBS = 48, MAX_CONST_JOBS = 24, MAX_AXPY_JOBS = 24;
@@ -751,9 +772,29 @@ struct CopyBatch { CopyJob j[MAX_COPY_JOBS]; };
 struct ConstBatch { ConstJob j[MAX_CONST_JOBS]; };
 struct AxpyBatch { AxpyJob j[MAX_AXPY_JOBS]; };
 
-__global__ void __launch_bounds__(256) copy2d_batch_kernel(CopyBatch b)
-{
+__global__ void __launch_bounds__(256) copy2d_batch_kernel(CopyBatch b, int phase)      // phase 0: the plain copies, 1: the pack jobs
+{                                                                                        // (a pack job may read what a plain copy wrote)
     const CopyJob &j = b.j[blockIdx.y];
+    if ((j.pack != 0) != (phase != 0)) return;
+    if (j.pack) {
+        const int nblk = (j.N + GT - 1) / GT;
+        const long total = (long)(j.K / 2) * nblk * GT;        // one thread per (row pair, padded column)
+        uint32_t *dst = reinterpret_cast<uint32_t *>(j.dst);
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+            const int n = (int)(e % (nblk * GT));
+            const int k = 2 * (int)(e / (nblk * GT));
+            const float x0 = n < j.N ? j.src[(long)k * j.lds_ + n] : 0.0f, x1 = n < j.N ? j.src[(long)(k + 1) * j.lds_ + n] : 0.0f;
+            const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{x0, x1}, bf16x2_t));
+            const uint32_t lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{x0 - __builtin_bit_cast(float, hi << 16),
+                                                                                                 x1 - __builtin_bit_cast(float, hi & 0xffff0000u)}, bf16x2_t));
+            const int step = k >> 4, kk = k & 15, h = kk >> 3, jp = (kk & 7) >> 1, cb = n >> 7, t = (n & 127) >> 5, r = n & 31;
+            uint32_t *piece = dst + ((long)step * nblk + cb) * (GK * GT);       // 2048 dwords = 8 KB
+            const int at = (t * 64 + h * 32 + r) * 4 + jp;                      // dword within the hi (or lo) half
+            piece[at] = hi;
+            piece[GK * GT / 2 + at] = lo;
+        }
+        return;
+    }
     const long total = (long)j.K * j.N;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long m = e / j.N; const int n = (int)(e % j.N);
@@ -827,7 +868,10 @@ struct Bwd {
     void check() { if (!err) err = (int)hipGetLastError(); }
     void flush_copies()
     {
-        if (ncopy > 0 && ncopy <= MAX_COPY_JOBS) { copy2d_batch_kernel<<<dim3(16, ncopy), 256, 0, st>>>(copies); check(); }
+        if (ncopy > 0 && ncopy <= MAX_COPY_JOBS) {
+            copy2d_batch_kernel<<<dim3(16, ncopy), 256, 0, st>>>(copies, 0); check();
+            copy2d_batch_kernel<<<dim3(16, ncopy), 256, 0, st>>>(copies, 1); check();
+        }
     }
     void flush_deferred()
     {
@@ -849,13 +893,30 @@ struct Bwd {
         const long nbm = (P + GT - 1) / GT;
         dim3 g((unsigned)(((nbm + 7) / 8) * 8 * nbn), 1, 1);
         if (K % GK == 0 && al(dY, ldy)) {
-            if (!al(W, ldw)) {
+            if (x3()) {      // the B operand pre-split into bf16 hi / lo in MFMA fragment order (CopyJob pack), one batched launch per walk
+                const long words = (long)K * nbn * GT;
+                if (walo + words > wal_cap) { if (!err) err = (int)hipErrorOutOfMemory; return; }
+                float *dst = wal + walo;
+                walo += words;
+                if (dry) {
+                    if (ncopy < MAX_COPY_JOBS) copies.j[ncopy] = CopyJob{W, dst, ldw, 0, K, N, 1};
+                    ++ncopy;
+                    return;
+                }
+                if (ncopy > MAX_COPY_JOBS) {       // more jobs than a batch holds: pack one by one
+                    CopyBatch one;
+                    one.j[0] = CopyJob{W, dst, ldw, 0, K, N, 1};
+                    copy2d_batch_kernel<<<dim3(16, 1), 256, 0, st>>>(one, 1);
+                    check();
+                }
+                W = dst; ldw = 0;
+            } else if (!al(W, ldw)) {
                 const long ldb = (N + 3) / 4 * 4;
                 if (walo + (long)K * ldb > wal_cap) { if (!err) err = (int)hipErrorOutOfMemory; return; }   // scratch sized for one level's weights
                 float *dst = wal + walo;
                 walo += (long)K * ldb;
                 if (dry) {
-                    if (ncopy < MAX_COPY_JOBS) copies.j[ncopy] = CopyJob{W, dst, ldw, ldb, K, N};
+                    if (ncopy < MAX_COPY_JOBS) copies.j[ncopy] = CopyJob{W, dst, ldw, ldb, K, N, 0};
                     ++ncopy;       // (more than MAX_COPY_JOBS: the real pass copies one by one, as before)
                     return;
                 }
@@ -1009,7 +1070,7 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
     // copies); rows of a head's gradient scratch added to the flat gradient (deferred to the end of the walk, batched)
     auto head_copy = [&](const float *src, float *dst, int rows, int cols) {
         if (!b.dry) return;
-        if (b.ncopy < MAX_COPY_JOBS) b.copies.j[b.ncopy] = CopyJob{src, dst, cols, cols, rows, cols};
+        if (b.ncopy < MAX_COPY_JOBS) b.copies.j[b.ncopy] = CopyJob{src, dst, cols, cols, rows, cols, 0};
         else b.err = (int)hipErrorOutOfMemory;
         ++b.ncopy;
     };
