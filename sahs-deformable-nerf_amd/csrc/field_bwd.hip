@@ -947,7 +947,8 @@ struct Bwd {
     {
         if (dry) return;
         const int tiles = ((N + GT - 1) / GT) * ((M + GT - 1) / GT);
-        long kslab = (P * tiles / 512 + 15) / 16 * 16;
+        static const long wg_target = getenv("SAHS_BWD_TN_WGS") ? atol(getenv("SAHS_BWD_TN_WGS")) : 512;      // (tuning aid)
+        long kslab = (P * tiles / wg_target + 15) / 16 * 16;
         kslab = kslab < 512 ? 512 : (kslab > 8192 ? 8192 : kslab);
         dim3 g((N + GT - 1) / GT, (M + GT - 1) / GT, (unsigned)((P + kslab - 1) / kslab));
         if (al(dY, ldy) && al(X, ldx)) {

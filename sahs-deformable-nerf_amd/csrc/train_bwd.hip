@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256) composite_backward_kernel(long N, int S, 
 // AudioNet (modules.py:43-73) is 4 x [Conv1d(k3,s2,p1) + LeakyReLU(0.02)] + Linear 64->64 + LeakyReLU + Linear 64->76.
 __device__ __forceinline__ float dl02(float y) { return y > 0.0f ? 1.0f : 0.02f; }
 
-__global__ void __launch_bounds__(256) conditioning_backward_kernel(const float *__restrict__ flat, const float *__restrict__ audio,
+__global__ void __launch_bounds__(1024) conditioning_backward_kernel(const float *__restrict__ flat, const float *__restrict__ audio,
                                                                     const float *__restrict__ grad_cond, float *__restrict__ grad_flat,
                                                                     float *__restrict__ grad_audio)
 {
@@ -259,13 +259,13 @@ __global__ void __launch_bounds__(256) conditioning_backward_kernel(const float 
     __shared__ float h1[64], dh[76], dh1[64];
     const int tid = threadIdx.x;
     const int cin[4] = {29, 32, 32, 64}, cout[4] = {32, 32, 64, 64};
-    for (int e = tid; e < 29 * 16; e += 256) { int c = e / 16, t = e % 16; a[0][c * 16 + t] = audio[t * 29 + c]; }
+    for (int e = tid; e < 29 * 16; e += 1024) { int c = e / 16, t = e % 16; a[0][c * 16 + t] = audio[t * 29 + c]; }
     __syncthreads();
     int L = 16;
     for (int l = 0; l < 4; ++l) {
         const int Lo = L / 2;
         const float *w = flat + F.conv_w[l], *bs = flat + F.conv_b[l];
-        for (int e = tid; e < cout[l] * Lo; e += 256) {
+        for (int e = tid; e < cout[l] * Lo; e += 1024) {
             const int o = e / Lo, t = e % Lo;
             float s = bs[o];
             for (int c = 0; c < cin[l]; ++c)
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) conditioning_backward_kernel(const float 
     if (tid < D_DRV) dh[tid] = grad_cond[tid];
     __syncthreads();
     // fc1.2: 64 -> 76
-    for (int e = tid; e < D_DRV * 64; e += 256) grad_flat[F.fc_w[1] + e] += dh[e / 64] * h1[e % 64];
+    for (int e = tid; e < D_DRV * 64; e += 1024) grad_flat[F.fc_w[1] + e] += dh[e / 64] * h1[e % 64];
     if (tid < D_DRV) grad_flat[F.fc_b[1] + tid] += dh[tid];
     if (tid < 64) {
         float s = 0.0f;
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256) conditioning_backward_kernel(const float 
     }
     __syncthreads();
     // fc1.0: 64 -> 64 (input a[4])
-    for (int e = tid; e < 64 * 64; e += 256) grad_flat[F.fc_w[0] + e] += dh1[e / 64] * a[4][e % 64];
+    for (int e = tid; e < 64 * 64; e += 1024) grad_flat[F.fc_w[0] + e] += dh1[e / 64] * a[4][e % 64];
     if (tid < 64) grad_flat[F.fc_b[0] + tid] += dh1[tid];
     if (tid < 64) {
         float s = 0.0f;
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256) conditioning_backward_kernel(const float 
         float *gw = grad_flat + F.conv_w[l], *gb = grad_flat + F.conv_b[l];
         const float *dout = d[cur];
         float *din = d[cur ^ 1];
-        for (int e = tid; e < cout[l] * cin[l] * 3; e += 256) {
+        for (int e = tid; e < cout[l] * cin[l] * 3; e += 1024) {
             const int o = e / (cin[l] * 3), c = (e / 3) % cin[l], k = e % 3;
             float s = 0.0f;
             for (int t = 0; t < Lout; ++t) {
@@ -320,12 +320,12 @@ __global__ void __launch_bounds__(256) conditioning_backward_kernel(const float 
             }
             gw[e] += s;
         }
-        for (int o = tid; o < cout[l]; o += 256) {
+        for (int o = tid; o < cout[l]; o += 1024) {
             float s = 0.0f;
             for (int t = 0; t < Lout; ++t) s += dout[o * Lout + t];
             gb[o] += s;
         }
-        for (int e = tid; e < cin[l] * Lin; e += 256) {
+        for (int e = tid; e < cin[l] * Lin; e += 1024) {
             const int c = e / Lin, ti = e % Lin;
             float s = 0.0f;
             for (int o = 0; o < cout[l]; ++o)
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256) conditioning_backward_kernel(const float 
         Lout = Lin;
     }
     if (grad_audio != nullptr)
-        for (int e = tid; e < 29 * 16; e += 256) { int c = e / 16, t = e % 16; grad_audio[t * 29 + c] += d[cur][c * 16 + t]; }
+        for (int e = tid; e < 29 * 16; e += 1024) { int c = e / 16, t = e % 16; grad_audio[t * 29 + c] += d[cur][c * 16 + t]; }
 }
 
 }  // namespace sahs
@@ -373,6 +373,6 @@ extern "C" int sahs_stage1_loss_forward_launch(long N, const float *map_c, const
 extern "C" int sahs_conditioning_backward_launch(const float *flat, const float *audio, const float *grad_cond, float *grad_flat,
                                                  float *grad_audio, hipStream_t stream)
 {
-    conditioning_backward_kernel<<<1, 256, 0, stream>>>(flat, audio, grad_cond, grad_flat, grad_audio);
+    conditioning_backward_kernel<<<1, 1024, 0, stream>>>(flat, audio, grad_cond, grad_flat, grad_audio);
     return (int)hipGetLastError();
 }
