@@ -143,6 +143,28 @@ __device__ __forceinline__ void pack_tick(const Acc &acc, Blk &o, float slope, P
         }
         return;
     }
+#ifndef SAHS_BF16W_EXACT_LEAKY      // LeakyReLU on the packed bf16 bit patterns (field_bf16w.hip: pack_tick)
+    if (slope != 1.0f) {
+        if constexpr (T - 2 >= 1 && T - 2 < NV && ((T - 2) & 1)) {
+            constexpr int U = T - 2, P = U >> 1, qq = P & 3, jp = P >> 2, rt = jp >> 1, rp = jp & 1;
+            ps.d[P & 1] = cvt_pair(acc.t[rt][qq][2 * rp], acc.t[rt][qq][2 * rp + 1]);
+        }
+        if constexpr (T - 3 >= 1 && T - 3 < NV && ((T - 3) & 1)) {
+            constexpr int U = T - 3, P = U >> 1;
+            uint32_t sg;
+            asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(sg) : "v"(ps.d[P & 1]));
+            ps.r[P & 1] = __builtin_bit_cast(float, sg);
+        }
+        if constexpr (T - 4 >= 1 && T - 4 < NV && ((T - 4) & 1)) {
+            constexpr int U = T - 4, P = U >> 1, qq = P & 3, jp = P >> 2;
+            const uint32_t kk = 0x03520352u;
+            uint32_t o_;
+            asm("v_pk_mad_i16 %0, %1, %2, %3 clamp" : "=v"(o_) : "v"(__builtin_bit_cast(uint32_t, ps.r[P & 1])), "s"(kk), "v"(ps.d[P & 1]));
+            o.s[qq][jp] = o_;
+        }
+        return;
+    }
+#endif
     if constexpr (T >= 0 && T < NV && !(T & 1)) {           // A(T), T even: both values of the pair
         constexpr int P = T >> 1, qq = P & 3, jp = P >> 2, rt = jp >> 1, rp = jp & 1;
         if (slope != 1.0f) ps.m2[P & 1] = f32x2{acc.t[rt][qq][2 * rp], acc.t[rt][qq][2 * rp + 1]} * f32x2{slope, slope};
