@@ -38,3 +38,42 @@ def spade_block(sd, x, fid, downsample=False, upsample=False):
     x2 = F.conv2d(x2, _sn_weight(sd, "conv2."), sd["conv2.bias"], padding=1)
     xs = F.leaky_relu(spade_layer(sd, "spade_s.", identity, fid), 0.2)
     return F.conv2d(xs, _sn_weight(sd, "conv_s."), sd["conv_s.bias"], padding=1) + x2
+
+
+def _sub(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def _conv_bn_relu(sd, prefix, x):
+    """Conv2d(3x3, pad 1) -> BatchNorm2d in eval mode (running statistics) -> ReLU: the `initial` / `residual` Sequentials."""
+    x = F.conv2d(x, sd[prefix + "0.weight"], sd[prefix + "0.bias"], padding=1)
+    x = F.batch_norm(x, sd[prefix + "1.running_mean"], sd[prefix + "1.running_var"], sd[prefix + "1.weight"], sd[prefix + "1.bias"], training=False, eps=1e-5)
+    return F.relu(x)
+
+
+def res_block(sd, x, downsample=False):
+    """_init_spade.py:26-37."""
+    out = _conv_bn_relu(sd, "initial.", x)
+    if downsample:
+        identity = F.conv2d(x, sd["downsample_layer.weight"], sd["downsample_layer.bias"], stride=2, padding=1)
+        return F.conv2d(out, sd["residual_downsample.weight"], sd["residual_downsample.bias"], stride=2, padding=1) + identity
+    return _conv_bn_relu(sd, "residual.", out) + x
+
+
+def id_encoder(sd, x):
+    """_init_spade.py:198-204."""
+    x = F.avg_pool2d(F.conv2d(x, sd["layer1.0.weight"], sd["layer1.0.bias"], padding=1), 2, stride=2)
+    x1 = res_block(_sub(sd, "layer2."), x)
+    x2 = res_block(_sub(sd, "layer3."), x1, downsample=True)
+    return x1, x2, res_block(_sub(sd, "layer4."), x2, downsample=True)
+
+
+def generator(sd, i_src, i_raw):
+    """_init_spade.py:302-325: Generator.forward = RefineNetwork(I_raw, *IdEncoder(I_src))."""
+    f1, f2, f3 = id_encoder(_sub(sd, "idencoder."), i_src)
+    r = _sub(sd, "refine_network.")
+    x = F.avg_pool2d(F.conv2d(i_raw, r["layer1.0.weight"], r["layer1.0.bias"], padding=1), 2, stride=2)
+    for name, fid, down, up in (("layer2.", f1, True, False), ("layer3.", f2, True, False), ("layer4.", f3, False, False),
+                                ("layer5.", f3, False, True), ("layer6.", f2, False, True), ("layer7.", f1, False, True)):
+        x = spade_block(_sub(r, name), x, fid, downsample=down, upsample=up)
+    return F.conv2d(x, r["layer8.weight"], r["layer8.bias"], padding=1)

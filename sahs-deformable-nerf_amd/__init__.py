@@ -6,7 +6,7 @@ or through the ``sahs_amd`` alias module at the repo root.
 """
 from . import weights, cfgnode                      # noqa: F401  (pure python, no GPU needed)
 from . import _lib, ops                             # noqa: F401  (binds libsahs_nerf.so lazily, fails loudly)
-from . import models, nerf_helpers, train_utils, volume_rendering_utils, distributed, training, evaluation   # noqa: F401
+from . import models, nerf_helpers, train_utils, volume_rendering_utils, distributed, training, evaluation, spade   # noqa: F401
 from .cfgnode import CfgNode, default_config        # noqa: F401
 from .models import AudioFaceModel, NeRFaceModel    # noqa: F401
 from .train_utils import run_one_iter_of_nerf, predict_and_render_radiance, run_network   # noqa: F401

@@ -71,3 +71,77 @@ class SPADEBlock(nn.Module):
         x2 = self.conv2_sn(self.spade2(x1, fid, _slope=self.lrelu2.negative_slope))
         x_ = self.conv_s(self.spade_s(identity, fid, _slope=self.lrelu_s.negative_slope))
         return x_ + x2
+
+
+def _conv_bn_relu(cin, cout):
+    return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=3, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=False))
+
+
+class ResBlock2d(nn.Module):
+    """_init_spade.py:7-37 (the identity encoder's residual block; library convolutions and batch norm throughout)."""
+
+    def __init__(self, in_channels, out_channels, downsample=False):
+        super().__init__()
+        self.downsample = downsample
+        self.initial = _conv_bn_relu(in_channels, out_channels)
+        if downsample:
+            self.downsample_layer = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=2, padding=1)
+            self.residual_downsample = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=2, padding=1)
+        self.residual = _conv_bn_relu(out_channels, out_channels)
+
+    def forward(self, x):
+        out = self.initial(x)
+        if self.downsample:
+            return self.residual_downsample(out) + self.downsample_layer(x)
+        return self.residual(out) + x
+
+
+class IdEncoder(nn.Module):
+    """_init_spade.py:185-204: the three identity feature maps (64, 128, 256 channels at 1/2, 1/4, 1/8 resolution) that modulate the refiner."""
+
+    def __init__(self):
+        super().__init__()
+        self.layer1 = nn.Sequential(nn.Conv2d(3, 64, kernel_size=3, padding=1), nn.AvgPool2d(2, stride=2))
+        self.layer2 = ResBlock2d(64, 64)
+        self.layer3 = ResBlock2d(64, 128, downsample=True)
+        self.layer4 = ResBlock2d(128, 256, downsample=True)
+
+    def forward(self, x):
+        x1 = self.layer2(self.layer1(x))
+        x2 = self.layer3(x1)
+        return x1, x2, self.layer4(x2)
+
+
+class RefineNetwork(nn.Module):
+    """_init_spade.py:284-312: conv + pool, six SPADE blocks (down, down, -, up, up, up), conv."""
+
+    def __init__(self, fid_channels1, fid_channels2, fid_channels3):
+        super().__init__()
+        self.layer1 = nn.Sequential(nn.Conv2d(3, 64, kernel_size=3, padding=1), nn.AvgPool2d(2, stride=2))
+        self.layer2 = SPADEBlock(64, 64, fid_channels1, downsample=True)
+        self.layer3 = SPADEBlock(64, 128, fid_channels2, downsample=True)
+        self.layer4 = SPADEBlock(128, 256, fid_channels3)
+        self.layer5 = SPADEBlock(256, 256, fid_channels3, upsample=True)
+        self.layer6 = SPADEBlock(256, 128, fid_channels2, upsample=True)
+        self.layer7 = SPADEBlock(128, 64, fid_channels1, upsample=True)
+        self.layer8 = nn.Conv2d(64, 3, kernel_size=3, padding=1)
+
+    def forward(self, x, fid1, fid2, fid3):
+        x = self.layer1(x)
+        for block, fid in ((self.layer2, fid1), (self.layer3, fid2), (self.layer4, fid3), (self.layer5, fid3), (self.layer6, fid2), (self.layer7, fid1)):
+            x = block(x, fid)
+        return self.layer8(x)
+
+
+class Generator(nn.Module):
+    """_init_spade.py:315-325: the Stage-II generator G(I_src, I_raw) of eval_get_texture_photo_audio.py:154 -- identity features of the
+    source image modulate the refinement of the Stage-I render.  Inference only (see SPADELayer)."""
+
+    def __init__(self):
+        super().__init__()
+        self.idencoder = IdEncoder()
+        self.refine_network = RefineNetwork(64, 128, 256)
+
+    def forward(self, I_src, I_raw):
+        fid1, fid2, fid3 = self.idencoder(I_src)
+        return self.refine_network(I_raw, fid1, fid2, fid3)

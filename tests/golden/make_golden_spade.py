@@ -56,6 +56,28 @@ def main():
         for k, v in m.state_dict().items():
             out[name + ":sd:" + k] = v.detach().numpy()
         print(name, tuple(x.shape), "->", tuple(y.shape), "state_dict keys:", len(m.state_dict()))
+    # The whole Stage-II generator (:315-325; 17.3 M parameters -- not stored: a fixed seed regenerates them, the drop-in's constructor
+    # creates its parameters in the reference's order, and a checksum pins that the two initialisations are the same tensor for tensor)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    mine = importlib.import_module("sahs-deformable-nerf_amd.spade")
+    torch.manual_seed(7)
+    G = S.Generator().eval()
+    torch.manual_seed(7)
+    Gm = mine.Generator().eval()
+    sd, sdm = G.state_dict(), Gm.state_dict()
+    assert list(sd.keys()) == list(sdm.keys()), "state_dict layout differs from the reference's"
+    assert all(torch.equal(sd[k], sdm[k]) for k in sd), "seeded initialisation differs from the reference's"
+    gen = torch.Generator().manual_seed(11)
+    i_src, i_raw = torch.rand(1, 3, 64, 64, generator=gen), torch.rand(1, 3, 64, 64, generator=gen)
+    with torch.no_grad():
+        y = G(i_src, i_raw)
+        f1, f2, f3 = G.idencoder(i_src)
+    out["generator:i_src"], out["generator:i_raw"], out["generator:y"] = i_src.numpy(), i_raw.numpy(), y.numpy()
+    out["generator:fid3"] = f3.numpy()
+    out["generator:seed"] = np.array(7, np.int64)
+    out["generator:param_count"] = np.array(sum(v.numel() for v in sd.values()), np.int64)
+    out["generator:param_abs_sum"] = np.array(sum(float(v.double().abs().sum()) for v in sd.values()), np.float64)
+    print("generator", tuple(i_src.shape), "->", tuple(y.shape), "state_dict entries:", len(sd), "values:", int(out["generator:param_count"]))
     np.savez_compressed(os.path.join(HERE, "spade.npz"), **out)
     print("wrote", os.path.join(HERE, "spade.npz"), os.path.getsize(os.path.join(HERE, "spade.npz")), "bytes")
 

@@ -166,3 +166,30 @@ def test_side_stream_and_graph_capture(ops, setup):
     torch.cuda.synchronize()
     for a, b in zip(captured, ref):
         assert torch.equal(a, b)
+
+
+def test_launch_probe_and_backward_precision_edges(ops, setup):
+    """The round-3 additions to the C ABI at their edges: a probe smaller than the number of launches counts the rest as dropped (and says
+    so instead of returning a short list), re-arming resets it, reading past the count is an error; the backward GEMM precision switch
+    rejects anything but its two values and is restored."""
+    L = pkg("_lib").lib()
+    import ctypes
+    _, packed, frame, _, _ = setup
+    rays, z = T(make_rays(8, 3)[0]), torch.zeros(8, 4, device=dev()) + 0.6
+    with ops.LaunchProbe(2) as probe:
+        for _ in range(3):
+            ops.field_forward(packed, frame, 0, rays, z)
+        assert L.sahs_probe_count() == 2 and L.sahs_probe_dropped() == 1
+        with pytest.raises(Exception):
+            probe.records()
+    with ops.LaunchProbe(4) as probe:
+        ops.field_forward(packed, frame, 1, rays, z)
+        recs = probe.records()
+    assert len(recs) == 1 and recs[0]["level"] == 1 and recs[0]["part"] == 0 and recs[0]["samples"] == 32 and recs[0]["ms"] > 0.0
+    k, n, ms = ctypes.c_int(), ctypes.c_long(), ctypes.c_float()
+    assert L.sahs_probe_read(5, ctypes.byref(k), ctypes.byref(n), ctypes.byref(ms)) != 0
+    assert L.sahs_probe_arm(0) != 0
+    assert ops.backward_gemm_precision() == "bf16x3"
+    assert L.sahs_backward_gemm_precision(1) == -1 and ops.backward_gemm_precision() == "bf16x3"
+    assert ops.backward_gemm_precision("fp32") == "fp32" and ops.backward_gemm_precision() == "fp32"
+    assert ops.backward_gemm_precision("bf16x3") == "bf16x3"

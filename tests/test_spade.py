@@ -43,6 +43,45 @@ def test_spade_modules_have_the_reference_state_dict():
             S.SPADELayer(6, 5)(torch.zeros(1, 6, 4, 4), torch.zeros(1, 5, 4, 4))
 
 
+def _seeded_generator(g):
+    """The drop-in Generator under the fixture's seed: the reference's own initialisation, tensor for tensor (make_golden_spade.py asserts
+    it against the imported reference; the checksum pins it here)."""
+    S = pkg("spade")
+    torch.manual_seed(int(g["generator:seed"]))
+    G = S.Generator().eval()
+    sd = G.state_dict()
+    assert sum(v.numel() for v in sd.values()) == int(g["generator:param_count"])
+    total = sum(float(v.double().abs().sum()) for v in sd.values())
+    assert abs(total - float(g["generator:param_abs_sum"])) <= 1e-9 * total, "seeded initialisation differs from the fixture's (another torch build?)"
+    return G
+
+
+def test_generator_restatement_vs_reference():
+    """The whole Stage-II generator (IdEncoder + RefineNetwork, 17.3 M parameters regenerated from the fixture's seed) by the CPU restatement
+    against the reference's output; the identity encoder's deepest feature map as an inner seam."""
+    from oracle import spade_eager as SE
+    g = load_golden("spade")
+    sd = _seeded_generator(g).state_dict()
+    with torch.no_grad():
+        y = SE.generator(sd, torch.from_numpy(g["generator:i_src"]), torch.from_numpy(g["generator:i_raw"]))
+        f3 = SE.id_encoder({k[len("idencoder."):]: v for k, v in sd.items() if k.startswith("idencoder.")}, torch.from_numpy(g["generator:i_src"]))[2]
+    assert np.abs(f3.numpy() - g["generator:fid3"]).max() <= 1e-4 * np.abs(g["generator:fid3"]).max()
+    assert y.shape == g["generator:y"].shape
+    assert np.abs(y.numpy() - g["generator:y"]).max() <= 2e-4 * np.abs(g["generator:y"]).max()
+
+
+@pytest.mark.gpu
+def test_generator_vs_reference_on_gpu():
+    g = load_golden("spade")
+    dev = torch.device("cuda:0")
+    G = _seeded_generator(g).to(dev)
+    with torch.no_grad():
+        y = G(torch.from_numpy(g["generator:i_src"]).to(dev), torch.from_numpy(g["generator:i_raw"]).to(dev))
+    ref = g["generator:y"]
+    assert tuple(y.shape) == ref.shape
+    assert float((y.cpu() - torch.from_numpy(ref)).abs().max()) <= 5e-4 * float(np.abs(ref).max())      # 7 SPADE blocks of MIOpen convolutions deep
+
+
 @pytest.mark.gpu
 def test_spade_modules_vs_reference_on_gpu():
     S, ops = pkg("spade"), pkg("ops")
