@@ -62,3 +62,55 @@ def test_two_ranks_render_one_frame_together(tmp_path, size):
     torch.save(ref, str(tmp_path / "ref.pt"))
     port = 37500 + (os.getpid() % 2000)
     mp.start_processes(_worker, args=(2, port, size, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+
+
+def _train_worker(rank, world, port, path):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import importlib
+    sahs = importlib.import_module("sahs-deformable-nerf_amd")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        W, Tr = sahs.weights, sahs.training
+        cfg = sahs.default_config()
+        cfg.nerf.train.num_random_rays = 256
+        model = sahs.AudioFaceModel(cfg).to(dev).load_flat(W.flatten_state_dict(W.hash_state_dict(**VARIANT_KW["hdr"]))).train()
+        opt = torch.optim.Adam(model.parameters(), lr=float(cfg.optimizer.lr))
+        g = torch.Generator(device=dev).manual_seed(5)
+        H = Wd = 32
+        image = torch.rand(H, Wd, 3, device=dev, generator=g)
+        mask = torch.zeros(H, Wd, 12, device=dev).scatter_(2, torch.randint(0, 12, (H, Wd, 1), device=dev, generator=g), 1.0)
+        bg = torch.cat([torch.rand(H, Wd, 3, device=dev, generator=g), torch.ones(H, Wd, 1, device=dev), torch.zeros(H, Wd, 11, device=dev)], 2)
+        audio = torch.randn(16, 29, device=dev, generator=g)
+        pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32)).to(dev)
+        intr = np.array([1200.0 * H / 512, 1200.0 * H / 512, 0.5, 0.5], np.float32)
+        prob = torch.ones(12, device=dev) / 12
+        torch.manual_seed(100 + rank)          # the ranks' own noise streams differ (as they would on separate GPUs) ...
+        out = None
+        for step in range(2):                  # ... the batch draw does not: one generator state on every rank
+            out = Tr.train_step(model, opt, cfg, step, image, mask, pose, intr, audio, bg, prob, generator=torch.Generator(device=dev).manual_seed(9 + step))
+            prob = out["sample_prob"]
+        flat = model.flat_params().cpu()
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1]), "the replicas diverged: max %.3e" % float((both[0] - both[1]).abs().max())
+        start = torch.from_numpy(W.flatten_state_dict(W.hash_state_dict(**VARIANT_KW["hdr"])))
+        assert bool(torch.isfinite(flat).all()) and float((flat - start).abs().max()) > 0.0 and np.isfinite(out["loss"])
+        assert abs(float(prob.sum()) - 1.0) < 1e-5
+        if rank == 0:
+            torch.save(dict(loss=out["loss"], prob=prob.cpu()), os.path.join(path, "r0.pt"))
+        dist.barrier()
+        if rank == 1:
+            r0 = torch.load(os.path.join(path, "r0.pt"))
+            assert r0["loss"] == out["loss"] and torch.equal(r0["prob"], prob.cpu())       # the reduced statistics are the same number on both
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_train_data_parallel(tmp_path):
+    """training.train_step on two ranks (HIP forward/backward on each rank's slice of the 256-ray batch, gradients and the sampling
+    feedback all-reduced over gloo): after two steps the replicas hold bit-identical parameters, loss and sample_prob."""
+    port = 39500 + (os.getpid() % 2000)
+    mp.start_processes(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
