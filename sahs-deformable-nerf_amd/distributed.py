@@ -7,6 +7,8 @@ the reference's 8-tuple) assembles the frame on every rank.  On a fully connecte
 all-gather moves 4.7 MB per rank per 512x512 frame -- microseconds against the render.
 The functions are backend-agnostic (the CPU tests run them over gloo).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -59,7 +61,10 @@ def all_gather_rows_inplace(full, num_rays, group=None):
     rank = dist.get_rank(group)
     lo, hi = shard_bounds(num_rays, world, rank)
     if num_rays % world == 0 and full.is_contiguous():
-        dist.all_gather_into_tensor(full, full[lo:hi], group=group)
+        # SAHS_ALLGATHER_OUT_OF_PLACE=1: send from a copy of the slice instead (an escape hatch should a collective library ever reject
+        # the aliasing; costs one copy of R/N x 36 floats)
+        send = full[lo:hi].clone() if os.environ.get("SAHS_ALLGATHER_OUT_OF_PLACE") else full[lo:hi]
+        dist.all_gather_into_tensor(full, send, group=group)
         return full
     full.copy_(all_gather_rows(full[lo:hi].contiguous(), num_rays, group))
     return full
