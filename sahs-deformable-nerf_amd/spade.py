@@ -15,121 +15,129 @@ from torch.nn.utils import spectral_norm
 from . import ops
 
 
+def _conv3(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 3, stride, 1)
+
+
 class SPADELayer(nn.Module):
-    """_init_spade.py:114-139: out = InstanceNorm(x) * (1 + gamma(F_id)) + beta(F_id), F_id resized to x by nearest neighbour."""
+    """_init_spade.py:114-139: out = InstanceNorm(x) * (1 + gamma(F_id)) + beta(F_id), F_id resized to x by nearest neighbour.
+    The parameter-free norm and the activation of the reference's module tree hold no state and are not modules here: they are the
+    fused kernel's ``eps`` and ``slope``."""
+    HIDDEN = 128
+    EPS = 1e-5          # nn.InstanceNorm2d's default, which the reference uses
 
     def __init__(self, norm_nc, label_nc):
         super().__init__()
-        self.param_free_norm = nn.InstanceNorm2d(norm_nc, affine=False)      # no parameters; kept for the module tree (eps 1e-5)
-        self.mlp_shared = nn.Sequential(nn.Conv2d(label_nc, 128, kernel_size=3, padding=1), nn.ReLU(inplace=False))
-        self.conv_gamma = nn.Conv2d(128, norm_nc, kernel_size=3, padding=1)
-        self.conv_beta = nn.Conv2d(128, norm_nc, kernel_size=3, padding=1)
+        self.mlp_shared = nn.Sequential(_conv3(label_nc, self.HIDDEN), nn.ReLU())
+        self.conv_gamma, self.conv_beta = _conv3(self.HIDDEN, norm_nc), _conv3(self.HIDDEN, norm_nc)
 
     def forward(self, x, F_id, _slope=1.0):
         """_slope (not in the reference): the LeakyReLU slope of the SPADEBlock that follows, fused into the modulate kernel."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError("the fused SPADE modulation is inference-only: call under torch.no_grad()")
-        F_id = F.interpolate(F_id, size=x.size()[2:], mode="nearest")
-        actv = self.mlp_shared(F_id)
-        return ops.spade_modulate(x, self.conv_gamma(actv), self.conv_beta(actv), eps=self.param_free_norm.eps, slope=_slope)
+        hidden = self.mlp_shared(F.interpolate(F_id, size=x.shape[-2:], mode="nearest"))
+        return ops.spade_modulate(x, self.conv_gamma(hidden), self.conv_beta(hidden), eps=self.EPS, slope=_slope)
 
 
 class SPADEBlock(nn.Module):
-    """_init_spade.py:235-282."""
+    """_init_spade.py:235-282: two SPADE -> LeakyReLU -> spectral-normalised conv stages plus a SPADE shortcut, optionally halving
+    (average pool on the main branch, strided conv on the shortcut) or doubling (nearest upsample / transposed conv) the resolution
+    between the stages.  Registration order = the reference's: it fixes both the state_dict key order and the order in which the
+    initialisers draw from the global RNG (tests/test_spade.py regenerates the reference's seeded weights)."""
+    SLOPE = 0.2
 
     def __init__(self, in_channels, out_channels, fid_channels, downsample=False, upsample=False):
         super().__init__()
-        self.spade1 = SPADELayer(in_channels, fid_channels)
-        self.lrelu1 = nn.LeakyReLU(0.2)
-        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1)
-        self.conv1_sn = spectral_norm(self.conv1)            # the same module under a second name, as in the reference
-        self.spade2 = SPADELayer(out_channels, fid_channels)
-        self.lrelu2 = nn.LeakyReLU(0.2)
-        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1)
-        self.conv2_sn = spectral_norm(self.conv2)
-        self.downsample = downsample
-        if downsample:
-            self.downsampler = nn.AvgPool2d(2, stride=2)
-            self.residual_downsample = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=1)
-        self.upsample = upsample
-        if upsample:
-            self.upsampler = nn.Upsample(scale_factor=2, mode="nearest")
-            self.residual_upsample = nn.ConvTranspose2d(in_channels, in_channels, kernel_size=3, stride=2, padding=1, output_padding=1)
+        for tag, cin in (("1", in_channels), ("2", out_channels)):
+            self.add_module("spade" + tag, SPADELayer(cin, fid_channels))
+            conv = _conv3(cin, out_channels)
+            self.add_module("conv" + tag, conv)
+            self.add_module("conv%s_sn" % tag, spectral_norm(conv))      # the same module under a second name, as in the reference
+        self.downsample, self.upsample = bool(downsample), bool(upsample)
+        if self.downsample:
+            self.residual_downsample = _conv3(in_channels, in_channels, stride=2)
+        if self.upsample:
+            self.residual_upsample = nn.ConvTranspose2d(in_channels, in_channels, 3, 2, 1, output_padding=1)
         self.spade_s = SPADELayer(in_channels, fid_channels)
-        self.lrelu_s = nn.LeakyReLU(0.2)
-        self.conv_s = spectral_norm(nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1))
+        self.conv_s = spectral_norm(_conv3(in_channels, out_channels))
 
     def forward(self, x, fid):
-        identity = x
-        x1 = self.conv1_sn(self.spade1(x, fid, _slope=self.lrelu1.negative_slope))
+        main = self.conv1_sn(self.spade1(x, fid, _slope=self.SLOPE))
+        skip = x
         if self.downsample:
-            x1 = self.downsampler(x1)
-            identity = self.residual_downsample(identity)
+            main, skip = F.avg_pool2d(main, 2, 2), self.residual_downsample(skip)
         if self.upsample:
-            x1 = self.upsampler(x1)
-            identity = self.residual_upsample(identity)
-        x2 = self.conv2_sn(self.spade2(x1, fid, _slope=self.lrelu2.negative_slope))
-        x_ = self.conv_s(self.spade_s(identity, fid, _slope=self.lrelu_s.negative_slope))
-        return x_ + x2
+            main, skip = F.interpolate(main, scale_factor=2, mode="nearest"), self.residual_upsample(skip)
+        main = self.conv2_sn(self.spade2(main, fid, _slope=self.SLOPE))
+        return self.conv_s(self.spade_s(skip, fid, _slope=self.SLOPE)) + main
 
 
 def _conv_bn_relu(cin, cout):
-    return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=3, padding=1), nn.BatchNorm2d(cout), nn.ReLU(inplace=False))
+    return nn.Sequential(_conv3(cin, cout), nn.BatchNorm2d(cout), nn.ReLU())
+
+
+def _stem():
+    """conv 3 -> 64 at full resolution, then 2x average pool: the first layer of both the identity encoder and the refiner."""
+    return nn.Sequential(_conv3(3, 64), nn.AvgPool2d(2, 2))
 
 
 class ResBlock2d(nn.Module):
-    """_init_spade.py:7-37 (the identity encoder's residual block; library convolutions and batch norm throughout)."""
+    """_init_spade.py:7-37 (the identity encoder's residual block; library convolutions and batch norm throughout).  As in the
+    reference a non-downsampling block needs in_channels == out_channels, and a downsampling one does not use ``residual``."""
 
     def __init__(self, in_channels, out_channels, downsample=False):
         super().__init__()
-        self.downsample = downsample
+        self.downsample = bool(downsample)
         self.initial = _conv_bn_relu(in_channels, out_channels)
-        if downsample:
-            self.downsample_layer = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=2, padding=1)
-            self.residual_downsample = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=2, padding=1)
+        if self.downsample:
+            self.downsample_layer = _conv3(in_channels, out_channels, stride=2)
+            self.residual_downsample = _conv3(out_channels, out_channels, stride=2)
         self.residual = _conv_bn_relu(out_channels, out_channels)
 
     def forward(self, x):
-        out = self.initial(x)
-        if self.downsample:
-            return self.residual_downsample(out) + self.downsample_layer(x)
-        return self.residual(out) + x
+        y = self.initial(x)
+        return self.residual_downsample(y) + self.downsample_layer(x) if self.downsample else self.residual(y) + x
 
 
 class IdEncoder(nn.Module):
     """_init_spade.py:185-204: the three identity feature maps (64, 128, 256 channels at 1/2, 1/4, 1/8 resolution) that modulate the refiner."""
+    WIDTHS = (64, 128, 256)
 
     def __init__(self):
         super().__init__()
-        self.layer1 = nn.Sequential(nn.Conv2d(3, 64, kernel_size=3, padding=1), nn.AvgPool2d(2, stride=2))
-        self.layer2 = ResBlock2d(64, 64)
-        self.layer3 = ResBlock2d(64, 128, downsample=True)
-        self.layer4 = ResBlock2d(128, 256, downsample=True)
+        self.layer1 = _stem()
+        cin = self.WIDTHS[0]
+        for i, cout in enumerate(self.WIDTHS):
+            self.add_module("layer%d" % (i + 2), ResBlock2d(cin, cout, downsample=i > 0))
+            cin = cout
 
     def forward(self, x):
-        x1 = self.layer2(self.layer1(x))
-        x2 = self.layer3(x1)
-        return x1, x2, self.layer4(x2)
+        x, maps = self.layer1(x), []
+        for i in range(len(self.WIDTHS)):
+            x = getattr(self, "layer%d" % (i + 2))(x)
+            maps.append(x)
+        return tuple(maps)
 
 
 class RefineNetwork(nn.Module):
-    """_init_spade.py:284-312: conv + pool, six SPADE blocks (down, down, -, up, up, up), conv."""
+    """_init_spade.py:284-312: stem, six SPADE blocks (down, down, same, up, up, up; block k is modulated by identity map PLAN[k][2]),
+    conv to RGB."""
+    #        (in, out, identity map, resample)
+    PLAN = ((64, 64, 0, "down"), (64, 128, 1, "down"), (128, 256, 2, None), (256, 256, 2, "up"), (256, 128, 1, "up"), (128, 64, 0, "up"))
 
     def __init__(self, fid_channels1, fid_channels2, fid_channels3):
         super().__init__()
-        self.layer1 = nn.Sequential(nn.Conv2d(3, 64, kernel_size=3, padding=1), nn.AvgPool2d(2, stride=2))
-        self.layer2 = SPADEBlock(64, 64, fid_channels1, downsample=True)
-        self.layer3 = SPADEBlock(64, 128, fid_channels2, downsample=True)
-        self.layer4 = SPADEBlock(128, 256, fid_channels3)
-        self.layer5 = SPADEBlock(256, 256, fid_channels3, upsample=True)
-        self.layer6 = SPADEBlock(256, 128, fid_channels2, upsample=True)
-        self.layer7 = SPADEBlock(128, 64, fid_channels1, upsample=True)
-        self.layer8 = nn.Conv2d(64, 3, kernel_size=3, padding=1)
+        fid_channels = (fid_channels1, fid_channels2, fid_channels3)
+        self.layer1 = _stem()
+        for k, (cin, cout, which, how) in enumerate(self.PLAN):
+            self.add_module("layer%d" % (k + 2), SPADEBlock(cin, cout, fid_channels[which], downsample=how == "down", upsample=how == "up"))
+        self.layer8 = _conv3(64, 3)
 
     def forward(self, x, fid1, fid2, fid3):
+        fids = (fid1, fid2, fid3)
         x = self.layer1(x)
-        for block, fid in ((self.layer2, fid1), (self.layer3, fid2), (self.layer4, fid3), (self.layer5, fid3), (self.layer6, fid2), (self.layer7, fid1)):
-            x = block(x, fid)
+        for k, plan in enumerate(self.PLAN):
+            x = getattr(self, "layer%d" % (k + 2))(x, fids[plan[2]])
         return self.layer8(x)
 
 
@@ -140,8 +148,7 @@ class Generator(nn.Module):
     def __init__(self):
         super().__init__()
         self.idencoder = IdEncoder()
-        self.refine_network = RefineNetwork(64, 128, 256)
+        self.refine_network = RefineNetwork(*IdEncoder.WIDTHS)
 
     def forward(self, I_src, I_raw):
-        fid1, fid2, fid3 = self.idencoder(I_src)
-        return self.refine_network(I_raw, fid1, fid2, fid3)
+        return self.refine_network(I_raw, *self.idencoder(I_src))
