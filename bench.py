@@ -490,13 +490,33 @@ def launch_children(gpus, argv):
     with the children's status; rank 0's JSON line is the children's only stdout."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    progress("no launcher in the environment: starting %d ranks: %s" % (gpus, " ".join(cmd)))
-    return subprocess.call(cmd)
+    import threading
+    rc = 1
+    for attempt in range(2):      # the rendezvous port is free when picked but not reserved: if the launcher then finds it taken, pick another, once
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+        progress("no launcher in the environment: starting %d ranks: %s" % (gpus, " ".join(cmd)))
+        child = subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True, errors="replace")
+        port_taken = []
+
+        def relay():
+            for line in child.stderr:
+                sys.stderr.write(line)
+                if "ddress already in use" in line or "EADDRINUSE" in line:
+                    port_taken.append(line)
+            sys.stderr.flush()
+
+        th = threading.Thread(target=relay, daemon=True)
+        th.start()
+        rc = child.wait()
+        th.join(timeout=10)
+        if rc == 0 or not port_taken:
+            break
+        progress("rendezvous port %d was taken by another process: retrying once on a new port" % port)
+    return rc
 
 
 def load_injected_renderer(spec, args, world, rank):

@@ -216,9 +216,16 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <bool TA> constexpr int ring_depth() { return TA ? 4 : 3; }
 constexpr int DTILE = GK * GT;                // floats per operand tile (8 KB)
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() is a full fence and makes the compiler drain vmcnt too, i.e. wait for every
+// outstanding global STORE to be acknowledged -- not needed where the barrier only protects a staging buffer in LDS
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // eight fp32 values (this lane's k = 8h .. 8h+7 of one row/column) -> the bf16x8 MFMA fragments of their hi and lo parts
 __device__ __forceinline__ void split8(const float (&x)[8], u32x4_t &hi, u32x4_t &lo)
 {
+#ifdef SAHS_GEMM_ABL_NOSPLIT
+    for (int p = 0; p < 4; ++p) { hi[p] = __builtin_bit_cast(uint32_t, x[2 * p]); lo[p] = __builtin_bit_cast(uint32_t, x[2 * p + 1]); }
+    return;
+#endif
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{x[2 * p], x[2 * p + 1]}, bf16x2_t));
@@ -229,12 +236,22 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4_t &hi, u32x4_t
 }
 __device__ __forceinline__ f32x16_t mfma3(const u32x4_t &ah, const u32x4_t &al, const u32x4_t &bh, const u32x4_t &bl, f32x16_t c)
 {
+#ifdef SAHS_GEMM_ABL_NOMFMA
+    asm volatile("" :: "v"(ah), "v"(al), "v"(bh), "v"(bl));
+    return c;
+#endif
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bl), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, bh), c, 0, 0, 0);
     return c;
 }
 
+#ifdef SAHS_GEMM_STAMP      // diagnostic build (tools/stamp_gemm.py): where a wave's cycles go, summed over every wave of every launch
+constexpr int STAMP_SLOTS = 8192;      // spread over many addresses: same-address atomics from every wave would themselves congest the memory system
+__device__ unsigned long long g_gemm_stamp[2][STAMP_SLOTS][8];      // [TA][slot][wait vmcnt | barrier | K-step body | prologue | epilogue | total | waves | K-steps]
+__device__ unsigned long long g_gemm_stamp2[STAMP_SLOTS][8];      // gemm_tn_split_kernel: [DMA issue | stage reads | split + writes (+ bits) | barrier B | fragment reads | MFMA issue | wait vmcnt | barrier A]
+#define SAHS_STAMP_NOW() __builtin_amdgcn_s_memtime()
+#endif
 template <bool TA, bool X3>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA && X3) ? 2 : 3, 3))) gemm_dma_kernel(int M, int N, int K, const float *__restrict__ A, long lda,
                                                        const float *__restrict__ B, long ldb, float *__restrict__ C, long ldc, int mode,
@@ -249,6 +266,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
     constexpr int DST = ring_depth<TA>();
     __shared__ __attribute__((aligned(16))) float smem[DST][2][DTILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c16 = lane & 15;
+#ifdef SAHS_GEMM_STAMP
+    const unsigned long long st_begin = SAHS_STAMP_NOW();
+    unsigned long long st_wait = 0, st_bar = 0, st_body = 0, st_loop0 = 0, st_loop1 = 0, st_steps = 0;
+    auto st_fin = [&]() {
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned long long e = SAHS_STAMP_NOW();
+            unsigned long long *g = g_gemm_stamp[TA ? 1 : 0][(blockIdx.x * 4u + (threadIdx.x >> 6)) % STAMP_SLOTS];
+            atomicAdd(g + 0, st_wait); atomicAdd(g + 1, st_bar); atomicAdd(g + 2, st_body); atomicAdd(g + 3, st_loop0 - st_begin);
+            atomicAdd(g + 4, e - st_loop1); atomicAdd(g + 5, e - st_begin); atomicAdd(g + 6, 1ull); atomicAdd(g + 7, st_steps);
+        }
+    };
+#endif
     const int wm = wave >> 1, wn = wave & 1;
     int bx = blockIdx.x, by = blockIdx.y;
     long bz = blockIdx.z;
@@ -313,7 +342,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float *g = (colok[u] && k0 + krow[u] < k_hi) ? src[u] + (long)t * step[u] : zero;
+#ifdef SAHS_GEMM_ABL_NODMA      // timing-only ablations (SAHS_GEMM_ABL_*): results wrong by construction
+            asm volatile("" :: "v"(g), "v"(dstb));
+#else
             __builtin_amdgcn_global_load_lds((gbl_void_t)g, (lds_void_t)(dstb + u * 256), 16, 0, 0);
+#endif
         }
     };
 
@@ -363,10 +396,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
     if (T > 0) issue(0);      // an empty K slab (k_lo >= K) issues nothing and falls through to a zero contribution
     if (T > 1) issue(1);
     if (DST > 3 && T > 2) issue(2);
+#ifdef SAHS_GEMM_STAMP
+    st_loop0 = SAHS_STAMP_NOW();
+#endif
     for (int t = 0; t < T; ++t) {
+#ifdef SAHS_GEMM_STAMP
+        const unsigned long long sa = SAHS_STAMP_NOW();
+        if (DST > 3 && t + 2 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long sb = SAHS_STAMP_NOW();
+        asm volatile("s_barrier" ::: "memory");
+        const unsigned long long sc = SAHS_STAMP_NOW();
+        st_wait += sb - sa; st_bar += sc - sb;
+#elif defined(SAHS_GEMM_ABL_NOBARRIER)
+        if (DST > 3 && t + 2 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         if (DST > 3 && t + 2 < T) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
         else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         if (t + DST - 1 < T) issue(t + DST - 1);          // into the buffer every wave finished reading before the barrier above
         const float *As = &smem[t % DST][0][0], *Bs = &smem[t % DST][1][0];
         if (TA && bits != nullptr && by == 0) {      // thread (kk, g): the 8 columns 8g .. 8g+7 of sample row kk of the X tile -> one byte
@@ -381,6 +432,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
                 bits[k * (N >> 3) + (n0 >> 3) + g] = (unsigned char)b8;
             }
         }
+#ifdef SAHS_GEMM_ABL_NOCOMPUTE
+        if constexpr (X3) { asm volatile("" :: "v"(As), "v"(Bs)); } else
+#endif
         if constexpr (X3) {
             u32x4_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -449,6 +503,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
             }
         }
     }
+#ifdef SAHS_GEMM_STAMP
+    st_loop1 = SAHS_STAMP_NOW();
+    st_body = st_loop1 - st_loop0 - st_wait - st_bar;
+    st_steps = (unsigned long long)(T > 0 ? T : 0);
+#endif
     // one accessor for both accumulator layouts: value of row `row` (0..63 of this wave's block, as enumerated below) x column
     // f32 form: tile (i, j) register r  -> row 16 i + 4 q + r,                       column 16 j + c16
     // X3 form : tile (i, j) register e  -> row 32 i + (e & 3) + 8 (e >> 2) + 4 h,    column 32 j + r32
@@ -459,53 +518,93 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
     if (!TA && mode != 2 && ((reinterpret_cast<uintptr_t>(C) | (mask ? reinterpret_cast<uintptr_t>(mask) : 0)) & 15) == 0 && ldc % 4 == 0 &&
         (mask == nullptr || ldm % 4 == 0)) {
         // Data-gradient epilogue through LDS: the accumulator layout gives 64-byte row segments per store instruction (64 mask loads
-        // + 64 stores per lane); staged, every thread moves whole float4s of 512-byte rows (8 mask loads + 8 stores per lane per half).
+        // + 64 stores per lane); staged, every thread moves whole float4s of 512-byte rows (8 stores per lane per half).
+        // Everything the stores need from memory -- the mask (as sign bits or as the fp32 activation) and, for mode 1, the old value -- is
+        // fetched by ONE batch of loads per half through clamped addresses (no per-lane branches), ahead of the staging barrier; the
+        // stores then follow each other with no wait between them.  (Round 3, from the cycle stamps of tools/stamp_gemm.py: with a load
+        // inside each store's guard the compiler put `s_waitcnt vmcnt(0)` -- which on gfx9 also waits for every earlier STORE -- in front of
+        // all 16 stores of a lane: a serial chain of 16 memory round trips, 60 % of this kernel's wave time.)
         constexpr int SLD = GT + 4;
         float *stage = &smem[0][0][0];                      // 64 x 132 floats = 33 KB of the 48 KB ring, free after the K loop
-        __syncthreads();
+        const bool by_bits = mask != nullptr && bits != nullptr, by_mask = mask != nullptr && bits == nullptr, whole4 = (N & 3) == 0;
+        const int erow = tid >> 5, en = n0 + 4 * (tid & 31);
+        unsigned nibs[2] = {0u, 0u};                        // this lane's 16 mask nibbles (row erow + 8 e, columns en .. en+3), 4 bits each
+        if (by_bits) {
+            unsigned char raw[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long m = m0 + erow + 8 * e;
+                raw[e] = bits[(m < M && en < N) ? m * (N >> 3) + (en >> 3) : 0];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) nibs[e >> 3] |= (((unsigned)raw[e] >> (en & 4)) & 15u) << (4 * (e & 7));
+        }
+        lds_barrier();
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            if (wm == half) {
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
+            for (int grp = 0; grp < 2; ++grp) {             // the rarer fp32-mask / accumulate forms fetch in two batches of four per half
+                f32x4 mk[4], od[4];
+                if (whole4 && by_mask) {
 #pragma unroll
-                    for (int j = 0; j < NI; ++j)
+                    for (int e = 0; e < 4; ++e) {
+                        const long m = m0 + 64 * half + erow + 8 * (4 * grp + e);
+                        mk[e] = *reinterpret_cast<const f32x4 *>(mask + ((m < M && en < N) ? m * ldm + en : 0));
+                    }
+                }
+                if (whole4 && mode == 1) {
 #pragma unroll
-                        for (int r = 0; r < NR; ++r) stage[row_of(i, r) * SLD + 64 * wn + col_of(j)] = val_of(i, j, r);
-            }
-            __syncthreads();
+                    for (int e = 0; e < 4; ++e) {
+                        const long m = m0 + 64 * half + erow + 8 * (4 * grp + e);
+                        od[e] = *reinterpret_cast<const f32x4 *>(C + ((m < M && en < N) ? m * ldc + en : 0));
+                    }
+                }
+                if (grp == 0) {
+                    if (wm == half) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int idx = tid + 256 * e, row = idx >> 5, c4 = idx & 31;
-                const long m = m0 + 64 * half + row;
-                const int n = n0 + 4 * c4;
-                if (m < M && n < N) {
-                    f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * SLD + 4 * c4);
-                    if (n + 3 < N) {
-                        if (mask != nullptr && bits != nullptr) {
-                            const unsigned nib = bits[m * (N >> 3) + (n >> 3)] >> (n & 4);
+                        for (int i = 0; i < NI; ++i)
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) v[k] *= ((nib >> k) & 1u) ? 1.0f : slope;
-                        } else if (mask != nullptr) {
-                            const f32x4 mk = *reinterpret_cast<const f32x4 *>(mask + m * ldm + n);
+                            for (int j = 0; j < NI; ++j)
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) v[k] *= (mk[k] > 0.0f) ? 1.0f : slope;
+                                for (int r = 0; r < NR; ++r) stage[row_of(i, r) * SLD + 64 * wn + col_of(j)] = val_of(i, j, r);
+                    }
+                    lds_barrier();
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = erow + 8 * (4 * grp + e);
+                    const long m = m0 + 64 * half + row;
+                    const unsigned nb = nibs[half] >> (4 * (4 * grp + e));
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(stage + row * SLD + 4 * (tid & 31));
+                    if (whole4) {
+                        if (by_bits) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] *= ((nb >> k) & 1u) ? 1.0f : slope;
+                        } else if (by_mask) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] *= (mk[e][k] > 0.0f) ? 1.0f : slope;
                         }
-                        f32x4 *dst = reinterpret_cast<f32x4 *>(C + m * ldc + n);
-                        if (mode == 1) { const f32x4 o = *dst; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
-                        *dst = v;
-                    } else {
-                        for (int k = 0; k < 4 && n + k < N; ++k) {
-                            float x = v[k];
-                            if (mask != nullptr) x *= (mask[m * ldm + n + k] > 0.0f) ? 1.0f : slope;
-                            float *dst = C + m * ldc + n + k;
-                            *dst = (mode == 1) ? *dst + x : x;
+                        if (mode == 1) { v[0] += od[e][0]; v[1] += od[e][1]; v[2] += od[e][2]; v[3] += od[e][3]; }
+                        if (m < M && en < N) *reinterpret_cast<f32x4 *>(C + m * ldc + en) = v;
+                    } else if (m < M && en < N) {            // ragged N (the encodings' gradients): element-wise, rare and small
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (en + k < N) {
+                                float x = v[k];
+                                if (by_bits) x *= ((nb >> k) & 1u) ? 1.0f : slope;
+                                else if (by_mask) x *= (mask[m * ldm + en + k] > 0.0f) ? 1.0f : slope;
+                                float *dst = C + m * ldc + en + k;
+                                *dst = (mode == 1) ? *dst + x : x;
+                            }
                         }
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
+#ifdef SAHS_GEMM_STAMP
+        st_fin();
+#endif
         return;
     }
     if (TA && mode == 2) {
@@ -535,6 +634,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
             __syncthreads();
         }
         if (do_sum && tid < GT && m0 + tid < M) atomicAdd(rowsum + m0 + tid, cs);
+#ifdef SAHS_GEMM_STAMP
+        st_fin();
+#endif
         return;
     }
 #pragma unroll
@@ -555,7 +657,249 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
                 }
             }
     if (do_sum && tid < GT && m0 + tid < M) atomicAdd(rowsum + m0 + tid, cs);
+#ifdef SAHS_GEMM_STAMP
+    st_fin();
+#endif
 }
+
+// ------------------------------------------------------------------------------------------------
+// The weight-gradient GEMM on the bf16 pipe, operands split ONCE per workgroup (round 3).  gemm_dma_kernel<true, true> splits every fp32
+// operand value on its way from LDS into the MFMA -- in each of the two waves that use it, behind eight scalar LDS reads per fragment --
+// and its K-step body (286 instructions per wave for 12 MFMAs) is what bounds it: s_memtime stamps (tools/stamp_gemm.py) put 2,250 of a
+// K-step's 2,530 cycles into the body, 120 into the wait for the LDS-DMA and 155 into the barrier.  Here a K-step is two phases:
+//   split   thread (operand = tid >> 7, column = tid & 127) reads its column's 16 samples of the fp32 stage (conflict-free: a wave reads 64
+//           consecutive columns of one sample row), splits them (48 VALU instructions) and writes the column's hi and lo bf16 fragments
+//           [column][16 k] with four ds_write_b128; the bias-gradient column sum rides on the same registers;
+//   MFMA    a wave fetches its 2 + 2 (hi, lo) fragment pairs with eight ds_read_b128 (lane (r32, h): 16 bytes at column * 32 + 16 h) and
+//           issues the 12 MFMAs.
+// Same tiles, LDS-DMA ring (depth 4), XCD-aware 1-D grid, sign-bit emission, staged atomic epilogue and arguments as the kernel it replaces
+// for X3; 64 KB ring + 16 KB fragments = 80 KB of LDS: two workgroups per CU.
+constexpr int TN_DST = 4, TN_THREADS = 512;
+constexpr int TN_RING_FLOATS = TN_DST * 2 * DTILE;
+constexpr int TN_FRAG_DWORDS = 2 * 2 * GT * 8;             // [operand][hi | lo][column][8 dwords = 16 bf16]
+constexpr int TN_LDS_BYTES = (TN_RING_FLOATS + TN_FRAG_DWORDS) * 4;
+static_assert(TN_LDS_BYTES == 81920, "two workgroups per CU: 2 x 80 KB = the 160 KB of a gfx950 CU");
+
+__global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) gemm_tn_split_kernel(int M, int N, int K, const float *__restrict__ A, long lda,
+                                                       const float *__restrict__ B, long ldb, float *__restrict__ C, long ldc, int kslab,
+                                                       float *__restrict__ rowsum, int nx, const float *__restrict__ zero,
+                                                       unsigned char *__restrict__ bits)
+{
+    extern __shared__ __attribute__((aligned(16))) float tn_lds[];
+    float *ring = tn_lds;                                                    // [TN_DST][2][DTILE]
+    uint32_t *frag = reinterpret_cast<uint32_t *>(tn_lds + TN_RING_FLOATS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3, h = lane >> 5, r32 = lane & 31, c32 = lane & 31;
+    // 1-D grid: the nx x ny output tiles of ONE sample slab read the same dY and X rows -- they run on the same XCD (workgroup ids congruent
+    // mod 8, consecutive slots), so that XCD's L2 fetches the slab from HBM once instead of once per tile
+    const int ny = (M + GT - 1) / GT, tiles = nx * ny;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, tile = slot % tiles;
+    const long bz = (long)(slot / tiles) * 8 + xcd;
+    const int bx = tile % nx, by = tile / nx;
+    if (bz * kslab >= K) return;
+    const long m0 = (long)by * GT;
+    const int n0 = bx * GT;
+    const long k_lo = bz * kslab;
+    const long k_hi = (k_lo + kslab < K) ? k_lo + kslab : K;
+    const int T = (int)((k_hi - k_lo + GK - 1) / GK);
+    const bool do_sum = rowsum != nullptr && bx == 0;
+#ifdef SAHS_GEMM_STAMP
+    const unsigned long long st_begin = SAHS_STAMP_NOW();
+    unsigned long long st_wait = 0, st_bar = 0, st_split = 0, st_bar2 = 0, st_issue = 0, st_rd = 0, st_frd = 0, st_mfma = 0;
+#endif
+
+    // this wave's two DMA instructions per K-step: waves 0..3 move the dY tile, waves 4..7 the X tile; K-major [16 k][128 cols], 32 chunks
+    // per row, two rows per instruction, XOR-swizzled by 16 floats on odd rows (kept from gemm_dma_kernel: the sign-bit pass relies on it)
+    const float *src[2]; long step[2]; int krow[2]; bool colok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int rp = (wave & 3) * 2 + u;
+        const float *base = (wave < 4) ? A : B;
+        const long ld = (wave < 4) ? lda : ldb;
+        const long c0 = (wave < 4) ? m0 : n0;
+        const int dim = (wave < 4) ? M : N;
+        const int row = 2 * rp + h;
+        const int j = c32 ^ ((row & 1) << 2);
+        src[u] = base + (k_lo + row) * ld + c0 + 4 * j;
+        step[u] = GK * ld;
+        krow[u] = row;
+        colok[u] = c0 + 4 * j < dim;
+    }
+    const int dst_off = ((wave < 4) ? 0 : DTILE) + (wave & 3) * 2 * 256;
+    auto issue = [&](int t) {
+        float *dstb = ring + (t % TN_DST) * 2 * DTILE + dst_off;
+        const long k0 = k_lo + (long)t * GK;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float *g = (colok[u] && k0 + krow[u] < k_hi) ? src[u] + (long)t * step[u] : zero;
+            __builtin_amdgcn_global_load_lds((gbl_void_t)g, (lds_void_t)(dstb + u * 256), 16, 0, 0);
+        }
+    };
+    // split phase: this thread's column of its operand tile, at its two swizzle positions (even / odd sample rows)
+    const int sop = tid >> 8, skh = (tid >> 7) & 1, scol = tid & 127;        // samples 8 skh .. 8 skh + 7 of the column
+    const int spos0 = scol, spos1 = (((scol >> 2) ^ 4) << 2) + (scol & 3);
+    uint32_t *fdst = frag + ((sop * 2) * GT + scol) * 8 + 4 * skh;           // hi row of this column; the lo row is GT * 8 dwords further
+    // MFMA phase: fragment rows of this wave's 2 + 2 column blocks
+    const uint32_t *fa[2], *fb;                                              // wave (wm, wn): rows 64 wm + 32 i, columns 32 wn
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i] = frag + ((0 * 2) * GT + 64 * wm + 32 * i + r32) * 8 + 4 * h;
+    fb = frag + ((1 * 2) * GT + 32 * wn + r32) * 8 + 4 * h;
+    f32x16_t acx[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acx[i][e] = 0.0f;
+    float cs = 0.0f;
+
+    // vmcnt accounting as in gemm_dma_kernel: the wave's only loads are its 2 LDS-DMA instructions per issue(), completing in issue order;
+    // the sign-bit store of the by == 0 workgroups can only make a counted wait stricter
+    if (T > 0) issue(0);
+    if (T > 1) issue(1);
+    if (T > 2) issue(2);
+#ifdef SAHS_GEMM_STAMP
+    const unsigned long long st_loop0 = SAHS_STAMP_NOW();
+#endif
+    for (int t = 0; t < T; ++t) {
+#ifdef SAHS_GEMM_STAMP
+        const unsigned long long sa = SAHS_STAMP_NOW();
+        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long sb = SAHS_STAMP_NOW();
+        asm volatile("s_barrier" ::: "memory");
+        const unsigned long long sc = SAHS_STAMP_NOW();
+        st_wait += sb - sa; st_bar += sc - sb;
+#else
+        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+        // (every wave has finished the MFMA phase of step t-1: the fragment buffer and ring stage (t-1) % 4 are free)
+        if (t + TN_DST - 1 < T) issue(t + TN_DST - 1);
+#ifdef SAHS_GEMM_STAMP
+        const unsigned long long si = SAHS_STAMP_NOW();
+        st_issue += si - sc;
+#endif
+        const float *stage = ring + (t % TN_DST) * 2 * DTILE;
+        {
+            const float *col = stage + sop * DTILE + 8 * skh * GT;
+            float x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = col[k * GT + ((k & 1) ? spos1 : spos0)];
+#ifdef SAHS_GEMM_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+            const unsigned long long sr = SAHS_STAMP_NOW();
+            st_rd += sr - si;
+#endif
+            u32x4_t hi, lo;
+            split8(x, hi, lo);
+            *reinterpret_cast<u32x4_t *>(fdst) = hi;
+            *reinterpret_cast<u32x4_t *>(fdst + GT * 8) = lo;
+            if (do_sum && sop == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cs += x[k];
+            }
+        }
+        if (bits != nullptr && by == 0 && tid < 256) {      // thread (kk, g): the 8 columns 8g .. 8g+7 of sample row kk of the X tile -> one byte
+            const int kk = tid >> 4, g = tid & 15;
+            const long k = k_lo + (long)t * GK + kk;
+            if (k < k_hi && n0 + 8 * g < N) {
+                const float *px = stage + DTILE + kk * GT + 4 * ((2 * g) ^ ((kk & 1) << 2));     // chunks 2g, 2g+1 stay adjacent under the swizzle
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(px), v1 = *reinterpret_cast<const f32x4 *>(px + 4);
+                unsigned b8 = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b8 |= (v0[i] > 0.0f ? 1u : 0u) << i | (v1[i] > 0.0f ? 1u : 0u) << (4 + i);
+                bits[k * (N >> 3) + (n0 >> 3) + g] = (unsigned char)b8;
+            }
+        }
+#ifdef SAHS_GEMM_STAMP
+        const unsigned long long sd = SAHS_STAMP_NOW();
+        lds_barrier();
+        const unsigned long long se = SAHS_STAMP_NOW();
+        st_split += sd - si; st_bar2 += se - sd;
+#else
+        lds_barrier();
+#endif
+        u32x4_t ah[2], al[2], bh, bl;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const u32x4_t *>(fa[i]);
+            al[i] = *reinterpret_cast<const u32x4_t *>(fa[i] + GT * 8);
+        }
+        bh = *reinterpret_cast<const u32x4_t *>(fb);
+        bl = *reinterpret_cast<const u32x4_t *>(fb + GT * 8);
+#ifdef SAHS_GEMM_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(ah[1]), "+v"(al[0]), "+v"(al[1]), "+v"(bh), "+v"(bl));
+        const unsigned long long sf = SAHS_STAMP_NOW();
+        st_frd += sf - se;
+#endif
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acx[i] = mfma3(ah[i], al[i], bh, bl, acx[i]);
+#ifdef SAHS_GEMM_STAMP
+        st_mfma += SAHS_STAMP_NOW() - sf;
+#endif
+    }
+#ifdef SAHS_GEMM_STAMP
+    const unsigned long long st_loop1 = SAHS_STAMP_NOW();
+#endif
+    // epilogue through LDS: one atomic instruction covers 256 contiguous bytes of a dW row.  Accumulator tile i register e is
+    // row 32 i + (e & 3) + 8 (e >> 2) + 4 h, column r32 of this wave's 64 x 32 block
+    constexpr int SLD = GT + 4;
+    float *out = ring;                                   // 64 x 132 floats = 33 KB of the ring, free after the K loop
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) out[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * SLD + 32 * wn + r32] = acx[i][e];
+        }
+        lds_barrier();
+#pragma unroll 4
+        for (int e = 0; e < 16; ++e) {
+            const int idx = tid + TN_THREADS * e, row = idx >> 7, col = idx & 127;
+            const long m = m0 + 64 * half + row;
+            const int n = n0 + col;
+            if (m < M && n < N && ldc > 0) atomicAdd(C + m * ldc + n, out[row * SLD + col]);
+        }
+        lds_barrier();
+    }
+    if (do_sum && sop == 0 && m0 + scol < M) atomicAdd(rowsum + m0 + scol, cs);      // (two partial sums per column: samples 0..7 and 8..15 of every step)
+#ifdef SAHS_GEMM_STAMP
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long e = SAHS_STAMP_NOW();
+        unsigned long long *g = g_gemm_stamp[1][(blockIdx.x * 8u + (threadIdx.x >> 6)) % STAMP_SLOTS];
+        atomicAdd(g + 0, st_wait); atomicAdd(g + 1, st_bar + st_bar2); atomicAdd(g + 2, st_loop1 - st_loop0 - st_wait - st_bar - st_bar2);
+        atomicAdd(g + 3, st_loop0 - st_begin); atomicAdd(g + 4, e - st_loop1); atomicAdd(g + 5, e - st_begin); atomicAdd(g + 6, 1ull);
+        atomicAdd(g + 7, (unsigned long long)T);
+        unsigned long long *g2 = g_gemm_stamp2[(blockIdx.x * 8u + (threadIdx.x >> 6)) % STAMP_SLOTS];
+        atomicAdd(g2 + 0, st_issue); atomicAdd(g2 + 1, st_rd); atomicAdd(g2 + 2, st_split - st_rd); atomicAdd(g2 + 3, st_bar2); atomicAdd(g2 + 4, st_frd);
+        atomicAdd(g2 + 5, st_mfma); atomicAdd(g2 + 6, st_wait); atomicAdd(g2 + 7, st_bar);
+    }
+#endif
+}
+
+#if defined(SAHS_GEMM_STAMP) && SAHS_MODEL == 0
+extern "C" int sahs_dbg_gemm_stamps(unsigned long long *out24, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    static unsigned long long host[3][STAMP_SLOTS][8];
+    if (out24) {
+        if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamp), 2 * sizeof host[0]) != hipSuccess) return 2;
+        if (hipMemcpyFromSymbol(host[2], HIP_SYMBOL(g_gemm_stamp2), sizeof host[0]) != hipSuccess) return 2;
+        for (int i = 0; i < 24; ++i) out24[i] = 0;
+        for (int ta = 0; ta < 3; ++ta)
+            for (int sl = 0; sl < STAMP_SLOTS; ++sl)
+                for (int i = 0; i < 8; ++i) out24[8 * ta + i] += host[ta][sl][i];
+    }
+    if (reset) {
+        void *d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_gemm_stamp)) != hipSuccess || hipMemset(d, 0, 2 * sizeof host[0]) != hipSuccess) return 3;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_gemm_stamp2)) != hipSuccess || hipMemset(d, 0, sizeof host[0]) != hipSuccess) return 3;
+    }
+    return 0;
+}
+#endif
 
 // dst[m*ldd + n] (op)= src[m*lds + n] for n < N   (mode 0 copy, 1 add)
 __global__ void copy2d_kernel(long M, int N, const float *__restrict__ src, long lds_, float *__restrict__ dst, long ldd, int mode)
@@ -949,7 +1293,8 @@ struct Bwd {
         const int tiles = ((N + GT - 1) / GT) * ((M + GT - 1) / GT);
         static const long wg_target = getenv("SAHS_BWD_TN_WGS") ? atol(getenv("SAHS_BWD_TN_WGS")) : 512;      // (tuning aid)
         long kslab = (P * tiles / wg_target + 15) / 16 * 16;
-        kslab = kslab < 512 ? 512 : (kslab > 8192 ? 8192 : kslab);
+        static const long min_slab = getenv("SAHS_BWD_TN_MINSLAB") ? atol(getenv("SAHS_BWD_TN_MINSLAB")) : 512;      // (tuning aid)
+        kslab = kslab < min_slab ? min_slab : (kslab > 8192 ? 8192 : kslab);
         dim3 g((N + GT - 1) / GT, (M + GT - 1) / GT, (unsigned)((P + kslab - 1) / kslab));
         if (al(dY, ldy) && al(X, ldx)) {
             const int nx = (N + GT - 1) / GT, slabs = (int)((P + kslab - 1) / kslab);
@@ -957,7 +1302,15 @@ struct Bwd {
             unsigned char *mb = (sign_bits != nullptr && N % 8 == 0 && N <= 256) ? sign_bits : nullptr;
             static const bool dbg_noatomic = getenv("SAHS_BWD_DBG_NOATOMIC") != nullptr;      // timing experiment: results wrong
             if (dbg_noatomic) ldw = 0;
-            if (x3()) gemm_dma_kernel<true, true><<<g1, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, -nx, zero, mb);
+            static const bool split_once = getenv("SAHS_BWD_TN_INLINE_SPLIT") == nullptr;      // (A/B aid: the per-wave split of gemm_dma_kernel<true, true>)
+            if (x3() && split_once) {
+                static sahs_once::Flags attr_set;       // the large-LDS attribute is per device
+                const hipError_t ae = sahs_once::per_device(attr_set, [&]() {
+                    return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+                });
+                if (ae != hipSuccess) { if (!err) err = (int)ae; return; }
+                gemm_tn_split_kernel<<<g1, TN_THREADS, TN_LDS_BYTES, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, (int)kslab, db, nx, zero, mb);
+            } else if (x3()) gemm_dma_kernel<true, true><<<g1, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, -nx, zero, mb);
             else gemm_dma_kernel<true, false><<<g1, 256, 0, st>>>(M, N, (int)P, dY, ldy, X, ldx, dW, ldw, 2, nullptr, 0, 0.0f, (int)kslab, db, -nx, zero, mb);
             bits_of = mb ? X : nullptr;
             bits_n = N;

@@ -103,3 +103,12 @@ def pytest_terminal_summary(terminalreporter):
         terminalreporter.write_line("float64 yardstick (max / rms error vs the reference model in float64; 'ref' = the reference's own fp32):")
         for what, e, r, er, rr, sc in YARDSTICK_LOG:
             terminalreporter.write_line("  %-44s max %.2e (ref %.2e)  rms %.2e (ref %.2e)  scale %.2e" % (what, e, r, er, rr, sc))
+
+
+def free_port():
+    """A TCP port that is free now (bind to 0, read it back): each multi-process test gets its own rendezvous port instead of a fixed one
+    that the previous test may have left in TIME_WAIT."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import REPO, pkg
+from conftest import REPO, free_port, pkg
 
 
 def _worker(rank, world, port, num_rays, path):
@@ -59,7 +59,7 @@ def test_two_rank_ray_sharding(tmp_path, flat_weights, num_rays):
     ref = D.pack_outputs(tuple(torch.from_numpy(o[k]) for k in ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_bg", "depth_f"]))
     assert ref.shape == (num_rays, D.OUT_COLUMNS)
     np.save(path.replace(".npz", "_ref.npy"), ref.numpy())
-    port = 29500 + (os.getpid() % 2000)
+    port = free_port()
     mp.start_processes(_worker, args=(2, port, num_rays, path), nprocs=2, join=True, start_method="spawn")
 
 
@@ -124,7 +124,7 @@ def _inplace_worker(rank, world, port, num_rays):
 def test_render_rows_sharded_in_place(num_rays, world):
     """The product's sharding function: even splits all-gather IN PLACE (send buffer = the rank's slice of the receive buffer), ragged
     ones through the padded gather; also a frame with fewer rays than ranks (an empty block)."""
-    port = 35500 + (os.getpid() % 2000)
+    port = free_port()
     mp.start_processes(_inplace_worker, args=(world, port, num_rays), nprocs=world, join=True, start_method="spawn")
 
 
@@ -155,5 +155,5 @@ def _grad_worker(rank, world, port):
 
 
 def test_two_rank_gradient_all_reduce():
-    port = 31500 + (os.getpid() % 2000)
+    port = free_port()
     mp.start_processes(_grad_worker, args=(2, port), nprocs=2, join=True, start_method="spawn")

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import REPO, VARIANT_KW
+from conftest import REPO, VARIANT_KW, free_port
 
 pytestmark = pytest.mark.gpu
 
@@ -60,7 +60,7 @@ def test_two_ranks_render_one_frame_together(tmp_path, size):
     ref = _render(sahs, sahs.weights, size, True)           # no process group: the single-process frame under the same keyed draws
     assert all(bool(torch.isfinite(r).all()) for r in ref) and not torch.equal(ref[0], ref[1])
     torch.save(ref, str(tmp_path / "ref.pt"))
-    port = 37500 + (os.getpid() % 2000)
+    port = free_port()
     mp.start_processes(_worker, args=(2, port, size, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
 
 
@@ -112,5 +112,5 @@ def _train_worker(rank, world, port, path):
 def test_two_ranks_train_data_parallel(tmp_path):
     """training.train_step on two ranks (HIP forward/backward on each rank's slice of the 256-ray batch, gradients and the sampling
     feedback all-reduced over gloo): after two steps the replicas hold bit-identical parameters, loss and sample_prob."""
-    port = 39500 + (os.getpid() % 2000)
+    port = free_port()
     mp.start_processes(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")

@@ -22,6 +22,9 @@ VARIANTS = {"base": [],  "nope": ["SAHS_ABLATE_NOPE"], "nobarrier": ["SAHS_ABLAT
             "wnopack": ["SAHS_ABLATE_NOPACK"], "wagpr": ["SAHS_NOTHING"], "wnodma": ["SAHS_ABLATE_NODMA"],
             "wfp32relu": ["SAHS_BF16W_FP32_RELU"], "wpkmul": ["SAHS_BF16W_PKMUL"], "wexact": ["SAHS_BF16W_EXACT_LEAKY"],
             "x3nodma": ["SAHS_X3_NODMA"], "x3nobar": ["SAHS_X3_NOBARRIER"], "x3noaread": ["SAHS_X3_NOAREAD"], "x3floor": ["SAHS_X3_NODMA", "SAHS_X3_NOBARRIER", "SAHS_X3_NOAREAD"],
+            # round 3: backward GEMM (gemm_dma_kernel<*, X3>) -- what the K loop waits for (tools/ab_bwd.sh runs them under rocprofv3)
+            "gnocompute": ["SAHS_GEMM_ABL_NOCOMPUTE"], "gnodma": ["SAHS_GEMM_ABL_NODMA"], "gnosplit": ["SAHS_GEMM_ABL_NOSPLIT"], "gnomfma": ["SAHS_GEMM_ABL_NOMFMA"],
+            "gnobarrier": ["SAHS_GEMM_ABL_NOBARRIER"], "gstamp": ["SAHS_GEMM_STAMP"], "gstamp_nocompute": ["SAHS_GEMM_STAMP", "SAHS_GEMM_ABL_NOCOMPUTE"], "gstamp_nodma": ["SAHS_GEMM_STAMP", "SAHS_GEMM_ABL_NODMA"], "gnodma_nobarrier": ["SAHS_GEMM_ABL_NODMA", "SAHS_GEMM_ABL_NOBARRIER"],
             "w4": ["SAHS_BF16_WAVES=4"], "w4apf6": ["SAHS_BF16_WAVES=4", "SAHS_BF16_APF=6"]}
 
 
