@@ -249,7 +249,7 @@ __device__ __forceinline__ f32x16_t mfma3(const u32x4_t &ah, const u32x4_t &al, 
 #ifdef SAHS_GEMM_STAMP      // diagnostic build (tools/stamp_gemm.py): where a wave's cycles go, summed over every wave of every launch
 constexpr int STAMP_SLOTS = 8192;      // spread over many addresses: same-address atomics from every wave would themselves congest the memory system
 __device__ unsigned long long g_gemm_stamp[2][STAMP_SLOTS][8];      // [TA][slot][wait vmcnt | barrier | K-step body | prologue | epilogue | total | waves | K-steps]
-__device__ unsigned long long g_gemm_stamp2[STAMP_SLOTS][8];      // gemm_tn_split_kernel: [DMA issue | stage reads | split + writes (+ bits) | barrier B | fragment reads | MFMA issue | wait vmcnt | barrier A]
+__device__ unsigned long long g_gemm_stamp2[STAMP_SLOTS][8], g_gemm_stamp3[STAMP_SLOTS][8];      // gemm_tn_split_kernel: [DMA issue | stage reads | split + writes (+ bits) | barrier B | fragment reads | MFMA issue | wait vmcnt | barrier A]
 #define SAHS_STAMP_NOW() __builtin_amdgcn_s_memtime()
 #endif
 template <bool TA, bool X3>
@@ -393,6 +393,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
     // issue(); they complete in issue order, so "vmcnt(4)" at step t means step t has landed while step t+1 may still be in flight --
     // and any further VMEM instruction the compiler might ever add there could only make that wait stricter, never weaker.
     // (depth DST: steps t+1 .. t+DST-2 may be in flight at step t's wait -- 4 DMA instructions each -- and step t+DST-1 is issued after it)
+    // data-gradient GEMM: this lane's 16 mask bytes of the epilogue (row (tid >> 5) + 8 e, columns n0 + 4 (tid & 31) ..) are requested
+    // here, ahead of the K loop -- they are older than every LDS-DMA, so the counted waits below stay correct (stricter) -- and have long
+    // landed when the epilogue packs them; fetched after the loop they cost every workgroup an exposed memory round trip
+    unsigned char pre_raw[16];
+    const bool pre_bits = !TA && mode != 2 && mask != nullptr && bits != nullptr;
+    if constexpr (!TA) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const long m = m0 + (tid >> 5) + 8 * e;
+            const int en = n0 + 4 * (tid & 31);
+            pre_raw[e] = pre_bits ? bits[(m < M && en < N) ? m * (N >> 3) + (en >> 3) : 0] : (unsigned char)0;
+        }
+    }
     if (T > 0) issue(0);      // an empty K slab (k_lo >= K) issues nothing and falls through to a zero contribution
     if (T > 1) issue(1);
     if (DST > 3 && T > 2) issue(2);
@@ -530,16 +543,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
         const int erow = tid >> 5, en = n0 + 4 * (tid & 31);
         unsigned nibs[2] = {0u, 0u};                        // this lane's 16 mask nibbles (row erow + 8 e, columns en .. en+3), 4 bits each
         if (by_bits) {
-            unsigned char raw[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const long m = m0 + erow + 8 * e;
-                raw[e] = bits[(m < M && en < N) ? m * (N >> 3) + (en >> 3) : 0];
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) nibs[e >> 3] |= (((unsigned)raw[e] >> (en & 4)) & 15u) << (4 * (e & 7));
+            for (int e = 0; e < 16; ++e) nibs[e >> 3] |= (((unsigned)pre_raw[e] >> (en & 4)) & 15u) << (4 * (e & 7));
         }
         lds_barrier();
+#ifdef SAHS_GEMM_STAMP
+        unsigned long long ep[6]; int epn = 0;
+        ep[epn++] = SAHS_STAMP_NOW();
+#endif
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -569,6 +580,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
                                 for (int r = 0; r < NR; ++r) stage[row_of(i, r) * SLD + 64 * wn + col_of(j)] = val_of(i, j, r);
                     }
                     lds_barrier();
+#ifdef SAHS_GEMM_STAMP
+                    ep[epn++] = SAHS_STAMP_NOW();
+#endif
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -600,9 +614,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
                     }
                 }
             }
+#ifdef SAHS_GEMM_STAMP
+            ep[epn++] = SAHS_STAMP_NOW();
+#endif
             lds_barrier();
         }
 #ifdef SAHS_GEMM_STAMP
+        if ((threadIdx.x & 63) == 0) {      // [first barrier | stage 0 + barrier | stores 0 | barrier + stage 1 + barrier | stores 1 | last barrier]
+            unsigned long long *g3 = g_gemm_stamp2[(blockIdx.x * 4u + (threadIdx.x >> 6)) % STAMP_SLOTS];
+            const unsigned long long ee = SAHS_STAMP_NOW();
+            atomicAdd(g3 + 0, ep[0] - st_loop1); atomicAdd(g3 + 1, ep[1] - ep[0]); atomicAdd(g3 + 2, ep[2] - ep[1]); atomicAdd(g3 + 3, ep[3] - ep[2]);
+            atomicAdd(g3 + 4, ep[4] - ep[3]); atomicAdd(g3 + 5, ee - ep[4]); atomicAdd(g3 + 6, 1ull);
+        }
         st_fin();
 #endif
         return;
@@ -872,7 +895,7 @@ __global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu
         atomicAdd(g + 0, st_wait); atomicAdd(g + 1, st_bar + st_bar2); atomicAdd(g + 2, st_loop1 - st_loop0 - st_wait - st_bar - st_bar2);
         atomicAdd(g + 3, st_loop0 - st_begin); atomicAdd(g + 4, e - st_loop1); atomicAdd(g + 5, e - st_begin); atomicAdd(g + 6, 1ull);
         atomicAdd(g + 7, (unsigned long long)T);
-        unsigned long long *g2 = g_gemm_stamp2[(blockIdx.x * 8u + (threadIdx.x >> 6)) % STAMP_SLOTS];
+        unsigned long long *g2 = g_gemm_stamp3[(blockIdx.x * 8u + (threadIdx.x >> 6)) % STAMP_SLOTS];
         atomicAdd(g2 + 0, st_issue); atomicAdd(g2 + 1, st_rd); atomicAdd(g2 + 2, st_split - st_rd); atomicAdd(g2 + 3, st_bar2); atomicAdd(g2 + 4, st_frd);
         atomicAdd(g2 + 5, st_mfma); atomicAdd(g2 + 6, st_wait); atomicAdd(g2 + 7, st_bar);
     }
@@ -883,12 +906,13 @@ __global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu
 extern "C" int sahs_dbg_gemm_stamps(unsigned long long *out24, int reset)
 {
     if (hipDeviceSynchronize() != hipSuccess) return 1;
-    static unsigned long long host[3][STAMP_SLOTS][8];
-    if (out24) {
+    static unsigned long long host[4][STAMP_SLOTS][8];
+    if (out24) {      // 32 values: [data-gradient | weight-gradient | weight-gradient K-step detail | data-gradient epilogue detail]
         if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamp), 2 * sizeof host[0]) != hipSuccess) return 2;
-        if (hipMemcpyFromSymbol(host[2], HIP_SYMBOL(g_gemm_stamp2), sizeof host[0]) != hipSuccess) return 2;
-        for (int i = 0; i < 24; ++i) out24[i] = 0;
-        for (int ta = 0; ta < 3; ++ta)
+        if (hipMemcpyFromSymbol(host[2], HIP_SYMBOL(g_gemm_stamp3), sizeof host[0]) != hipSuccess) return 2;
+        if (hipMemcpyFromSymbol(host[3], HIP_SYMBOL(g_gemm_stamp2), sizeof host[0]) != hipSuccess) return 2;
+        for (int i = 0; i < 32; ++i) out24[i] = 0;
+        for (int ta = 0; ta < 4; ++ta)
             for (int sl = 0; sl < STAMP_SLOTS; ++sl)
                 for (int i = 0; i < 8; ++i) out24[8 * ta + i] += host[ta][sl][i];
     }
@@ -896,6 +920,7 @@ extern "C" int sahs_dbg_gemm_stamps(unsigned long long *out24, int reset)
         void *d = nullptr;
         if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_gemm_stamp)) != hipSuccess || hipMemset(d, 0, 2 * sizeof host[0]) != hipSuccess) return 3;
         if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_gemm_stamp2)) != hipSuccess || hipMemset(d, 0, sizeof host[0]) != hipSuccess) return 3;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_gemm_stamp3)) != hipSuccess || hipMemset(d, 0, sizeof host[0]) != hipSuccess) return 3;
     }
     return 0;
 }

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(REPO, "tools"))
 import train_bench   # noqa: E402
 
 L = ctypes.CDLL(os.environ["SAHS_NERF_LIB"])
-buf = (ctypes.c_ulonglong * 24)()
+buf = (ctypes.c_ulonglong * 32)()
 orig = train_bench.time.perf_counter
 state = {"n": 0}
 
@@ -37,3 +37,6 @@ steps = buf[8 + 7]
 if buf[16 + 5]:
     names = ["DMA issue", "stage reads landed", "split + fragment writes (+ sign bits)", "barrier B", "fragment reads landed", "MFMA issue", "wait vmcnt", "barrier A"]
     print("weight-gradient K-step, cycles: " + ", ".join("%s %.0f" % (n, buf[16 + i] / steps) for i, n in enumerate(names)))
+if buf[24 + 6]:
+    names = ["first barrier", "stage half 0 + barrier", "stores half 0", "barrier + stage half 1 + barrier", "stores half 1", "last barrier"]
+    print("data-gradient epilogue, cycles per wave: " + ", ".join("%s %.0f" % (n, buf[24 + i] / buf[24 + 6]) for i, n in enumerate(names)))
