@@ -114,3 +114,42 @@ def test_two_ranks_train_data_parallel(tmp_path):
     feedback all-reduced over gloo): after two steps the replicas hold bit-identical parameters, loss and sample_prob."""
     port = free_port()
     mp.start_processes(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+
+
+def _rccl_worker(rank, world, port):
+    """ONE rank over the real collective backend ("nccl" = RCCL): every collective CALL the product and bench.py make, in the form they make
+    it -- the in-place all-gather whose send buffer is a row slice of its receive buffer, the flat gradient all-reduce, the MAX-reduce of
+    the step time, the barrier with device ids -- so that an argument the library rejects (aliasing, views, device ids) shows up on the
+    one-GPU box and not first in the driver's 8-GPU run.  (With one rank the data movement itself is trivial; two RCCL ranks cannot share
+    a device.)"""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import importlib
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        R, C = 4096, 36
+        want = torch.arange(R * C, dtype=torch.float32, device=dev).reshape(R, C)
+        full = want.clone()
+        dist.all_gather_into_tensor(full, full[0:R])                  # distributed.all_gather_rows_inplace: send = the rank's own rows of `full`
+        pad = torch.empty(R, C, device=dev)
+        dist.all_gather_into_tensor(pad, want.contiguous())           # distributed.all_gather_rows (the ragged / out-of-place form)
+        flat = torch.ones(2775633, device=dev)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)                   # distributed.all_reduce_gradients: one 11.1 MB bucket
+        t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                      # bench.py: MAX over ranks of the timed region
+        dist.barrier(device_ids=[0])
+        torch.cuda.synchronize()
+        assert torch.equal(full, want) and torch.equal(pad, want) and float(flat.sum()) == 2775633.0 and float(t) == 1.25
+        # and the product's own function inside an initialised RCCL group (one rank: one block, the buffer comes back complete)
+        D = importlib.import_module("sahs-deformable-nerf_amd.distributed")
+        got = D.render_rows_sharded(lambda lo, hi, rows: rows.copy_(want[lo:hi]), R, dev)
+        assert torch.equal(got, want)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_accepts_the_products_collective_calls():
+    mp.start_processes(_rccl_worker, args=(1, free_port()), nprocs=1, join=True, start_method="spawn")
