@@ -251,7 +251,7 @@ def measure(pkg, dev, size, precision, steps, warmup, arch="audio", num_fine=Non
             return r.roofline(dt, recs[-steps * per_step:])          # the timed region's launches only
 
         rec, out = run_headline(r, world, steps, warmup, dist, torch.cuda.synchronize,
-                                {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3 (hi + lo operands, f32 accumulate; deformation nets f32)"}[precision],
+                                {"fp32": "f32", "bf16": "bf16", "bf16x3": "bf16x3 (hi + lo bf16 operands, three MFMAs per product, f32 accumulate; all nets)"}[precision],
                                 config, roofline, device=dev, backend="nccl (RCCL)" if world > 1 else None)
     return rec, out, r
 

@@ -28,7 +28,8 @@ extern "C" {
 #define SAHS_F32 0
 #define SAHS_BF16 1
 #define SAHS_BF16X3 3    /* near-fp32 on the bf16 pipe (AudioFaceModel, split chain only): operands split into bf16 hi + lo, three MFMAs per product,
-                          * fp32 accumulate, for the RADIANCE nets; the deformation nets run on the fp32 kernel (mixed, like SAHS_MODEL_NERFACE + SAHS_BF16) */
+                          * fp32 accumulate, in the radiance AND (since round 3) the deformation launches; x' = x + tanh(.) and the encodings stay fp32 arithmetic.
+                          * SAHS_X3_DEFORM=f32 in the environment keeps the deformation launches on the fp32 kernel (the round-2 form) */
 /* precision values 2 and 4 are reserved (A/B kernels of development builds, csrc/sahs_common.hpp; not in the shipped library) */
 
 int sahs_abi_version(void);

@@ -27,12 +27,13 @@ FIELD_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
 # kernel (audio model, no activation saving) is held to zero scratch as a performance guard (a reload's wait also drains its in-flight
 # weight prefetch); its activation-saving and NeRFace builds do spill a little (build/<library>.resource_usage.txt).
 NO_SCRATCH = {"gemm_dma_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb0E": 0, "field_forward_bf16w_kernel": 0,
-              "field_radiance_bf16x3_kernel": 0}
+              "field_radiance_bf16x3_kernel": 0, "field_deform_bf16x3_kernel": 0, "gemm_tn_split_kernel": 0}
 # Kernels with hand-issued `asm volatile ds_read_b128` + counted waits (csrc/bf16_pipe.hpp): (source, SAHS_MODEL, kernel name pattern).
 # Every build compiles these to ISA as well and runs tools/check_lds_inflight.py on it: an object in which anything touches a read's
 # destination before the wait that retires it is never linked.
 HAND_SCHEDULED = [("field_bf16w.hip", 0, "field_forward_bf16w_kernel"), ("field_bf16w.hip", 1, "field_forward_bf16w_kernel"),
-                  ("field_bf16w.hip", 2, "field_forward_bf16w_kernel"), ("field_bf16x3.hip", 0, "field_radiance_bf16x3_kernel")]
+                  ("field_bf16w.hip", 2, "field_forward_bf16w_kernel"), ("field_bf16x3.hip", 0, "field_radiance_bf16x3_kernel"),
+                  ("field_bf16x3.hip", 0, "field_deform_bf16x3_kernel")]
 # field_bf16w.hip (one wave per SIMD, 512 registers): MFMA accumulators must live in ARCH VGPRs.  Left to its heuristics the compiler
 # puts them in AGPRs, and every accumulator value the activation code touches then costs a v_accvgpr_read -- which, unlike plain VALU
 # work, does NOT hide under the wave's own MFMAs (tools/micro/mfma_valu_overlap.hip: 2 reads per MFMA = 55 cycles per MFMA instead of 36).

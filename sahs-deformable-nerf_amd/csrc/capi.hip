@@ -92,9 +92,11 @@ int sahs_field_forward_bf16q_split_launch(const float *packed, const float *fram
                                           int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
                                           int num_cu, hipStream_t stream);
 #endif
-// AudioFaceModel, SAHS_BF16X3: the radiance nets with operands split into bf16 hi + lo (field_bf16x3.hip); deformation nets fp32
+// AudioFaceModel, SAHS_BF16X3: operands split into bf16 hi + lo (field_bf16x3.hip): radiance launch and, since round 3, deformation launch
 long sahs_layout_packed_words_bf16x3(void);
 int sahs_pack_weights_bf16x3_launch(const float *flat, float *packed, hipStream_t stream);
+int sahs_field_deform_bf16x3_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
+                                    const float *zvals, float *xw, int xw_row, int xw_col0, int num_cu, hipStream_t stream);
 int sahs_field_radiance_bf16x3_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                       float *raw, const float *xw, int xw_row, const int *src, int num_cu, hipStream_t stream);
 // NeRFaceModel without deformation nets (person_1.yml): the whole network in bf16
@@ -625,7 +627,14 @@ int sahs_model_field_forward_split(int model, const void *packed, const float *f
         const float *pk16 = (const float *)packed, *pk32 = pk16 + (x3 ? sahs_layout_packed_words_bf16x3() : sahs_layout_packed_words_bf16_nf());
         REQUIRE(mode != 0 || xw_col0 == 0, "sahs_model_field_forward_split(mixed precision, mode 0: xw_col0 must be 0)");
         int e = 0;
-        if (mode != 2)
+        // SAHS_BF16X3: the deformation nets run on the split-operand pipe as well (round 3; SAHS_X3_DEFORM=f32 in the environment keeps
+        // them on the fp32 kernel, the A/B reference and the form rounds 2 shipped)
+        static const bool x3_deform_f32 = getenv("SAHS_X3_DEFORM") != nullptr && strcmp(getenv("SAHS_X3_DEFORM"), "f32") == 0;
+        if (mode != 2 && x3 && !x3_deform_f32)
+            e = probed(probe_kind(model, precision, level, 1), N * S, st, [&] {
+                return sahs_field_deform_bf16x3_launch(pk16, frame, level, N * S, S, rays, ray_stride, z, xw, xw_row, xw_col0, num_cus(), st);
+            });
+        else if (mode != 2)
             e = probed(probe_kind(model, SAHS_F32, level, 1), N * S, st, [&] {
                 return x3 ? sahs_field_forward_f32_split_launch(pk32, frame, level, 1, N * S, S, rays, ray_stride, z, nullptr, xw, xw_row, xw_col0, nullptr,
                                                                 nullptr, num_cus(), st)

@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import SAHS_F32, SAHS_BF16, SAHS_BF16_2W, SAHS_BF16X3, SAHS_BF16_Q, check
 
 PRECISIONS = {"fp32": SAHS_F32, "f32": SAHS_F32, "bf16": SAHS_BF16,
-              "bf16x3": SAHS_BF16X3}    # near-fp32 on the bf16 pipe: radiance nets with hi + lo bf16 operands (3 MFMAs per product), deformation nets fp32
+              "bf16x3": SAHS_BF16X3}    # near-fp32 on the bf16 pipe: every net with hi + lo bf16 operands (3 MFMAs per product); SAHS_X3_DEFORM=f32 keeps the deformation nets on the fp32 kernel
 AB_PRECISIONS = {"bf16_2w": SAHS_BF16_2W, "bf16q": SAHS_BF16_Q}    # development A/B builds only (tools/cmp_*.py); the shipped library rejects them
 
 

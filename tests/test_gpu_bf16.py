@@ -108,12 +108,12 @@ def test_bf16_full_frame_psnr(weights_mod):
     assert res["psnr_bf16_vs_fp32"] > 35.0, res
 
 
-# ---- SAHS_BF16X3: near-fp32 on the bf16 matrix pipe (radiance nets with bf16 hi + lo operands, three MFMAs per product; the
-# deformation nets on the fp32 kernel) -------------------------------------------------------------------------------------------
+# ---- SAHS_BF16X3: near-fp32 on the bf16 matrix pipe (every net with bf16 hi + lo operands, three MFMAs per product; round 2 kept the
+# deformation nets on the fp32 kernel, SAHS_X3_DEFORM=f32 still does) ---------------------------------------------------------------
 @pytest.mark.parametrize("variant", ["boosted", "hdr"])
 def test_bf16x3_field_vs_oracle(flat_weights, variant):
-    """Field seam against the CPU oracle: (x', w) are the fp32 kernel's own (same bounds as the fp32 path); the radiance nets' raw
-    output carries 16-17 significant bits per operand: bounds ~4x the observed error, 500-1000x below plain bf16's."""
+    """Field seam against the CPU oracle: (x', w) from the split-operand deformation launch, the radiance nets' raw output on top of them;
+    every operand carries 16-17 significant bits: bounds ~4x the observed error, 300-500x below plain bf16's."""
     from conftest import VARIANT_KW
     ops, lib = pkg("ops"), pkg("_lib")
     g = load_golden("cond")
@@ -145,9 +145,11 @@ def test_bf16x3_field_vs_oracle(flat_weights, variant):
     print(variant, json.dumps(stats))
     for level in (0, 1):
         st = stats[level]
-        assert st["xprime_max"] < 2e-6 and st["w_max"] < 2e-6, st                    # fp32 deformation nets
-        assert st["col_rms"] < 6e-5 * max(1.0, st["col_scale"]) and st["sig_rms"] < 6e-5 * max(1.0, st["sig_scale"]), st
-        assert st["col_max"] < 6e-4 * max(1.0, st["col_scale"]) and st["sig_max"] < 6e-4 * max(1.0, st["sig_scale"]), st
+        # deformation nets on the split-operand pipe as well (round 3): x' = x + tanh(.) adds a small correction to an exact x (observed
+        # 6.1e-7; the fp32 kernel: 1e-7), w is a raw network output (observed 9.8e-6 on a scale of ~1); bounds = 4x observed
+        assert st["xprime_max"] < 2.5e-6 and st["w_max"] < 4e-5, st
+        assert st["col_rms"] < 6e-5 * max(1.0, st["col_scale"]) and st["sig_rms"] < 1.2e-4 * max(1.0, st["sig_scale"]), st
+        assert st["col_max"] < 6e-4 * max(1.0, st["col_scale"]) and st["sig_max"] < 1.2e-3 * max(1.0, st["sig_scale"]), st
 
 
 def test_bf16x3_frame_vs_fp32_within_4x_of_its_tolerance(weights_mod):
