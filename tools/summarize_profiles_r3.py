@@ -45,6 +45,8 @@ def kind(kn, leg):
     nf = "sahs_nf" in kn
     if "field_radiance_bf16x3_kernel" in kn:
         return "bf16x3_radiance"
+    if "field_deform_bf16x3_kernel" in kn:
+        return "bf16x3_deform"
     if "field_forward_bf16w" in kn:
         m = mode_of(kn, "kernel<")
         return None if m is None else ("nf_bf16_" if nf else "bf16_") + {"0": "all", "1": "deform", "2": "radiance"}[m]
@@ -61,7 +63,7 @@ stats = {}
 for leg, args, steps, what in (("f32", "--precision fp32", 2, "fp32 W512 headline; per 131,072-ray chunk: field<false,0> = coarse launch (8.39 M samples, whole network), "
                                 "<false,1> = deformation nets on the 8.39 M new depths, <false,2> = radiance nets on the 16.78 M fine samples"),
                                ("bf16", "--precision bf16", 4, "bf16 W512: field_forward_bf16w_kernel<0|1|2>, same three launches per chunk"),
-                               ("bf16x3", "--precision bf16x3", 2, "bf16x3 W512: fp32 deformation launches (field_forward_f32_kernel<false,1>, coarse and new depths) + "
+                               ("bf16x3", "--precision bf16x3", 2, "bf16x3 W512: field_deform_bf16x3_kernel (deformation nets, coarse and new depths: 8.39 M samples each) + "
                                 "field_radiance_bf16x3_kernel on the 8.39 M coarse and the 16.78 M fine samples of a chunk"),
                                ("nfmixed", "--arch nerface --precision bf16", 3, "NeRFaceModel (config/expression/person_2.yml) in mixed precision: fp32 deformation "
                                 "launches (sahs_nf::field_forward_f32_kernel<false,1>) + sahs_nf::field_forward_bf16w_kernel<2> radiance launches")):
@@ -70,7 +72,7 @@ for leg, args, steps, what in (("f32", "--precision fp32", 2, "fp32 W512 headlin
     shutil.copy(os.path.join(base, "bench_trace_%s.json" % leg), os.path.join(out, "%s_%s_bench_under_rocprof.json" % (tag, {"f32": "fp32"}.get(leg, leg))))
 stats["train"] = kernel_stats("trace_train", tag + "_train_T2048_kernel_stats.csv",
                               "rocprofv3 --kernel-trace --stats -- python3 tools/train_bench.py --steps 5 --warmup 2   (T2048: 2048-ray forward + backward; "
-                              "gemm_dma_kernel<true|false, true> = weight- / data-gradient GEMMs on the bf16 pipe with split operands)")
+                              "gemm_tn_split_kernel / gemm_dma_kernel<false, true> = weight- / data-gradient GEMMs on the bf16 pipe with split operands)")
 shutil.copy(os.path.join(base, "bench_trace_train.json"), os.path.join(out, tag + "_train_T2048_bench_under_rocprof.json"))
 
 agg = collections.OrderedDict()
@@ -103,6 +105,7 @@ for k, label, pick, samples, alg_bytes in (
         ("bf16_deform", "bf16 deformation-net launch (8.39 M new depths)", 0, P_FINE // 2, (P_FINE // 2) * (4 + 32)),
         ("bf16x3_radiance", "bf16x3 radiance-net launch over the 16.78 M fine samples (second dispatch of a chunk; the first is the coarse pass's 8.39 M)",
          1, P_FINE, P_FINE * (64 + 32 + 4)),
+        ("bf16x3_deform", "bf16x3 deformation-net launch (8.39 M depths)", 0, P_FINE // 2, (P_FINE // 2) * (4 + 32)),
         ("nf_bf16_radiance", "NeRFaceModel bf16 radiance-net launch over the 16.78 M fine samples (second dispatch of a chunk)", 1, P_FINE, P_FINE * (64 + 32 + 4))):
     if (k, "GRBM_GUI_ACTIVE") not in agg or len(agg[(k, "GRBM_GUI_ACTIVE")]) <= pick:
         continue
@@ -143,7 +146,7 @@ try:
     tr = collections.OrderedDict()
     for a, b in zip(fs, ws):
         n = a["Kernel_Name"]
-        nm = ("weight-gradient GEMM gemm_dma_kernel<true,true>" if "gemm_dma_kernel<true" in n else "data-gradient GEMM gemm_dma_kernel<false,true>" if "gemm_dma_kernel<false" in n
+        nm = ("weight-gradient GEMM gemm_tn_split_kernel" if "gemm_tn_split_kernel" in n else "weight-gradient GEMM gemm_dma_kernel<true,*>" if "gemm_dma_kernel<true" in n else "data-gradient GEMM gemm_dma_kernel<false,true>" if "gemm_dma_kernel<false" in n
               else "field_forward_f32_kernel<true,*> (activation-saving forward)" if "field_forward" in n else "gemm_f32_kernel" if "gemm_f32" in n else "other")
         d = tr.setdefault(nm, [0, 0.0, 0.0, 0.0])
         d[0] += 1
