@@ -22,7 +22,7 @@ def short(name):
 
 
 def kernel_stats(sub, dst, header):
-    ks = glob.glob(os.path.join(base, sub, "*", "*_kernel_stats.csv"))[0]
+    ks = newest(os.path.join(base, sub, "*", "*_kernel_stats.csv"))
     rows = list(csv.DictReader(open(ks)))
     with open(os.path.join(out, dst), "w") as f:
         f.write("# " + header + "\n")
@@ -31,6 +31,11 @@ def kernel_stats(sub, dst, header):
         for r in rows:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
     return rows
+
+
+def newest(pattern):
+    """gpurun MERGES a call's files into gpurun_out/: an earlier call's run directory (another pid) may still sit beside the new one."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
 
 
 def mode_of(kn, lead):
@@ -77,7 +82,7 @@ shutil.copy(os.path.join(base, "bench_trace_train.json"), os.path.join(out, tag 
 
 agg = collections.OrderedDict()
 for leg in ("f32", "bf16", "bf16x3", "nfmixed"):
-    for f in sorted(glob.glob(os.path.join(base, "pmc_%s_*" % leg, "*", "*counter_collection.csv"))):
+    for f in sorted(newest(os.path.join(d, "*", "*counter_collection.csv")) for d in glob.glob(os.path.join(base, "pmc_%s_*" % leg))):
         for r in csv.DictReader(open(f)):
             k = kind(r["Kernel_Name"], leg)
             if k:
@@ -141,8 +146,8 @@ def last_step(rows):
 
 
 try:
-    fs = last_step(list(csv.DictReader(open(glob.glob(os.path.join(base, "pmc_train_FETCH_SIZE", "*", "*counter_collection.csv"))[0]))))
-    ws = last_step(list(csv.DictReader(open(glob.glob(os.path.join(base, "pmc_train_WRITE_SIZE", "*", "*counter_collection.csv"))[0]))))
+    fs = last_step(list(csv.DictReader(open(newest(os.path.join(base, "pmc_train_FETCH_SIZE", "*", "*counter_collection.csv"))))))
+    ws = last_step(list(csv.DictReader(open(newest(os.path.join(base, "pmc_train_WRITE_SIZE", "*", "*counter_collection.csv"))))))
     tr = collections.OrderedDict()
     for a, b in zip(fs, ws):
         n = a["Kernel_Name"]
