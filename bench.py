@@ -307,7 +307,7 @@ def add_secondary_legs(result, pkg, dev, args):
                                     "psnr_mixed_vs_fp32_db": psnr(rgb_fine(outm), rgb_fine(f32n)), "psnr_mixed_vs_target_db": p_b,
                                     "psnr_fp32_vs_target_db": p_f, "delta_psnr_db": abs(p_b - p_f), "w_bg_mean": float(f32n[6].mean())}
     del rm, rn, outm, f32n, tgtn
-    # near-fp32 on the bf16 pipe: fp32 deformation nets + radiance nets with bf16 hi/lo operands (3 MFMAs per product)
+    # near-fp32 on the bf16 pipe (round 3: the deformation nets too): every net with bf16 hi/lo operands (3 MFMAs per product)
     progress("bf16x3 leg")
     recx, outx, rx = measure(pkg, dev, size, "bf16x3", min(args.steps, 5), 1)
     f32a = rows_of(ProductRenderer(pkg, dev, size, "fp32").frame())
@@ -315,7 +315,7 @@ def add_secondary_legs(result, pkg, dev, args):
     dx = (rowx - f32a).abs()
     coarse_cols = list(range(0, 17))
     result["bf16x3"] = {"value": recx["value"], "unit": "rays/s", "ms_per_step": recx["ms_per_step"],
-                        "dtype": "f32 deformation nets + bf16 hi/lo radiance nets (3 MFMAs per product, f32 accumulate)",
+                        "dtype": "bf16 hi/lo operands in every net (3 MFMAs per product, f32 accumulate)",
                         "speedup_vs_fp32": recx["value"] / result["value"], "roofline": recx["roofline"],
                         "psnr_vs_fp32_db": psnr(rgb_fine(outx), f32a[:, 17:20]), "max_abs_diff_coarse_outputs": float(dx[:, coarse_cols].max()),
                         "rays_within_4x_fp32_tolerance": float(((dx <= 4e-5 + 4e-4 * f32a.abs()).all(dim=1)).float().mean())}
