@@ -158,7 +158,7 @@ class ProductRenderer:
         self.prec = self.model.precision
         self.flop_per_sample = FLOP_PER_SAMPLE[arch]
         self.split = arch != "nerface_static" and self.nf > 0      # the driver evaluates the deformation nets once per depth
-        self.mixed = self.ops.is_mixed(arch, self.prec)            # fp32 deformation launches + low-precision radiance launches
+        self.mixed = self.ops.is_mixed(arch, self.prec)            # split-chain-only precisions (split-operand deformation + low-precision radiance launches)
         ex = lambda part: 2 * self.ops.executed_macs_per_sample(arch, self.prec, part)
         self.exec_flop_per_sample = ex(0)
         # executed FLOPs per RAY: coarse = nc whole-network evaluations; fine = nf deformation + (nc + nf) radiance evaluations when split
@@ -196,10 +196,10 @@ class ProductRenderer:
                  "frac_executed": rays_done * self.exec_flop_per_ray / (field_ms * 1e-3) / 1e12 / peak,
                  "launches": len(recs), "field_ms_per_step": field_ms / max(1, self.steps_timed), "field_time_share": field_ms * 1e-3 / dt,
                  "flop_per_sample": self.flop_per_sample, "flop_per_sample_executed": self.exec_flop_per_sample, "shared_deformation": self.split}
-        if self.mixed:
-            chain["frac_executed"] = None       # two pipes at two rates: no single peak to price the executed work against
-            chain["mixed_precision"] = ("fp32 deformation launches + low-precision radiance launches: the chain figures price both against the "
-                                        "low-precision peak and are NOT a kernel roofline")
+        if self.mixed:      # split-operand deformation launches (three bf16 MFMAs per product) + bf16 / split-operand radiance launches: ONE pipe
+            chain["frac_executed"] = rays_done * self.exec_flop_per_ray / (field_ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"]
+            chain["mixed_precision"] = ("deformation launches with split bf16 operands (three MFMAs per product) + low-precision radiance launches, all on the "
+                                        "bf16 matrix pipe: frac_executed prices the issued MFMA work against its 2.5 PFLOP/s; the chain figures are NOT a kernel roofline")
         rad = [r for r in recs if r["part"] == 2] or [r for r in recs if r["part"] == 0 and r["level"] == 1]
         kname = {"fp32": "field_forward_f32_kernel<false, 2>", "bf16": "field_forward_bf16w_kernel<2>", "bf16x3": "field_radiance_bf16x3_kernel"}[self.precision_name]
         rms, rsm = sum(r["ms"] for r in rad), sum(r["samples"] for r in rad)
@@ -294,7 +294,7 @@ def add_secondary_legs(result, pkg, dev, args):
     rec, _, _ = measure(pkg, dev, size, "fp32", min(args.steps, 5), 1, arch="nerface")
     result["nerface_fp32"] = {"value": rec["value"], "unit": "rays/s", "ms_per_step": rec["ms_per_step"], "dtype": "f32",
                               "workload": rec["config"]["workload"], "roofline": rec["roofline"]}
-    # the same model in mixed precision (fp32 deformation nets, bf16 radiance nets) and the section-8d PSNR protocol on it
+    # the same model in mixed precision (deformation nets with split bf16 operands, plain-bf16 radiance nets) and the section-8d PSNR protocol on it
     progress("nerface mixed-precision leg")
     recm, outm, rm = measure(pkg, dev, size, "bf16", min(args.steps, 5), 1, arch="nerface")
     rn = ProductRenderer(pkg, dev, size, "fp32", arch="nerface")
@@ -302,7 +302,7 @@ def add_secondary_legs(result, pkg, dev, args):
     rn.seed += 1000
     tgtn = rn.frame()
     p_b, p_f = psnr(rgb_fine(outm), rgb_fine(tgtn)), psnr(rgb_fine(f32n), rgb_fine(tgtn))
-    result["nerface_mixed_bf16"] = {"value": recm["value"], "unit": "rays/s", "ms_per_step": recm["ms_per_step"], "dtype": "f32 deformation nets + bf16 radiance nets",
+    result["nerface_mixed_bf16"] = {"value": recm["value"], "unit": "rays/s", "ms_per_step": recm["ms_per_step"], "dtype": "bf16 radiance nets + deformation nets with split bf16 operands (hi + lo, three MFMAs per product); f32 accumulate",
                                     "speedup_vs_nerface_fp32": recm["value"] / rec["value"], "roofline": recm["roofline"],
                                     "psnr_mixed_vs_fp32_db": psnr(rgb_fine(outm), rgb_fine(f32n)), "psnr_mixed_vs_target_db": p_b,
                                     "psnr_fp32_vs_target_db": p_f, "delta_psnr_db": abs(p_b - p_f), "w_bg_mean": float(f32n[6].mean())}

@@ -160,8 +160,9 @@ int sahs_conditioning_backward(const float *flat_params, const float *audio, con
  * window for the AudioFaceModel and the 76-d expression vector (models.py:368 `driving.repeat`) for the NeRFaceModels;
  * rays, depths and outputs are the same, and sahs_get_ray_bundle, sahs_ray_uniforms, sahs_stratified_depths,
  * sahs_composite_forward, sahs_resample, sahs_sample_pdf are model-independent.  Training is SAHS_F32 for every model; rendering
- * additionally has SAHS_BF16 for all three (for SAHS_MODEL_NERFACE that means MIXED precision: fp32 deformation nets + bf16 radiance
- * nets, see sahs_model_field_forward_split) and SAHS_BF16X3 for SAHS_MODEL_AUDIO. */
+ * additionally has SAHS_BF16 for all three (for SAHS_MODEL_NERFACE that means MIXED precision: deformation nets with split bf16 operands --
+ * hi + lo, three MFMAs per product, as SAHS_BF16X3 -- + plain-bf16 radiance nets, see sahs_model_field_forward_split) and SAHS_BF16X3 for
+ * SAHS_MODEL_AUDIO. */
 #define SAHS_MODEL_AUDIO 0
 #define SAHS_MODEL_NERFACE 1
 #define SAHS_MODEL_NERFACE_STATIC 2
@@ -224,9 +225,9 @@ int sahs_resample_merge(long N, int S, int nf, const float *z, const float *weig
  * radiance net of `level` only, for S samples per ray whose (x', w) are xw[ray][src[ray][s]] (z unused).  Same arithmetic on the same
  * operands as sahs_model_field_forward: bit-identical raw.  SAHS_F32 for the models with deformation nets (not SAHS_MODEL_NERFACE_STATIC);
  * SAHS_BF16 for SAHS_MODEL_AUDIO (packed from sahs_pack_weights(..., SAHS_BF16, ...)) and for SAHS_MODEL_NERFACE, where it means MIXED
- * precision: mode 1 runs the fp32 deformation nets, mode 2 the bf16 radiance nets (src may then be NULL: sample s of a ray is column s
- * of xw), mode 0 both one after the other (xw_col0 must be 0); packed = sahs_model_pack_weights(SAHS_MODEL_NERFACE, ..., SAHS_BF16, ...) =
- * [bf16 radiance stream | fp32 pack].  SAHS_MODEL_NERFACE_STATIC has no deformation nets: its SAHS_BF16 path is sahs_model_field_forward.
+ * precision: mode 1 runs the deformation nets with split bf16 operands (fp32 kernel under SAHS_X3_DEFORM=f32), mode 2 the bf16 radiance nets
+ * (src may then be NULL: sample s of a ray is column s of xw), mode 0 both one after the other (xw_col0 must be 0); packed =
+ * sahs_model_pack_weights(SAHS_MODEL_NERFACE, ..., SAHS_BF16, ...) = [bf16 radiance stream | fp32 pack | hi/lo streams].  SAHS_MODEL_NERFACE_STATIC has no deformation nets: its SAHS_BF16 path is sahs_model_field_forward.
  * PRECONDITION (not checked on the device): every src[ray][s] lies in [0, xw_row) -- it indexes xw's row of that ray (a permutation from
  * sahs_resample_merge satisfies it; ops.field_forward_split validates a caller-made one). */
 int sahs_model_field_forward_split(int model, const void *packed, const float *frame, int precision, int level, int mode, long N, int S, const float *rays,

@@ -17,6 +17,7 @@ SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "spade_ops.hip", "field_f32
 AB_SOURCES = ["ab/field_bf16.hip", "ab/field_bf16q.hip"]
 # sources built again for the NeRFaceModel architectures (csrc/sahs_model.hpp: -DSAHS_MODEL=1 / 2, symbols suffixed _nf / _ns)
 MODEL_SOURCES = ["pack.hip", "field_f32.hip", "field_bwd.hip"]
+NERFACE_DEFORM_SOURCES = ["field_bf16x3.hip"]      # NeRFaceModel WITH deformation nets (SAHS_MODEL=1): their split-operand kernel (mixed precision)
 MODEL1_SOURCES = ["field_bf16w.hip"]      # NeRFaceModel: the bf16 radiance nets (with deformation nets: those stay fp32; without: the whole net)
 # field kernels: no sNaN-quieting v_max before every fmaxf (activations); NaNs still propagate through the MFMAs
 FIELD_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
@@ -33,7 +34,7 @@ NO_SCRATCH = {"gemm_dma_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb0E": 0
 # destination before the wait that retires it is never linked.
 HAND_SCHEDULED = [("field_bf16w.hip", 0, "field_forward_bf16w_kernel"), ("field_bf16w.hip", 1, "field_forward_bf16w_kernel"),
                   ("field_bf16w.hip", 2, "field_forward_bf16w_kernel"), ("field_bf16x3.hip", 0, "field_radiance_bf16x3_kernel"),
-                  ("field_bf16x3.hip", 0, "field_deform_bf16x3_kernel")]
+                  ("field_bf16x3.hip", 0, "field_deform_bf16x3_kernel"), ("field_bf16x3.hip", 1, "field_deform_bf16x3_kernel")]
 # field_bf16w.hip (one wave per SIMD, 512 registers): MFMA accumulators must live in ARCH VGPRs.  Left to its heuristics the compiler
 # puts them in AGPRs, and every accumulator value the activation code touches then costs a v_accvgpr_read -- which, unlike plain VALU
 # work, does NOT hide under the wave's own MFMAs (tools/micro/mfma_valu_overlap.hip: 2 reads per MFMA = 55 cycles per MFMA instead of 36).
@@ -94,7 +95,7 @@ def build(force=False, verbose=False, defines=(), out=None, check_inflight=True)
     tag = os.path.basename(LIB)
     procs = []
     ab = AB_SOURCES if "SAHS_AB_KERNELS" in defines else []
-    for src, model in [(s, 0) for s in SOURCES + ab] + [(s, m) for m in (1, 2) for s in MODEL_SOURCES] + [(s, m) for m in (1, 2) for s in MODEL1_SOURCES]:
+    for src, model in [(s, 0) for s in SOURCES + ab] + [(s, m) for m in (1, 2) for s in MODEL_SOURCES] + [(s, m) for m in (1, 2) for s in MODEL1_SOURCES] + [(s, 1) for s in NERFACE_DEFORM_SOURCES]:
         obj = os.path.join(bdir, (tag + "." if out else "") + os.path.basename(src).replace(".hip", ".m%d.o" % model if model else ".o"))
         objs.append(obj)
         cmd = _compile_cmd(hipcc, src, model, defines) + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]

@@ -97,6 +97,11 @@ long sahs_layout_packed_words_bf16x3(void);
 int sahs_pack_weights_bf16x3_launch(const float *flat, float *packed, hipStream_t stream);
 int sahs_field_deform_bf16x3_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                     const float *zvals, float *xw, int xw_row, int xw_col0, int num_cu, hipStream_t stream);
+// NeRFaceModel with deformation nets: the same kernel for its mixed-precision path's deformation launches (field_bf16x3.hip, SAHS_MODEL=1)
+long sahs_layout_packed_words_bf16x3_nf(void);
+int sahs_pack_weights_bf16x3_launch_nf(const float *flat, float *packed, hipStream_t stream);
+int sahs_field_deform_bf16x3_launch_nf(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
+                                       const float *zvals, float *xw, int xw_row, int xw_col0, int num_cu, hipStream_t stream);
 int sahs_field_radiance_bf16x3_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                       float *raw, const float *xw, int xw_row, const int *src, int num_cu, hipStream_t stream);
 // NeRFaceModel without deformation nets (person_1.yml): the whole network in bf16
@@ -481,12 +486,14 @@ static const ModelFns kModels[3] = {
 #define REQUIRE_MODEL(m, name) do { if ((m) < 0 || (m) > 2) return fail(3, "%s: unknown model %ld", name, (long)(m)); } while (0)
 
 long sahs_model_param_count(int model) { return (model < 0 || model > 2) ? -1 : kModels[model].param_count(); }
+// NeRFaceModel, mixed precision: word offset of the split-operand streams behind [bf16 radiance pack | fp32 pack], 16-byte aligned
+static long nf_mixed_x3_off() { return (sahs_layout_packed_words_bf16_nf() + kModels[SAHS_MODEL_NERFACE].packed_words_f32() + 3) / 4 * 4; }
 long sahs_model_packed_words(int model, int precision)
 {
     if (model < 0 || model > 2) return -1;
     if (model == SAHS_MODEL_AUDIO) return sahs_packed_words(precision);
-    if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)     // mixed precision: [bf16 radiance pack | fp32 pack (deformation nets)]
-        return sahs_layout_packed_words_bf16_nf() + kModels[model].packed_words_f32();
+    if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)     // mixed precision: [bf16 radiance pack | fp32 pack | hi/lo streams (deformation nets)]
+        return nf_mixed_x3_off() + sahs_layout_packed_words_bf16x3_nf();
     if (model == SAHS_MODEL_NERFACE_STATIC && precision == SAHS_BF16) return sahs_layout_packed_words_bf16_ns();
     return precision == SAHS_F32 ? kModels[model].packed_words_f32() : -1;
 }
@@ -495,10 +502,10 @@ long sahs_model_executed_macs_part(int model, int precision, int part)
     if (model < 0 || model > 2 || precision < SAHS_F32 || precision > SAHS_BF16_Q || part < 0 || part > 2) return -1;
     if (precision == SAHS_BF16_Q || precision == SAHS_BF16_2W) precision = SAHS_BF16;      // A/B kernels: the same MFMA work
     if (precision == SAHS_BF16X3)       // fp32 deformation nets + three bf16 MFMAs per product of the radiance nets
-        return model != SAHS_MODEL_AUDIO ? -1 : (part != 2 ? sahs_layout_executed_macs(SAHS_F32, 1) : 0) + (part != 1 ? 3 * sahs_layout_executed_macs(SAHS_BF16, 2) : 0);
+        return model != SAHS_MODEL_AUDIO ? -1 : 3 * sahs_layout_executed_macs(SAHS_BF16, part);      // three bf16 MFMAs per product, every net
     if (model == SAHS_MODEL_NERFACE_STATIC && part != 0) return part == 2 ? sahs_layout_executed_macs_ns(precision == SAHS_F32 ? SAHS_F32 : SAHS_BF16, 0) : 0;
-    if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)      // mixed: fp32 deformation nets + bf16 radiance nets
-        return (part != 2 ? sahs_layout_executed_macs_nf(SAHS_F32, 1) : 0) + (part != 1 ? sahs_layout_executed_macs_nf(SAHS_BF16, 2) : 0);
+    if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)      // mixed: split-operand deformation nets (3 MFMAs per product) + bf16 radiance nets
+        return (part != 2 ? 3 * sahs_layout_executed_macs_nf(SAHS_BF16, 1) : 0) + (part != 1 ? sahs_layout_executed_macs_nf(SAHS_BF16, 2) : 0);
     return model == 0 ? sahs_layout_executed_macs(precision, part)
                       : (model == 1 ? sahs_layout_executed_macs_nf(precision, part) : sahs_layout_executed_macs_ns(precision, part));
 }
@@ -513,6 +520,7 @@ int sahs_model_pack_weights(int model, const float *flat_params, void *packed, i
     if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16) {
         int e = sahs_pack_weights_bf16_launch_nf(flat_params, (float *)packed, (hipStream_t)stream);
         if (!e) e = kModels[model].pack_f32(flat_params, (float *)packed + sahs_layout_packed_words_bf16_nf(), (hipStream_t)stream);
+        if (!e) e = sahs_pack_weights_bf16x3_launch_nf(flat_params, (float *)packed + nf_mixed_x3_off(), (hipStream_t)stream);
         return e ? hip_fail("sahs_model_pack_weights", e) : 0;
     }
     if (model == SAHS_MODEL_NERFACE_STATIC && precision == SAHS_BF16) {
@@ -627,12 +635,15 @@ int sahs_model_field_forward_split(int model, const void *packed, const float *f
         const float *pk16 = (const float *)packed, *pk32 = pk16 + (x3 ? sahs_layout_packed_words_bf16x3() : sahs_layout_packed_words_bf16_nf());
         REQUIRE(mode != 0 || xw_col0 == 0, "sahs_model_field_forward_split(mixed precision, mode 0: xw_col0 must be 0)");
         int e = 0;
-        // SAHS_BF16X3: the deformation nets run on the split-operand pipe as well (round 3; SAHS_X3_DEFORM=f32 in the environment keeps
-        // them on the fp32 kernel, the A/B reference and the form rounds 2 shipped)
+        // the deformation nets run on the split-operand pipe (field_bf16x3.hip; round 3 -- SAHS_X3_DEFORM=f32 in the environment keeps them
+        // on the fp32 kernel, the A/B reference and the form round 2 shipped): SAHS_BF16X3 of the AudioFaceModel, and the mixed-precision
+        // NeRFaceModel, whose radiance nets are plain bf16 anyway
         static const bool x3_deform_f32 = getenv("SAHS_X3_DEFORM") != nullptr && strcmp(getenv("SAHS_X3_DEFORM"), "f32") == 0;
-        if (mode != 2 && x3 && !x3_deform_f32)
-            e = probed(probe_kind(model, precision, level, 1), N * S, st, [&] {
-                return sahs_field_deform_bf16x3_launch(pk16, frame, level, N * S, S, rays, ray_stride, z, xw, xw_row, xw_col0, num_cus(), st);
+        if (mode != 2 && !x3_deform_f32)
+            e = probed(probe_kind(model, x3 ? precision : SAHS_BF16X3, level, 1), N * S, st, [&] {
+                return x3 ? sahs_field_deform_bf16x3_launch(pk16, frame, level, N * S, S, rays, ray_stride, z, xw, xw_row, xw_col0, num_cus(), st)
+                          : sahs_field_deform_bf16x3_launch_nf(pk16 + nf_mixed_x3_off(), frame, level, N * S, S, rays, ray_stride, z, xw, xw_row, xw_col0,
+                                                               num_cus(), st);
             });
         else if (mode != 2)
             e = probed(probe_kind(model, SAHS_F32, level, 1), N * S, st, [&] {

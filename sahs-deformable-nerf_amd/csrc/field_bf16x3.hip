@@ -19,11 +19,13 @@
 #include "sahs_layout.hpp"
 #include "bf16_pipe.hpp"
 
-#if SAHS_MODEL != 0
-#error "field_bf16x3.hip is built for the AudioFaceModel only"
+#if SAHS_MODEL == 2
+#error "field_bf16x3.hip: the model without deformation nets has no use for it (its whole net is the plain-bf16 radiance kernel)"
 #endif
+// SAHS_MODEL 0 (AudioFaceModel): both kernels = precision SAHS_BF16X3.  SAHS_MODEL 1 (NeRFaceModel with deformation nets): the deformation
+// kernel only -- the deformation launches of that model's mixed-precision path (SAHS_BF16), whose radiance nets are plain bf16 anyway.
 
-namespace sahs {
+namespace SAHS_NS {
 namespace hx3 {
 using namespace hb;      // the bf16 layer program of sahs_layout.hpp (layers, blocks, bias offsets); offsets of the doubled stream derived below
 using namespace bfp;     // vector types, hand-issued LDS reads + retiring waits, bias helpers, the LDS-DMA chunk context (bf16_pipe.hpp)
@@ -346,6 +348,9 @@ __device__ __forceinline__ void pe_blocks_x(const float *v, int h, Blk *out)
         }
 }
 
+#define CHX(id) (pick_GX(kProgH.layer[id].KB32, kProgH.layer[id].NT32) * kProgH.layer[id].KB32 * 2048)   /* halfwords in one chunk of layer id */
+
+#if SAHS_MODEL == 0      // ---- the radiance kernel (AudioFaceModel) ----
 // trilinear lookup (fp32, ATen corner order, zeros padding); this lane takes channels 16s + 8g + 4h + 0..3
 __device__ __forceinline__ void grid_block_x(const float *__restrict__ grid, float x, float y, float z, int h, Blk &out)
 {
@@ -384,7 +389,6 @@ __device__ __forceinline__ void grid_block_x(const float *__restrict__ grid, flo
         }
 }
 
-#define CHX(id) (pick_GX(kProgH.layer[id].KB32, kProgH.layer[id].NT32) * kProgH.layer[id].KB32 * 2048)   /* halfwords in one chunk of layer id */
 
 // The radiance nets of `level` on S samples per ray whose (x', w) are xw[ray][src ? src[ray][s] : s] (field_f32.hip, FIELD_RADIANCE).
 __global__ void __launch_bounds__(X_THREADS, 1)
@@ -491,6 +495,8 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
     }
 }
 
+#endif      // SAHS_MODEL == 0
+
 // The deformation nets (warp field + hyper sheet, level-independent inputs) on the depths zvals: x' = x + tanh(warp(PE(x))), w = hyper(PE(x))
 // to xw[ray][xw_col0 + s] (field_f32.hip, FIELD_DEFORM; same arguments).  Round 3: with these launches on the split-operand pipe too the
 // bf16x3 frame no longer contains an fp32-MFMA launch.  What that costs in accuracy was measured before it was built
@@ -541,15 +547,16 @@ field_deform_bf16x3_kernel(const float *__restrict__ packed, const float *__rest
 #pragma unroll
             for (int i = 0; i < 3; ++i) x[i] = rp[i] + rp[3 + i] * z;
         }
-        Blk pe_x[2];
-        pe_blocks_x<3, 10, 2>(x, h, pe_x);
+        constexpr int KX32 = (KB_XYZ + 1) / 2;        // 32-feature blocks of PE(x): 2 (10 octaves) | 3 (15 octaves, NeRFaceModel)
+        Blk pe_x[KX32];
+        pe_blocks_x<3, L_XYZ, KX32>(x, h, pe_x);
         {   // warp field (models.py:296-305; layers alternate between two register sets)
             Blk A[4], B[4];
-            dense_x<2, 0, 0, 4, CHX(H_W1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_W0].bias_off, 0.0f, 0.0f);
+            dense_x<KX32, 0, 0, 4, CHX(H_W1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_W0].bias_off, 0.0f, 0.0f);
             dense_x<4, 0, 0, 4, CHX(H_W1), true>(cx, st, A, nullptr, nullptr, B, Ly[H_W1].bias_off, 0.0f, 0.0f);
             dense_x<4, 0, 0, 4, CHX(H_W1), true>(cx, st, B, nullptr, nullptr, A, Ly[H_W1].bias_off + 128, 0.0f, 0.0f);
             dense_x<4, 0, 0, 4, CHX(H_W4), true>(cx, st, A, nullptr, nullptr, B, Ly[H_W3].bias_off, 0.0f, 0.0f);
-            dense_x<4, 2, 0, 4, CHX(H_W5), true>(cx, st, B, pe_x, nullptr, A, Ly[H_W4].bias_off, 0.0f, 0.0f);
+            dense_x<4, KX32, 0, 4, CHX(H_W5), true>(cx, st, B, pe_x, nullptr, A, Ly[H_W4].bias_off, 0.0f, 0.0f);
             dense_x<4, 0, 0, 4, CHX(H_WF), true>(cx, st, A, nullptr, nullptr, B, Ly[H_W5].bias_off, 0.0f, 0.0f);
             f32x16 o;
             dense_x_out<4, CHX(H_H0)>(cx, st, B, o, Ly[H_WF].bias_off, true, 0.0f);
@@ -559,16 +566,16 @@ field_deform_bf16x3_kernel(const float *__restrict__ packed, const float *__rest
         }
         {   // hyper sheet (models.py:307-314)
             Blk A[2], B[2];
-            dense_x<2, 0, 0, 2, CHX(H_H1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_H0].bias_off, 0.0f, 0.0f);
+            dense_x<KX32, 0, 0, 2, CHX(H_H1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_H0].bias_off, 0.0f, 0.0f);
             dense_x<2, 0, 0, 2, CHX(H_H1), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H1].bias_off, 0.0f, 0.0f);
             dense_x<2, 0, 0, 2, CHX(H_H1), true>(cx, st, B, nullptr, nullptr, A, Ly[H_H1].bias_off + 64, 0.0f, 0.0f);
             dense_x<2, 0, 0, 2, CHX(H_H4), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H3].bias_off, 0.0f, 0.0f);
-            dense_x<2, 2, 0, 2, CHX(H_H5), true>(cx, st, B, pe_x, nullptr, A, Ly[H_H4].bias_off, 0.0f, 0.0f);
+            dense_x<2, KX32, 0, 2, CHX(H_H5), true>(cx, st, B, pe_x, nullptr, A, Ly[H_H4].bias_off, 0.0f, 0.0f);
             dense_x<2, 0, 0, 2, CHX(H_HF), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H5].bias_off, 0.0f, 0.0f);
             f32x16 o;
             dense_x_out<2, CHX(H_W0)>(cx, st, B, o, Ly[H_HF].bias_off, true, 0.0f);
             amb[0] = o[0];
-            amb[1] = o[1];
+            amb[1] = AMB_DIM > 1 ? o[1] : 0.0f;      // (NeRFaceModel: one ambient coordinate)
         }
         if (h == 0 && p_raw < P) {
             float *row = xw + ((p / S) * (long)xw_row + xw_col0 + (p % S)) * 8;
@@ -579,11 +586,12 @@ field_deform_bf16x3_kernel(const float *__restrict__ packed, const float *__rest
 }
 
 }  // namespace hx3
-}  // namespace sahs
+}  // namespace SAHS_NS
 
-using namespace sahs;
-using namespace sahs::hx3;
+using namespace SAHS_NS;
+using namespace SAHS_NS::hx3;
 
+#if SAHS_MODEL == 0
 // the radiance launch of the split evaluation (field_f32.hip: sahs_field_forward_f32_split_launch mode 2, same arguments)
 extern "C" int sahs_field_radiance_bf16x3_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays,
                                                  int ray_stride, float *raw, const float *xw, int xw_row, const int *src, int num_cu,
@@ -601,8 +609,10 @@ extern "C" int sahs_field_radiance_bf16x3_launch(const float *packed, const floa
     return (int)hipGetLastError();
 }
 
+#endif
+
 // the deformation launch of the split evaluation (field_f32.hip: sahs_field_forward_f32_split_launch mode 1, same arguments)
-extern "C" int sahs_field_deform_bf16x3_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
+extern "C" int SAHS_SYM(sahs_field_deform_bf16x3_launch)(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                                const float *zvals, float *xw, int xw_row, int xw_col0, int num_cu, hipStream_t stream)
 {
     if (P <= 0) return 0;

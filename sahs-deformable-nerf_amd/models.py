@@ -161,7 +161,7 @@ class _FieldModel(nn.Module):
                 raise NotImplementedError("gradients run through the fp32 path; build the model with precision='fp32'")
             raw = ops.FieldFn.apply(self.flat_params(differentiable=True), driving.to(torch.float32), pose.to(torch.float32), rays, z, packed,
                                     lvl, self.arch)
-        elif ops.is_mixed(self.arch, self.precision):     # mixed precision: fp32 deformation launch, low-precision radiance launch
+        elif ops.is_mixed(self.arch, self.precision):     # split-chain precisions: split-operand deformation launch, low-precision radiance launch
             xw = torch.empty(P, 1, 8, dtype=torch.float32, device=x.device)
             raw = ops.field_forward_split(packed, self.frame(driving, pose), lvl, ops.FIELD_ALL, rays, xw, z=z, arch=self.arch, precision=self.precision)
         else:
@@ -181,9 +181,11 @@ class AudioFaceModel(_FieldModel):
 class NeRFaceModel(_FieldModel):
     """models.py:189-378: expression-driven (driving = the 76-d expression vector).  Two architectures, chosen by the config as
     the reference does (models.py:231,244): warp + hyper sheet on (config/expression/person_2.yml, person_3.yml) or both off
-    (person_1.yml).  fp32 rendering and training; precision="bf16" (the deforming architecture only) is MIXED precision: the
-    deformation nets stay fp32 -- a bf16-level error in the warp output is 16 rad at the 15th octave -- and the radiance nets run on
-    the bf16 matrix pipe; rendering through run_one_iter_of_nerf only (it needs the per-chunk workspace)."""
+    (person_1.yml).  fp32 rendering and training; precision="bf16" (the deforming architecture only) is MIXED precision: a
+    bf16-level error in the warp output would be 16 rad at the 15th octave, so the deformation nets run with every operand split into
+    bf16 hi + lo (three MFMAs per product: x' within 9e-7 of the fp32 kernel's; round 2 ran them on the fp32 kernel, SAHS_X3_DEFORM=f32
+    still does) while the radiance nets run on plain bf16 operands; rendering through run_one_iter_of_nerf only
+    (it needs the per-chunk workspace)."""
 
     def __init__(self, cfg, precision="fp32"):
         super().__init__()

@@ -22,7 +22,8 @@ AB_PRECISIONS = {"bf16_2w": SAHS_BF16_2W, "bf16q": SAHS_BF16_Q}    # development
 
 
 def is_mixed(arch, precision):
-    """Precisions that exist as the split chain only (fp32 deformation launches + a low-precision radiance launch, exchanging x', w)."""
+    """Precisions that exist as the split chain only (a deformation launch with split bf16 operands -- fp32 under SAHS_X3_DEFORM=f32 -- and a
+    low-precision radiance launch, exchanging x', w)."""
     return (precision == SAHS_BF16 and arch == "nerface") or (precision == SAHS_BF16X3 and arch == "audio")
 
 
@@ -301,7 +302,7 @@ def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=
     z_c, z_f = buf("z_c", N, num_coarse), buf("z_f", N, Sf)
     raw, weights = buf("raw", N, Sf, 16), buf("weights", N, Sf)
     xw = src = z_new = None
-    mixed = is_mixed(arch, precision)      # fp32 deformation nets + low-precision radiance nets: only the split chain exists
+    mixed = is_mixed(arch, precision)      # split-operand deformation launch + low-precision radiance launch: only the split chain exists
     if mixed and not (share_deformation and num_fine > 0):
         raise _lib.SahsError("a mixed-precision model renders through the split chain (share_deformation=True, num_fine > 0)")
     if share_deformation and num_fine > 0 and arch != "nerface_static" and precision in (SAHS_F32, SAHS_BF16, SAHS_BF16X3, SAHS_BF16_Q):      # (_Q: A/B builds)

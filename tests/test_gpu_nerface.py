@@ -420,9 +420,12 @@ def test_field_backward_seam_vs_autograd(ops, nf, arch, level):
 
 
 
+X3_XPRIME_BOUND, X3_W_BOUND = 4e-6, 6e-5      # ~4x observed (8.9e-7; 1.55e-5 on a scale of 1.2); the fp32 kernel: 1e-7
+
+
 def test_mixed_precision_bf16_vs_fp32(ops, nf):
-    """NeRFaceModel in mixed precision (precision "bf16": fp32 deformation nets, bf16 radiance nets) against
-    its fp32 path on the same rays, weights and draws: the deformed points are the fp32 launch's own (bit-identical x', w), the
+    """NeRFaceModel in mixed precision (precision "bf16": deformation nets with split bf16 operands, plain-bf16 radiance nets; DESIGN.md
+    section 7b) against its fp32 path on the same rays, weights and draws: the deformed points agree to the split-operand accuracy, the
     radiance nets' raw output differs by bf16 rounding, and the rendered frame stays within the PSNR bound of the audio model's
     bf16 path.  Observed values are printed; the bounds are ~3x of them."""
     import json
@@ -449,8 +452,12 @@ def test_mixed_precision_bf16_vs_fp32(ops, nf):
         ops.render_rays_rows(packs[p], frame, rays, nc, nfine, rows, precision=ops.PRECISIONS[p], bg=bg, t_rand=t_rand, u=u, workspace=ws, arch="nerface")
         out[p] = (rows, ws["xw"].clone(), ws["raw"].clone(), ws["z_f"].clone())
         assert bool(torch.isfinite(rows).all()), p
-    # coarse pass: same depths, so the fp32 deformation launch gives bit-identical (x', w) for the coarse columns
-    assert torch.equal(out["fp32"][1][:, :nc, :5], out["bf16"][1][:, :nc, :5])
+    # coarse pass: same depths; the mixed path's deformation launch runs on the split-operand pipe (round 3), so its (x', w) are the fp32
+    # launch's to ~16 bits per operand: x' = x + tanh(.) adds a small correction to an exact x, w is a raw network output
+    dxw = (out["fp32"][1][:, :nc, :5] - out["bf16"][1][:, :nc, :5]).abs()
+    seam = dict(xprime_max=float(dxw[..., :3].max()), w_max=float(dxw[..., 3:5].max()), w_scale=float(out["fp32"][1][:, :nc, 3:5].abs().max()))
+    print(json.dumps(seam))
+    assert seam["xprime_max"] <= X3_XPRIME_BOUND and seam["w_max"] <= X3_W_BOUND * max(1.0, seam["w_scale"]), seam
     a, b = out["fp32"][0], out["bf16"][0]
     mse = lambda x, y: float(((x - y) ** 2).mean())
     psnr = lambda m: -10.0 * np.log10(max(m, 1e-30))
@@ -461,7 +468,7 @@ def test_mixed_precision_bf16_vs_fp32(ops, nf):
     print(json.dumps(res))
     assert res["psnr_rgb_coarse"] >= 38.0 and res["psnr_rgb_fine"] >= 33.0, res
     assert res["acc_max_abs"] <= 1e-3 and 0.02 < res["w_bg_mean"] < 0.98, res
-    # the B2 seam of a mixed-precision model: model(level, x) = fp32 deformation launch + bf16 radiance launch
+    # the B2 seam of a mixed-precision model: model(level, x) = split-operand deformation launch + bf16 radiance launch
     sahs = pkg()
     cfg = sahs.default_config("expression")
     m32 = sahs.NeRFaceModel(cfg).to(d).load_flat(fw).eval()
