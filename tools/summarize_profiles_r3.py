@@ -51,7 +51,7 @@ def kind(kn, leg):
     if "field_radiance_bf16x3_kernel" in kn:
         return "bf16x3_radiance"
     if "field_deform_bf16x3_kernel" in kn:
-        return "bf16x3_deform"
+        return "nf_x3_deform" if nf else "bf16x3_deform"
     if "field_forward_bf16w" in kn:
         m = mode_of(kn, "kernel<")
         return None if m is None else ("nf_bf16_" if nf else "bf16_") + {"0": "all", "1": "deform", "2": "radiance"}[m]
@@ -70,8 +70,8 @@ for leg, args, steps, what in (("f32", "--precision fp32", 2, "fp32 W512 headlin
                                ("bf16", "--precision bf16", 4, "bf16 W512: field_forward_bf16w_kernel<0|1|2>, same three launches per chunk"),
                                ("bf16x3", "--precision bf16x3", 2, "bf16x3 W512: field_deform_bf16x3_kernel (deformation nets, coarse and new depths: 8.39 M samples each) + "
                                 "field_radiance_bf16x3_kernel on the 8.39 M coarse and the 16.78 M fine samples of a chunk"),
-                               ("nfmixed", "--arch nerface --precision bf16", 3, "NeRFaceModel (config/expression/person_2.yml) in mixed precision: fp32 deformation "
-                                "launches (sahs_nf::field_forward_f32_kernel<false,1>) + sahs_nf::field_forward_bf16w_kernel<2> radiance launches")):
+                               ("nfmixed", "--arch nerface --precision bf16", 3, "NeRFaceModel (config/expression/person_2.yml) in mixed precision: deformation launches with split bf16 "
+                                "operands (sahs_nf::hx3::field_deform_bf16x3_kernel) + sahs_nf::field_forward_bf16w_kernel<2> radiance launches")):
     stats[leg] = kernel_stats("trace_" + leg, "%s_%s_kernel_stats.csv" % (tag, {"f32": "fp32"}.get(leg, leg)),
                               "rocprofv3 --kernel-trace --stats -- %s %s --steps %d --warmup 1   (%s)" % (B, args, steps, what))
     shutil.copy(os.path.join(base, "bench_trace_%s.json" % leg), os.path.join(out, "%s_%s_bench_under_rocprof.json" % (tag, {"f32": "fp32"}.get(leg, leg))))
@@ -111,6 +111,7 @@ for k, label, pick, samples, alg_bytes in (
         ("bf16x3_radiance", "bf16x3 radiance-net launch over the 16.78 M fine samples (second dispatch of a chunk; the first is the coarse pass's 8.39 M)",
          1, P_FINE, P_FINE * (64 + 32 + 4)),
         ("bf16x3_deform", "bf16x3 deformation-net launch (8.39 M depths)", 0, P_FINE // 2, (P_FINE // 2) * (4 + 32)),
+        ("nf_x3_deform", "NeRFaceModel (mixed precision) deformation-net launch with split bf16 operands (8.39 M depths)", 0, P_FINE // 2, (P_FINE // 2) * (4 + 32)),
         ("nf_bf16_radiance", "NeRFaceModel bf16 radiance-net launch over the 16.78 M fine samples (second dispatch of a chunk)", 1, P_FINE, P_FINE * (64 + 32 + 4))):
     if (k, "GRBM_GUI_ACTIVE") not in agg or len(agg[(k, "GRBM_GUI_ACTIVE")]) <= pick:
         continue
