@@ -555,15 +555,18 @@ def main(argv=None):
     backend = os.environ.get("SAHS_BENCH_BACKEND", "nccl")
     injected = os.environ.get("SAHS_BENCH_RENDERER")
     rehearsal = backend != "nccl"
-    if rehearsal and not injected:
-        raise SystemExit("bench.py: SAHS_BENCH_BACKEND=%s is the CPU rehearsal of the control flow and needs SAHS_BENCH_RENDERER" % backend)
+    # SAHS_BENCH_ONE_GPU=1 (tests/test_gpu_sharded.py): every rank drives cuda:0 and the collectives go over gloo (RCCL refuses two ranks
+    # on one device) -- the REAL renderer, launch probe and roofline code of an N > 1 run, rehearsed on a one-GPU box; not a measurement
+    one_gpu = rehearsal and os.environ.get("SAHS_BENCH_ONE_GPU") == "1"
+    if rehearsal and not injected and not one_gpu:
+        raise SystemExit("bench.py: SAHS_BENCH_BACKEND=%s is a rehearsal of the control flow and needs SAHS_BENCH_RENDERER or SAHS_BENCH_ONE_GPU=1" % backend)
     dist = None
-    if rehearsal:
+    if rehearsal and not one_gpu:
         dev = torch.device("cpu")
     else:
         assert torch.cuda.is_available(), "bench.py needs a MI355X"
-        torch.cuda.set_device(local)
-        dev = torch.device("cuda", local)
+        torch.cuda.set_device(0 if one_gpu else local)
+        dev = torch.device("cuda", 0 if one_gpu else local)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend, **({} if rehearsal else {"device_id": dev}))
@@ -578,6 +581,9 @@ def main(argv=None):
     else:
         pkg = importlib.import_module("sahs-deformable-nerf_amd")
         result, out, rend = measure(pkg, dev, args.size, args.precision, args.steps, args.warmup, arch=args.arch, world=world, dist=dist)
+        if one_gpu:
+            result["collective_backend"] = backend
+            result["rehearsal"] = "every rank on cuda:0, %s collectives: the N > 1 code path on one GPU, not a measurement" % backend
         if args.precision == "fp32" and world == 1 and args.arch == "audio":
             if not args.no_secondary:
                 add_secondary_legs(result, pkg, dev, args)

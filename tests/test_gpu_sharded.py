@@ -153,3 +153,28 @@ def _rccl_worker(rank, world, port):
 
 def test_rccl_accepts_the_products_collective_calls():
     mp.start_processes(_rccl_worker, args=(1, free_port()), nprocs=1, join=True, start_method="spawn")
+
+
+def test_bench_main_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` exactly as the driver invokes it, on the one-GPU test box: main() starts two fresh ranks, both drive
+    cuda:0 (SAHS_BENCH_ONE_GPU=1) and talk over gloo, and everything else is the N > 1 run's own code -- ProductRenderer(shard=True) ->
+    run_one_iter_of_nerf(_shard=True), the launch probe, the roofline of a rank's launches, barrier-bracketed timing, MAX over ranks,
+    rank 0's JSON line.  (RCCL itself: test_rccl_accepts_the_products_collective_calls.)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SAHS_BENCH_BACKEND="gloo", SAHS_BENCH_ONE_GPU="1")
+    for size in (64, 63):      # 4096 rays: even split, in-place all-gather; 3969 rays: ragged split, padded gather
+        p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", str(size)],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 == d["rccl_ranks"] and d["collective_backend"] == "gloo" and "rehearsal" in d and d["scaling"] == "strong"
+        assert d["config"]["rays_per_step"] == size * size and "rays x2" in d["config"]["parallelism"]
+        assert abs(d["value"] - size * size / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+        r = d["roofline"]
+        # rank 0's launches: its half of the rays, 3 field launches per chunk and step
+        assert r["bound"] == "mfma" and r["launches"] >= 2 and 0.0 < r["frac"] < 1.0 and r["chain"]["launches"] >= 6, r
+        assert "bf16" not in d and "cpu_baseline" not in d          # N > 1: the headline only
