@@ -77,3 +77,23 @@ def generator(sd, i_src, i_raw):
                                 ("layer5.", f3, False, True), ("layer6.", f2, False, True), ("layer7.", f1, False, True)):
         x = spade_block(_sub(r, name), x, fid, downsample=down, upsample=up)
     return F.conv2d(x, r["layer8.weight"], r["layer8.bias"], padding=1)
+
+
+def audio_code(sd, window):
+    """_init_spade.py:351-356 (AudioNet.forward of the Stage-II file): the 64 convolution features of the 16 x 29 window."""
+    x = window.unsqueeze(0).permute(0, 2, 1)
+    for i in (0, 2, 4, 6):
+        x = F.leaky_relu(F.conv1d(x, sd["encoder_conv.%d.weight" % i], sd["encoder_conv.%d.bias" % i], stride=2, padding=1), 0.02)
+    return x.squeeze(-1)
+
+
+def generator_audio(sd, i_src, i_raw, window):
+    """_init_spade.py:365-372: the third identity map replaced by the audio code repeated to (1, 256, 64, 4096), materialised as the reference does."""
+    f1, f2, _ = id_encoder(_sub(sd, "idencoder."), i_src)
+    f3 = audio_code(_sub(sd, "AudioNet."), window).unsqueeze(1).repeat(1, 256, 64, 64)
+    r = _sub(sd, "refine_network.")
+    x = F.avg_pool2d(F.conv2d(i_raw, r["layer1.0.weight"], r["layer1.0.bias"], padding=1), 2, stride=2)
+    for name, fid, down, up in (("layer2.", f1, True, False), ("layer3.", f2, True, False), ("layer4.", f3, False, False),
+                                ("layer5.", f3, False, True), ("layer6.", f2, False, True), ("layer7.", f1, False, True)):
+        x = spade_block(_sub(r, name), x, fid, downsample=down, upsample=up)
+    return F.conv2d(x, r["layer8.weight"], r["layer8.bias"], padding=1)

@@ -1,4 +1,4 @@
-"""Building blocks of the Stage-II SPADE refiner: drop-ins for ``SPADELayer`` and ``SPADEBlock`` of the
+"""The Stage-II SPADE refiner: drop-ins for ``SPADELayer``, ``SPADEBlock``, the generators built from them, of the
 reference's ``nerf/_init_spade.py`` (:114-160, :235-282) with the reference's ``state_dict`` layout (including the duplicated
 ``conv1`` / ``conv1_sn`` entries: the reference registers each spectral-normalised convolution under two names), so its checkpoints load.
 
@@ -19,6 +19,33 @@ def _conv3(cin, cout, stride=1):
     return nn.Conv2d(cin, cout, 3, stride, 1)
 
 
+class TiledCodeMap:
+    """The modulation map Generator_audio builds from the audio code (_init_spade.py:366-370): the 64-vector repeated to a (1, channels, height,
+    64 * tiles) tensor -- every channel and every row the same, the code tiled along the width; the reference materialises it (268 MB for
+    its 256 x 64 x 4096) and lets every SPADELayer resize it by nearest neighbour.  Here it stays the 64 numbers: ``nearest(size)`` returns
+    what ``F.interpolate(materialised, size, mode="nearest")`` returns, computed from ATen's own index rule."""
+
+    def __init__(self, code, channels, height, tiles):
+        self.code, self.channels, self.height, self.tiles = code.reshape(-1), int(channels), int(height), int(tiles)
+
+    @staticmethod
+    def _nearest_index(out_size, in_size):
+        """ATen upsample_nearest (non-exact mode): min(floor(dst * float32(in / out)), in - 1), evaluated in float32 as ATen does."""
+        import numpy as np
+        scale = np.float32(in_size) / np.float32(out_size)
+        idx = np.floor(np.arange(out_size, dtype=np.float32) * scale).astype(np.int64)
+        return np.minimum(idx, in_size - 1)
+
+    def nearest(self, size):
+        h, w = int(size[0]), int(size[1])
+        cols = torch.from_numpy(self._nearest_index(w, self.code.numel() * self.tiles) % self.code.numel()).to(self.code.device)
+        return self.code[cols].reshape(1, 1, 1, w).expand(1, self.channels, h, w).contiguous()
+
+    def materialise(self):
+        """The reference's tensor (tests compare ``nearest`` against interpolating this)."""
+        return self.code.reshape(1, 1, 1, -1).repeat(1, self.channels, self.height, self.tiles)
+
+
 class SPADELayer(nn.Module):
     """_init_spade.py:114-139: out = InstanceNorm(x) * (1 + gamma(F_id)) + beta(F_id), F_id resized to x by nearest neighbour.
     The parameter-free norm and the activation of the reference's module tree hold no state and are not modules here: they are the
@@ -35,7 +62,8 @@ class SPADELayer(nn.Module):
         """_slope (not in the reference): the LeakyReLU slope of the SPADEBlock that follows, fused into the modulate kernel."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError("the fused SPADE modulation is inference-only: call under torch.no_grad()")
-        hidden = self.mlp_shared(F.interpolate(F_id, size=x.shape[-2:], mode="nearest"))
+        F_id = F_id.nearest(x.shape[-2:]) if isinstance(F_id, TiledCodeMap) else F.interpolate(F_id, size=x.shape[-2:], mode="nearest")
+        hidden = self.mlp_shared(F_id)
         return ops.spade_modulate(x, self.conv_gamma(hidden), self.conv_beta(hidden), eps=self.EPS, slope=_slope)
 
 
@@ -152,3 +180,38 @@ class Generator(nn.Module):
 
     def forward(self, I_src, I_raw):
         return self.refine_network(I_raw, *self.idencoder(I_src))
+
+
+class AudioNet(nn.Module):
+    """_init_spade.py:327-357, the Stage-II file's own audio encoder: four stride-2 Conv1d over the 16-frame window of 29 DeepSpeech features,
+    LeakyReLU(0.02) after each; its ``encoder_fc1`` exists (it is in the checkpoints) but the forward returns the 64 convolution features."""
+    CHANNELS = (29, 32, 32, 64, 64)
+
+    def __init__(self, dim_aud=76, win_size=16):
+        super().__init__()
+        self.win_size, self.dim_aud = win_size, dim_aud
+        convs = []
+        for cin, cout in zip(self.CHANNELS[:-1], self.CHANNELS[1:]):
+            convs += [nn.Conv1d(cin, cout, 3, 2, 1), nn.LeakyReLU(0.02)]
+        self.encoder_conv = nn.Sequential(*convs)
+        self.encoder_fc1 = nn.Sequential(nn.Linear(64, 64), nn.LeakyReLU(0.02), nn.Linear(64, dim_aud))
+
+    def forward(self, x):
+        half = self.win_size // 2
+        return self.encoder_conv(x[:, 8 - half:8 + half, :].transpose(1, 2)).squeeze(-1)
+
+
+class Generator_audio(nn.Module):
+    """_init_spade.py:359-372: G(I_src, I_raw, audio window) of eval_get_texture_photo_audio.py:156 -- the deepest identity map is replaced by
+    the audio code tiled over a 256 x 64 x 4096 map (TiledCodeMap: never materialised here).  Inference only (see SPADELayer)."""
+
+    def __init__(self):
+        super().__init__()
+        self.idencoder = IdEncoder()
+        self.refine_network = RefineNetwork(*IdEncoder.WIDTHS)
+        self.AudioNet = AudioNet(76, 16)
+
+    def forward(self, I_src, I_raw, driving_data):
+        fid1, fid2, _ = self.idencoder(I_src)
+        code = self.AudioNet(driving_data.unsqueeze(0))                       # (1, 64)
+        return self.refine_network(I_raw, fid1, fid2, TiledCodeMap(code, IdEncoder.WIDTHS[2], 64, 64))

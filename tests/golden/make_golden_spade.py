@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Golden vectors for the Stage-II SPADE refiner's building blocks from the REAL reference:
-``SPADELayer`` and ``SPADEBlock`` of /root/reference/nerf-pytorch/nerf/_init_spade.py (:114-160, :235-282), imported unmodified through
+``SPADELayer`` and ``SPADEBlock`` of /root/reference/nerf-pytorch/nerf/_init_spade.py (:114-160, :235-282), its ``Generator`` (:315-325) and ``Generator_audio`` (:327-372), imported unmodified through
 the same harness shim as make_golden.py (plus an empty ``torchvision`` stub: the file imports torchvision.models for its VGG loss class,
 which is off this path; torchvision is not installed here).  Runs only in the build container.  Stores, per case, the module's
 state_dict (random init under a fixed seed -- small channel counts keep the file small), the inputs and the outputs in eval mode
@@ -78,6 +78,25 @@ def main():
     out["generator:param_count"] = np.array(sum(v.numel() for v in sd.values()), np.int64)
     out["generator:param_abs_sum"] = np.array(sum(float(v.double().abs().sum()) for v in sd.values()), np.float64)
     print("generator", tuple(i_src.shape), "->", tuple(y.shape), "state_dict entries:", len(sd), "values:", int(out["generator:param_count"]))
+    # Generator_audio (:359-372): the same generator with the audio code as its deepest modulation map
+    torch.manual_seed(9)
+    Ga = S.Generator_audio().eval()
+    torch.manual_seed(9)
+    Gam = mine.Generator_audio().eval()
+    sda, sdam = Ga.state_dict(), Gam.state_dict()
+    assert list(sda.keys()) == list(sdam.keys()), "Generator_audio: state_dict layout differs from the reference's"
+    assert all(torch.equal(sda[k], sdam[k]) for k in sda), "Generator_audio: seeded initialisation differs from the reference's"
+    window = torch.randn(16, 29, generator=gen)
+    i_src2, i_raw2 = torch.rand(1, 3, 48, 80, generator=gen), torch.rand(1, 3, 48, 80, generator=gen)      # feature maps 6 x 10 and 12 x 20: widths that do not divide 4096
+    with torch.no_grad():
+        ya = Ga(i_src2, i_raw2, window)
+        code = Ga.AudioNet(window.unsqueeze(0))
+    out["generator_audio:i_src"], out["generator_audio:i_raw"], out["generator_audio:window"] = i_src2.numpy(), i_raw2.numpy(), window.numpy()
+    out["generator_audio:y"], out["generator_audio:code"] = ya.numpy(), code.numpy()
+    out["generator_audio:seed"] = np.array(9, np.int64)
+    out["generator_audio:param_count"] = np.array(sum(v.numel() for v in sda.values()), np.int64)
+    out["generator_audio:param_abs_sum"] = np.array(sum(float(v.double().abs().sum()) for v in sda.values()), np.float64)
+    print("generator_audio", tuple(i_src2.shape), "->", tuple(ya.shape), "state_dict entries:", len(sda))
     np.savez_compressed(os.path.join(HERE, "spade.npz"), **out)
     print("wrote", os.path.join(HERE, "spade.npz"), os.path.getsize(os.path.join(HERE, "spade.npz")), "bytes")
 

@@ -70,6 +70,54 @@ def test_generator_restatement_vs_reference():
     assert np.abs(y.numpy() - g["generator:y"]).max() <= 2e-4 * np.abs(g["generator:y"]).max()
 
 
+def _seeded_generator_audio(g):
+    S = pkg("spade")
+    torch.manual_seed(int(g["generator_audio:seed"]))
+    G = S.Generator_audio().eval()
+    sd = G.state_dict()
+    assert sum(v.numel() for v in sd.values()) == int(g["generator_audio:param_count"])
+    total = sum(float(v.double().abs().sum()) for v in sd.values())
+    assert abs(total - float(g["generator_audio:param_abs_sum"])) <= 1e-9 * total, "seeded initialisation differs from the fixture's (another torch build?)"
+    return G
+
+
+def test_generator_audio_restatement_vs_reference():
+    """Generator_audio (_init_spade.py:327-372: the audio code as the deepest modulation map) by the CPU restatement -- which materialises the
+    reference's (1, 256, 64, 4096) map -- against the reference's output on a 48 x 80 frame (feature-map widths 10 and 20 do not divide 4096);
+    and the drop-in's TiledCodeMap against nearest-neighbour interpolation of the materialised map."""
+    from oracle import spade_eager as SE
+    S = pkg("spade")
+    g = load_golden("spade")
+    G = _seeded_generator_audio(g)
+    sd = G.state_dict()
+    window = torch.from_numpy(g["generator_audio:window"])
+    with torch.no_grad():
+        code = SE.audio_code({k[len("AudioNet."):]: v for k, v in sd.items() if k.startswith("AudioNet.")}, window)
+        assert np.abs(code.numpy() - g["generator_audio:code"]).max() <= 1e-5 * np.abs(g["generator_audio:code"]).max()
+        assert np.abs(G.AudioNet(window.unsqueeze(0)).numpy() - g["generator_audio:code"]).max() <= 1e-5 * np.abs(g["generator_audio:code"]).max()
+        y = SE.generator_audio(sd, torch.from_numpy(g["generator_audio:i_src"]), torch.from_numpy(g["generator_audio:i_raw"]), window)
+    ref = g["generator_audio:y"]
+    assert y.shape == ref.shape and np.abs(y.numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+    m = S.TiledCodeMap(torch.arange(64, dtype=torch.float32) * 0.5 - 7.0, channels=2, height=64, tiles=64)
+    big = m.materialise()
+    assert tuple(big.shape) == (1, 2, 64, 4096)
+    for size in ((6, 10), (12, 20), (8, 8), (64, 64), (5, 4096), (3, 8192), (7, 97), (1, 1)):
+        assert torch.equal(m.nearest(size), torch.nn.functional.interpolate(big, size=size, mode="nearest")), size
+
+
+@pytest.mark.gpu
+def test_generator_audio_vs_reference_on_gpu():
+    g = load_golden("spade")
+    dev = torch.device("cuda:0")
+    G = _seeded_generator_audio(g).to(dev)
+    T = lambda k: torch.from_numpy(g["generator_audio:" + k]).to(dev)
+    with torch.no_grad():
+        y = G(T("i_src"), T("i_raw"), T("window"))
+    ref = g["generator_audio:y"]
+    assert tuple(y.shape) == ref.shape
+    assert float((y.cpu() - torch.from_numpy(ref)).abs().max()) <= 5e-4 * float(np.abs(ref).max())
+
+
 @pytest.mark.gpu
 def test_generator_vs_reference_on_gpu():
     g = load_golden("spade")
