@@ -204,3 +204,34 @@ def test_bf16x3_frame_vs_fp32_within_4x_of_its_tolerance(weights_mod):
     for nm, a, b in zip(("rgb", "disp", "acc", "weights", "depth"), res["fp32"], res["bf16x3"]):
         a, b = a.reshape(N, -1), b.reshape(N, -1)
         assert bool(((a - b).abs() <= 4e-5 + 4e-4 * a.abs()).all()), (nm, float((a - b).abs().max()))
+
+
+def test_bf16x3_w512_frame_vs_fp32(weights_mod):
+    """BASELINE.json's full size (512 x 512 rays, 64 + 128 evaluations) through the drop-in driver, bf16x3 (every net with split bf16 operands)
+    against fp32 on the same keyed draws: every coarse output of every ray within 4x the fp32 tolerance, the fine outputs too except the
+    resampling-knot rays, image PSNR.  (Observed: coarse max |d| 4.1e-5, 6.6 % knot rays, 70.0 dB.)"""
+    sahs = pkg()
+    d = dev()
+    cfg = sahs.default_config()
+    fw = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 2.0, 30.0, hdr=True))
+    H = W = 512
+    rng = np.random.default_rng(42)
+    audio = T(rng.standard_normal((16, 29)).astype(np.float32))
+    pose = T(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32))
+    intr = np.array([1200.0, 1200.0, 0.5, 0.5], np.float32)
+    bg = T(np.concatenate([rng.uniform(0, 1, (H * W, 3)), np.ones((H * W, 1)), np.zeros((H * W, 11))], 1).astype(np.float32))
+    rows = {}
+    for prec in ("fp32", "bf16x3"):
+        model = sahs.AudioFaceModel(cfg, precision=prec).to(d).load_flat(fw).eval()
+        ro, rd = sahs.get_ray_bundle(H, W, intr, pose)
+        with torch.no_grad(), sahs.train_utils.partition_invariant_rng(7):
+            out = sahs.run_one_iter_of_nerf(H, W, intr, model, ro, rd, cfg, mode="validation", driving=audio, pose=pose, background_prior=bg)
+        rows[prec] = torch.cat([o.reshape(H * W, -1) for o in out], dim=1)
+        del model
+    a, b = rows["fp32"], rows["bf16x3"]
+    assert bool(torch.isfinite(b).all())
+    bad = (a - b).abs() > 4e-5 + 4e-4 * a.abs()
+    res = dict(coarse_max=float((a[:, :17] - b[:, :17]).abs().max()), coarse_bad=float(bad[:, :17].any(dim=1).float().mean()),
+               fine_bad=float(bad[:, 17:].any(dim=1).float().mean()), psnr_rgb_fine=psnr(a[:, 17:20], b[:, 17:20]), w_bg_mean=float(a[:, 34].mean()))
+    print(json.dumps(res))
+    assert res["coarse_bad"] == 0.0 and res["fine_bad"] <= 0.10 and res["psnr_rgb_fine"] >= 60.0 and 0.02 < res["w_bg_mean"] < 0.9, res
