@@ -1,6 +1,6 @@
 """Print the per-kernel summary of a rocprofv3 --kernel-trace --stats run (directory argument)."""
-import csv, glob, sys
-f = glob.glob(sys.argv[1] + '/**/*_kernel_stats.csv', recursive=True)[0]
+import csv, glob, os, sys
+f = max(glob.glob(sys.argv[1] + '/**/*_kernel_stats.csv', recursive=True), key=os.path.getmtime)      # (gpurun merges calls: take the newest run)
 rows = list(csv.DictReader(open(f)))
 div = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 print("total ms", sum(float(r['TotalDurationNs']) for r in rows) / 1e6 / div)
