@@ -1082,7 +1082,7 @@ __global__ void __launch_bounds__(256) grid_transpose_kernel(const float *__rest
         for (int r = 0; r < 4; ++r) { const int vv = j + 8 * r; t[vv][i] = src[(v0 + vv) * 32 + i]; }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int ch = j + 8 * r; dst[(long)ch * vox + v0 + i] += t[i][ch]; }
+        for (int r = 0; r < 4; ++r) { const int ch = j + 8 * r; atomicAdd(dst + (long)ch * vox + v0 + i, t[i][ch]); }      // (both levels' walks add here, possibly at once)
     }
 }
 
@@ -1110,22 +1110,24 @@ __global__ void __launch_bounds__(256) const_cols_backward_kernel(int rows, int 
     for (int r = threadIdx.x; r < rows; r += blockDim.x) {
         const float g = db[r];
         s += W[(long)r * ld + col0 + k] * g;
-        dW[(long)r * ld + col0 + k] += g * ck;
+        atomicAdd(dW + (long)r * ld + col0 + k, g * ck);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) dc[k] += (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) atomicAdd(dc + k, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
 __global__ void axpy_kernel(int n, const float *__restrict__ x, float *__restrict__ y)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[i] += x[i];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(y + i, x[i]);
 }
 
 // ---- the walk's small launches, batched: job lists travel as kernel arguments (no table upload, nothing allocated) ----
+// Everything a walk adds into the SHARED gradient buffers (grad_flat, grad_cond) is an atomicAdd: two walks -- the two levels' radiance parts, the
+// two deformation parts -- may run at once on two streams (ops.RenderRaysFn.backward).
 // (1) 16-byte aligned copies of the weight sub-matrices the data-gradient GEMMs stream by LDS-DMA: all of a walk's copies in ONE launch
 //     in front of it (the walk is run once dry to collect them); (2) the per-frame-constant columns and (3) the bias gradients that went
 //     through scratch: their results are read by nothing inside the walk, so they are deferred to one launch each at its end.
@@ -1181,7 +1183,7 @@ __global__ void __launch_bounds__(256) const_cols_batch_kernel(ConstBatch b)
     for (int r = threadIdx.x; r < j.rows; r += blockDim.x) {
         const float g = j.db[r];
         s += j.W[(long)r * j.ld + j.col0 + k] * g;
-        j.dW[(long)r * j.ld + j.col0 + k] += g * ck;
+        atomicAdd(j.dW + (long)r * j.ld + j.col0 + k, g * ck);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -1194,7 +1196,7 @@ __global__ void __launch_bounds__(256) const_cols_batch_kernel(ConstBatch b)
 __global__ void __launch_bounds__(256) axpy_batch_kernel(AxpyBatch b)
 {
     const AxpyJob &j = b.j[blockIdx.y];
-    for (int i = threadIdx.x; i < j.n; i += blockDim.x) j.y[i] += j.x[i];
+    for (int i = threadIdx.x; i < j.n; i += blockDim.x) atomicAdd(j.y + i, j.x[i]);
 }
 
 }  // namespace SAHS_NS

@@ -10,6 +10,7 @@ differentiated (the reference detaches it, train_utils.py:164).  The stand-alone
 volume_render_radiance_field (the radiance field), so the reference's own python driver can be run over them.
 """
 import ctypes
+import os
 
 import torch
 
@@ -402,22 +403,41 @@ def field_forward_split_save(packed, frame, level, mode, rays, xw, z=None, src=N
     return raw, act
 
 
-def field_backward_split(flat, frame, level, part, act, grad_flat, grad_cond, d_raw=None, xw_grad_in=None, arch="audio"):
+def field_backward_split(flat, frame, level, part, act, grad_flat, grad_cond, d_raw=None, xw_grad_in=None, arch="audio", full_act=False):
     """Backward of `part` (FIELD_DEFORM, FIELD_RADIANCE, or 3 = everything) of the field over activations saved by the forward of that
     part.  The seam is d loss / d (x', w), (P,8): FIELD_RADIANCE returns it (the only part that writes one), FIELD_DEFORM starts from
-    xw_grad_in, 3 adds xw_grad_in."""
+    xw_grad_in, 3 adds xw_grad_in.  full_act: `act` was saved by a WHOLE-network forward and only `part` of it is walked (a saved array of
+    column c starts at c * P in every save, so the part's arrays sit at their usual place behind the columns it does not use)."""
     flat, frame, act = _req(flat, "flat_params"), _req(frame, "frame"), _req(act, "act")
     d_raw, xw_grad_in = _req(d_raw, "d_raw"), _req(xw_grad_in, "xw_grad_in")
     P = act.shape[0]
-    if act.shape[1] != _fn("act_words_part", arch)[0](int(part)):
+    words = _fn("act_words_part", arch)[0]
+    act_ptr = _p(act)
+    if full_act and int(part) in (FIELD_DEFORM, FIELD_RADIANCE):
+        if act.shape[1] != words(3):
+            raise _lib.SahsError("field_backward_split(full_act): the activations were not saved by a whole-network forward")
+        col0 = 0 if int(part) == FIELD_DEFORM else words(3) - words(FIELD_RADIANCE)      # the radiance arrays are the table's tail
+        act_ptr = ctypes.c_void_p(act.data_ptr() + 4 * col0 * P)
+    elif act.shape[1] != words(int(part)):
         raise _lib.SahsError("field_backward_split: the activations were not saved by a forward of part %d" % part)
     if xw_grad_in is not None and xw_grad_in.numel() != P * 8:
         raise _lib.SahsError("field_backward_split: xw_grad_in must hold (P,8)")
     out = torch.empty(P, 8, dtype=torch.float32, device=act.device) if part == FIELD_RADIANCE else None
     ws = torch.empty(_fn("field_backward_workspace_words", arch)[0](P), dtype=torch.float32, device=act.device)
     f, name = _fn("field_backward_split", arch)
-    check(f(_p(flat), _p(frame), int(level), int(part), P, _p(act), _p(d_raw), _p(xw_grad_in), _p(out), _p(grad_flat), _p(grad_cond), _p(ws), _stream()), name)
+    check(f(_p(flat), _p(frame), int(level), int(part), P, act_ptr, _p(d_raw), _p(xw_grad_in), _p(out), _p(grad_flat), _p(grad_cond), _p(ws), _stream()), name)
     return out
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """One extra stream per device for the second of two independent backward walks (RenderRaysFn.backward)."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
 
 
 def route_xw_grad(src, g_fine, num_coarse):
@@ -641,6 +661,38 @@ class RenderRaysFn(torch.autograd.Function):
         grad_audio = torch.zeros_like(audio)
         c = lambda t: None if t is None else t.contiguous().float()
         N = rays.shape[0]
+        both_levels = loss_ops is not None or (any(g is not None for g in (g_rgb_f, g_disp_f, g_acc_f, g_depth_f, g_wbg)) and
+                                               any(g is not None for g in (g_rgb_c, g_disp_c, g_acc_c)))
+        if ctx.shared and nf > 0 and kept is not None and N <= RenderRaysFn.BLOCK_RAYS and both_levels and not os.environ.get("SAHS_BWD_ONE_STREAM"):
+            # The two levels' radiance walks are independent of each other, and so are the two deformation walks that follow them (coarse
+            # depths / new depths): each pair runs on two streams.  A walk is ~75 dependent GEMM launches whose fixed costs (ring fill, a
+            # K loop with one workgroup per CU, the atomic epilogue, ramp and tail: DESIGN.md section 7) leave most of the chip idle for
+            # part of every launch; the other stream's launches fill it.  Everything the walks add into grad_flat / grad_cond is atomic.
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            gb = lambda grads: [None if g is None else c(g) for g in grads]
+            lv_loss = lambda level: None if loss_ops is None else (loss_ops[level].contiguous(), l_tgt.contiguous(), l_msk.contiguous(), l_stats, gscale)
+            (raw1, act1), (raw0, act0) = kept[1], kept[0]
+            cc = lambda t: None if t is None else t.contiguous()
+            d_raw1 = composite_backward(raw1, cc(z_f), cc(rays), cc(noise_f), cc(bg), white, *gb((g_rgb_f, g_disp_f, g_acc_f, g_depth_f, g_wbg)), loss=lv_loss(1))
+            d_raw0 = composite_backward(raw0, cc(z_c), cc(rays), cc(noise_c), cc(bg), white, *gb((g_rgb_c, g_disp_c, g_acc_c, None, None)), loss=lv_loss(0))
+            grad_cond_side = torch.zeros_like(grad_cond)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                g_c0 = field_backward_split(flat, frame, 0, FIELD_RADIANCE, act0, grad_flat, grad_cond_side, d_raw=d_raw0.view(-1, 16), arch=ctx.arch, full_act=True)
+            g_f = field_backward_split(flat, frame, 1, FIELD_RADIANCE, act1, grad_flat, grad_cond, d_raw=d_raw1.view(-1, 16), arch=ctx.arch)
+            xwg_coarse, g_new = route_xw_grad(src, g_f, nc)
+            main.wait_stream(side)
+            xwg0 = g_c0 + xwg_coarse          # the seam gradient of the coarse samples: their own radiance walk's + the fine pass's share
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                field_backward_split(flat, frame, 0, FIELD_DEFORM, act0, grad_flat, grad_cond_side, xw_grad_in=xwg0, arch=ctx.arch, full_act=True)
+            field_backward_split(flat, frame, 1, FIELD_DEFORM, act_d, grad_flat, grad_cond, xw_grad_in=g_new, arch=ctx.arch)
+            main.wait_stream(side)
+            grad_cond += grad_cond_side
+            for t in (d_raw0, xwg0, grad_cond_side, act0, grad_flat, flat, frame):      # made on this stream, used on the side stream: the
+                t.record_stream(side)                                                     # allocator must not hand them out again before it is done
+            g_c0.record_stream(main)                                                      # (and the other way round)
+            N = 0                             # (the block loop below has nothing left to do)
         for s in range(0, N, RenderRaysFn.BLOCK_RAYS):
             e = min(N, s + RenderRaysFn.BLOCK_RAYS)
             sl = slice(s, e)
