@@ -200,7 +200,9 @@ class ProductRenderer:
             chain["frac_executed"] = rays_done * self.exec_flop_per_ray / (field_ms * 1e-3) / 1e12 / PEAK_TFLOPS["bf16"]
             chain["mixed_precision"] = ("deformation launches with split bf16 operands (three MFMAs per product) + low-precision radiance launches, all on the "
                                         "bf16 matrix pipe: frac_executed prices the issued MFMA work against its 2.5 PFLOP/s; the chain figures are NOT a kernel roofline")
-        rad = [r for r in recs if r["part"] == 2] or [r for r in recs if r["part"] == 0 and r["level"] == 1]
+        # the dominant dispatch = the LEVEL-1 radiance launch (all nc + nf sorted depths of a ray block); a split chain's level-0 launch
+        # (whole network, or radiance nets over the nc coarse depths) is a different, smaller launch and is not averaged into it
+        rad = [r for r in recs if r["part"] == 2 and r["level"] == 1] or [r for r in recs if r["part"] == 0 and r["level"] == 1]
         kname = {"fp32": "field_forward_f32_kernel<false, 2>", "bf16": "field_forward_bf16w_kernel<2>", "bf16x3": "field_radiance_bf16x3_kernel"}[self.precision_name]
         rms, rsm = sum(r["ms"] for r in rad), sum(r["samples"] for r in rad)
         part = 2 if rad and rad[0]["part"] == 2 else 0
@@ -326,13 +328,18 @@ def add_secondary_legs(result, pkg, dev, args):
     result["num_fine128"] = {"value": rec["value"], "unit": "rays/s", "ms_per_step": rec["ms_per_step"], "dtype": "f32",
                              "workload": rec["config"]["workload"], "roofline": rec["roofline"]}
     torch.cuda.empty_cache()
-    progress("train_T2048 leg")
-    result["train_T2048"] = train_leg(pkg, dev)
+    progress("train_T2048 leg (backward products in f32: the reference's arithmetic)")
+    result["train_T2048"] = train_leg(pkg, dev, backward="fp32")
+    progress("train_T2048_bf16x3 leg (the library's default: backward products as three bf16 MFMAs)")
+    result["train_T2048_bf16x3"] = train_leg(pkg, dev, backward="bf16x3")
 
 
-def train_leg(pkg, dev, rays=2048, steps=5, warmup=2):
+def train_leg(pkg, dev, rays=2048, steps=5, warmup=2, backward="fp32"):
     """BASELINE.json configs[4]: 2048 semantically-weighted rays, train mode (noise 0.1), forward + backward through the HIP autograd
-    op and the reference's loss recipe (train_stage_rays_auto.py:437-499); no optimiser step (not part of the path)."""
+    op and the reference's loss recipe (train_stage_rays_auto.py:437-499); no optimiser step (not part of the path).
+    backward: arithmetic of the backward's dense-layer products -- "fp32" = f32 MFMAs, the reference's precision (the entry named
+    train_T2048); "bf16x3" = split bf16 operands, three bf16 MFMAs per product (train_T2048_bf16x3, the library's default).  The forward is
+    the fp32 kernel in both."""
     W, Tr = pkg.weights, pkg.training
     cfg = pkg.default_config()
     model = pkg.AudioFaceModel(cfg).to(dev).load_flat(W.flatten_state_dict(W.hash_state_dict(**HDR))).train()
@@ -362,20 +369,47 @@ def train_leg(pkg, dev, rays=2048, steps=5, warmup=2):
         loss.backward()
         return loss
 
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    before = pkg.ops.backward_gemm_precision()
+    pkg.ops.backward_gemm_precision(backward)
+    try:
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        pkg.ops.backward_gemm_precision(before)
     assert bool(torch.isfinite(loss))
-    tflops = rays * 192 * FLOP_PER_SAMPLE["audio"] * 3 / dt / 1e12
+    return train_record(pkg, rays, dt, steps, backward)
+
+
+def train_record(pkg, rays, dt, steps, backward, nc=64, nf=64):
+    """The JSON entry of a training leg.  roofline.frac = the time the step's EXECUTED matrix work needs at each pipe's peak, summed over
+    the pipes, divided by the step time: forward launches (fp32 kernel: nc whole-network + nf deformation + (nc + nf) radiance evaluations
+    per ray, padded tiles as issued) on the f32 MFMA pipe; backward = two products per forward MAC (data gradient, weight gradient) on the
+    f32 pipe ("fp32") or as three bf16 MFMAs each on the bf16 pipe ("bf16x3").  frac_algorithmic is SURVEY.md section 8d's rule
+    (3 x forward GEMM FLOPs per training ray / fp32 peak) and is NOT a pipe roofline when the backward runs on the bf16 pipe."""
+    ex = lambda part: 2 * pkg.ops.executed_macs_per_sample("audio", pkg.ops.SAHS_F32, part)
+    fwd_exec = rays * (nc * ex(0) + nf * ex(1) + (nc + nf) * ex(2))                  # FLOPs issued by the saving forward launches
+    bwd_products = 2 * fwd_exec                                                        # dX and dW: one product each per forward MAC
+    f32_flops = fwd_exec + (bwd_products if backward == "fp32" else 0)
+    bf16_flops = 3 * bwd_products if backward == "bf16x3" else 0
+    t_f32, t_bf16 = f32_flops / (PEAK_TFLOPS["fp32"] * 1e12), bf16_flops / (PEAK_TFLOPS["bf16"] * 1e12)
+    alg = rays * (2 * nc + nf) * FLOP_PER_SAMPLE["audio"] * 3 / dt / 1e12
+    dtype = {"fp32": "f32", "bf16x3": "f32 forward + split-bf16 backward GEMMs (hi + lo operands, 3 bf16 MFMAs per product, f32 accumulate)"}[backward]
     return {"workload": "T%d: %d semantically-weighted rays, 64+128 evaluations/ray, train mode (noise 0.1), forward + loss recipe + backward"
-                        % (rays, rays), "ms_per_step": dt * 1e3, "value": rays / dt, "unit": "rays/s", "dtype": "f32", "steps": steps,
-            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": tflops / PEAK_TFLOPS["fp32"],
-                         "flop_rule": "3 x forward GEMM FLOPs per training ray (SURVEY.md section 8d)"}}
+                        % (rays, rays), "ms_per_step": dt * 1e3, "value": rays / dt, "unit": "rays/s", "dtype": dtype,
+            "backward_gemm_precision": backward, "steps": steps,
+            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "frac": (t_f32 + t_bf16) / dt,
+                         "what": "executed MFMA FLOPs per pipe / that pipe's peak, summed, / step time",
+                         "pipes": {"f32_mfma": {"executed_tflop": f32_flops / 1e12, "peak": PEAK_TFLOPS["fp32"], "ms_at_peak": t_f32 * 1e3},
+                                   "bf16_mfma": {"executed_tflop": bf16_flops / 1e12, "peak": PEAK_TFLOPS["bf16"], "ms_at_peak": t_bf16 * 1e3}},
+                         "achieved_algorithmic": alg, "peak_algorithmic": PEAK_TFLOPS["fp32"], "frac_algorithmic": alg / PEAK_TFLOPS["fp32"],
+                         "flop_rule_algorithmic": "3 x forward GEMM FLOPs per training ray (SURVEY.md section 8d) against the fp32 MFMA peak; "
+                                                  "a pipe roofline only for backward_gemm_precision fp32"}}
 
 
 def host_cores():
@@ -487,10 +521,15 @@ def add_baselines(result, out, rend, pkg, dev):
 def launch_children(gpus, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh processes (one per GPU) through torch.distributed.run and pass
     their output through.  The parent has made NO GPU call (nothing here touches torch.cuda), is never replaced by exec, and exits
-    with the children's status; rank 0's JSON line is the children's only stdout."""
+    with the children's status; rank 0's JSON line is the children's only stdout.
+    Wall-clock guard: a wedged rendezvous or collective must not end as "killed at the driver's limit, nothing written".  After
+    SAHS_BENCH_GUARD_S seconds (default 420) the parent terminates the children's process group (its own fresh children only), prints ONE
+    JSON line {"error": ..., "n_gpus": N} and exits non-zero."""
+    import signal
     import socket
     import subprocess
     import threading
+    guard_s = float(os.environ.get("SAHS_BENCH_GUARD_S", "420"))
     rc = 1
     for attempt in range(2):      # the rendezvous port is free when picked but not reserved: if the launcher then finds it taken, pick another, once
         with socket.socket() as sk:
@@ -498,9 +537,9 @@ def launch_children(gpus, argv):
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-        progress("no launcher in the environment: starting %d ranks: %s" % (gpus, " ".join(cmd)))
-        child = subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True, errors="replace")
-        port_taken = []
+        progress("no launcher in the environment: starting %d ranks (guard %.0f s): %s" % (gpus, guard_s, " ".join(cmd)))
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, errors="replace", start_new_session=True)      # own process group
+        port_taken, json_lines = [], []
 
         def relay():
             for line in child.stderr:
@@ -509,11 +548,43 @@ def launch_children(gpus, argv):
                     port_taken.append(line)
             sys.stderr.flush()
 
+        def relay_out():
+            for line in child.stdout:
+                sys.stdout.write(line)
+                sys.stdout.flush()
+                if line.lstrip().startswith("{"):
+                    json_lines.append(line)
+
         th = threading.Thread(target=relay, daemon=True)
         th.start()
-        rc = child.wait()
+        tho = threading.Thread(target=relay_out, daemon=True)
+        tho.start()
+        try:
+            rc = child.wait(timeout=guard_s)
+        except subprocess.TimeoutExpired:
+            for sig, grace in ((signal.SIGTERM, 15), (signal.SIGKILL, 15)):      # the group we started, by its exact id -- never a pattern
+                try:
+                    os.killpg(child.pid, sig)
+                except ProcessLookupError:
+                    break
+                try:
+                    child.wait(timeout=grace)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            th.join(timeout=5)
+            tho.join(timeout=5)
+            print(json.dumps({"error": "bench.py --gpus %d: the ranks did not finish within the %.0f s wall-clock guard (SAHS_BENCH_GUARD_S) and were "
+                                       "terminated: a wedged rendezvous or collective; rerun with NCCL_DEBUG=INFO, and SAHS_ALLGATHER_OUT_OF_PLACE=1 "
+                                       "selects the out-of-place all-gather" % (gpus, guard_s), "n_gpus": gpus}), flush=True)
+            return 124
         th.join(timeout=10)
+        tho.join(timeout=10)
         if rc == 0 or not port_taken:
+            if rc != 0 and not json_lines:      # a rank died (exception, collective timeout, watchdog abort): say so on stdout, as ONE JSON line
+                print(json.dumps({"error": "bench.py --gpus %d: the ranks exited with status %d before rank 0 printed its line (see stderr); "
+                                           "collective timeout SAHS_BENCH_DIST_TIMEOUT_S, fallback SAHS_ALLGATHER_OUT_OF_PLACE=1" % (gpus, rc),
+                                  "n_gpus": gpus}), flush=True)
             break
         progress("rendezvous port %d was taken by another process: retrying once on a new port" % port)
     return rc
@@ -568,8 +639,14 @@ def main(argv=None):
         torch.cuda.set_device(0 if one_gpu else local)
         dev = torch.device("cuda", 0 if one_gpu else local)
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group(backend, **({} if rehearsal else {"device_id": dev}))
+        # a short collective timeout: a rank that never arrives fails the others' rendezvous / collective with an exception (non-zero exit,
+        # relayed by launch_children) instead of hanging until the driver's limit
+        tmo = datetime.timedelta(seconds=float(os.environ.get("SAHS_BENCH_DIST_TIMEOUT_S", "120")))
+        dist.init_process_group(backend, timeout=tmo, **({} if rehearsal else {"device_id": dev}))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: the process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
 
     t_start = time.perf_counter()
     progress("headline")

@@ -497,15 +497,27 @@ long sahs_model_packed_words(int model, int precision)
     if (model == SAHS_MODEL_NERFACE_STATIC && precision == SAHS_BF16) return sahs_layout_packed_words_bf16_ns();
     return precision == SAHS_F32 ? kModels[model].packed_words_f32() : -1;
 }
+// SAHS_X3_DEFORM=f32 (read once): the split chains' deformation launches run on the fp32 kernel instead of the split-operand one (A/B aid)
+static bool x3_deform_on_f32()
+{
+    static const bool v = getenv("SAHS_X3_DEFORM") != nullptr && strcmp(getenv("SAHS_X3_DEFORM"), "f32") == 0;
+    return v;
+}
 long sahs_model_executed_macs_part(int model, int precision, int part)
 {
     if (model < 0 || model > 2 || precision < SAHS_F32 || precision > SAHS_BF16_Q || part < 0 || part > 2) return -1;
     if (precision == SAHS_BF16_Q || precision == SAHS_BF16_2W) precision = SAHS_BF16;      // A/B kernels: the same MFMA work
     if (precision == SAHS_BF16X3)       // fp32 deformation nets + three bf16 MFMAs per product of the radiance nets
-        return model != SAHS_MODEL_AUDIO ? -1 : 3 * sahs_layout_executed_macs(SAHS_BF16, part);      // three bf16 MFMAs per product, every net
+    {
+        if (model != SAHS_MODEL_AUDIO) return -1;
+        if (x3_deform_on_f32())       // the deformation launches are the fp32 kernel's then: price them as what is issued
+            return (part != 2 ? sahs_layout_executed_macs(SAHS_F32, 1) : 0) + (part != 1 ? 3 * sahs_layout_executed_macs(SAHS_BF16, 2) : 0);
+        return 3 * sahs_layout_executed_macs(SAHS_BF16, part);      // three bf16 MFMAs per product, every net
+    }
     if (model == SAHS_MODEL_NERFACE_STATIC && part != 0) return part == 2 ? sahs_layout_executed_macs_ns(precision == SAHS_F32 ? SAHS_F32 : SAHS_BF16, 0) : 0;
     if (model == SAHS_MODEL_NERFACE && precision == SAHS_BF16)      // mixed: split-operand deformation nets (3 MFMAs per product) + bf16 radiance nets
-        return (part != 2 ? 3 * sahs_layout_executed_macs_nf(SAHS_BF16, 1) : 0) + (part != 1 ? sahs_layout_executed_macs_nf(SAHS_BF16, 2) : 0);
+        return (part != 2 ? (x3_deform_on_f32() ? sahs_layout_executed_macs_nf(SAHS_F32, 1) : 3 * sahs_layout_executed_macs_nf(SAHS_BF16, 1)) : 0) +
+               (part != 1 ? sahs_layout_executed_macs_nf(SAHS_BF16, 2) : 0);
     return model == 0 ? sahs_layout_executed_macs(precision, part)
                       : (model == 1 ? sahs_layout_executed_macs_nf(precision, part) : sahs_layout_executed_macs_ns(precision, part));
 }
@@ -638,7 +650,7 @@ int sahs_model_field_forward_split(int model, const void *packed, const float *f
         // the deformation nets run on the split-operand pipe (field_bf16x3.hip; round 3 -- SAHS_X3_DEFORM=f32 in the environment keeps them
         // on the fp32 kernel, the A/B reference and the form round 2 shipped): SAHS_BF16X3 of the AudioFaceModel, and the mixed-precision
         // NeRFaceModel, whose radiance nets are plain bf16 anyway
-        static const bool x3_deform_f32 = getenv("SAHS_X3_DEFORM") != nullptr && strcmp(getenv("SAHS_X3_DEFORM"), "f32") == 0;
+        const bool x3_deform_f32 = x3_deform_on_f32();
         if (mode != 2 && !x3_deform_f32)
             e = probed(probe_kind(model, x3 ? precision : SAHS_BF16X3, level, 1), N * S, st, [&] {
                 return x3 ? sahs_field_deform_bf16x3_launch(pk16, frame, level, N * S, S, rays, ray_stride, z, xw, xw_row, xw_col0, num_cus(), st)

@@ -1239,7 +1239,9 @@ struct Bwd {
     void check() { if (!err) err = (int)hipGetLastError(); }
     void flush_copies()
     {
-        if (ncopy > 0 && ncopy <= MAX_COPY_JOBS) {
+        // more jobs than a batch holds would leave the heads' zero-padded weight copies unmade (head_copy only records): fail loudly
+        if (ncopy > MAX_COPY_JOBS) { if (!err) err = (int)hipErrorOutOfMemory; return; }
+        if (ncopy > 0) {
             copy2d_batch_kernel<<<dim3(16, ncopy), 256, 0, st>>>(copies, 0); check();
             copy2d_batch_kernel<<<dim3(16, ncopy), 256, 0, st>>>(copies, 1); check();
         }
@@ -1631,6 +1633,7 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
     b.dry = true;
     if (int e = walk()) return e;
     b.flush_copies();
+    if (b.err) return b.err;
     b.dry = false;
     return walk();
 }

@@ -58,3 +58,16 @@ class OracleRenderer:
 
 def make(args, world, rank):
     return OracleRenderer(args, world, rank)
+
+
+class SleepyRenderer(OracleRenderer):
+    """A rank that never comes back from its frame (a wedged collective, as far as the launcher can tell): bench.py's wall-clock guard must
+    end the run with an error line instead of waiting for the driver's limit (tests/test_distributed_gloo.py)."""
+
+    def frame(self):
+        import time
+        time.sleep(3600)
+
+
+def make_sleepy(args, world, rank):
+    return SleepyRenderer(args, world, rank)

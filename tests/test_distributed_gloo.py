@@ -88,7 +88,28 @@ def test_bench_main_self_launch_over_gloo(size):
     env["SAHS_BENCH_RENDERER"] = os.path.join(REPO, "tests", "gloo_bench_renderer.py") + ":does_not_exist"
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "4"],
                        env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode != 0 and "{" not in p.stdout
+    lines = [l for l in p.stdout.splitlines() if l.lstrip().startswith("{")]
+    assert p.returncode != 0 and len(lines) == 1 and "error" in json.loads(lines[0]) and json.loads(lines[0])["n_gpus"] == 2, p.stdout
+
+
+def test_bench_main_wall_clock_guard_ends_a_hung_run():
+    """A run whose ranks never finish (here: a renderer that sleeps; on hardware: a wedged rendezvous or RCCL collective) is ended by the
+    parent's wall-clock guard: the children's process group is terminated, ONE JSON line {"error", "n_gpus"} is printed, the exit status is
+    non-zero -- instead of being killed at the driver's limit with nothing written."""
+    import json
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SAHS_BENCH_BACKEND="gloo", SAHS_BENCH_RENDERER=os.path.join(REPO, "tests", "gloo_bench_renderer.py") + ":make_sleepy",
+               OMP_NUM_THREADS="2", SAHS_BENCH_GUARD_S="25")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "4"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 124 and time.time() - t0 < 120, (p.returncode, p.stderr[-2000:])
+    lines = [l for l in p.stdout.splitlines() if l.lstrip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    err = json.loads(lines[0])
+    assert err["n_gpus"] == 2 and "guard" in err["error"]
 
 
 def test_bench_refuses_a_mismatched_launcher():

@@ -565,3 +565,62 @@ def test_backward_gemms_bf16x3_vs_f32(arch, weights_mod):
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
     print(arch, "bf16x3 vs f32 backward GEMMs, worst |delta| / scale:", ", ".join("%s %.2e" % kv for kv in top))
     assert top[0][1] <= 1e-4, top
+
+
+@pytest.mark.parametrize("arch,with_loss", [("audio", False), ("audio", True), ("nerface", False)])
+def test_two_stream_backward_matches_one_stream(arch, with_loss, weights_mod, monkeypatch):
+    """The backward of a kept, shared training batch issues its independent walks pairwise on two streams (ops.RenderRaysFn.backward);
+    SAHS_BWD_ONE_STREAM=1 (read per call) selects the serial order.  Same forward, same upstream gradient (plain-gradient form and the
+    fused-loss form): every gradient must agree to the order of the float atomics -- a missing stream edge or a non-atomic add into the
+    shared gradient buffers would show as an error of the size of a whole walk's contribution."""
+    ops = pkg("ops")
+    dev = torch.device("cuda:0")
+    model_name = "audio" if arch == "audio" else "nerface"
+    fw = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 2.0, 30.0, model=model_name, hdr=(arch == "audio")), model=model_name)
+    gen = torch.Generator(device=dev).manual_seed(23)
+    N, nc, nf = 517, 64, 64
+    drv = torch.randn(16, 29, device=dev, generator=gen) if arch == "audio" else torch.randn(76, device=dev, generator=gen) * 0.5
+    cam = 0.8 if arch == "audio" else 0.5
+    pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [cam]]], 1).astype(np.float32)).to(dev)
+    near, far = (0.483771, 1.083771) if arch == "audio" else (0.2, 0.8)
+    rays = torch.zeros(N, 8, device=dev)
+    rays[:, 2] = cam
+    rays[:, 3:6] = torch.randn(N, 3, device=dev, generator=gen) * 0.15 + torch.tensor([0, 0, -1.0], device=dev)
+    rays[:, 6], rays[:, 7] = near, far
+    bg = torch.cat([torch.rand(N, 3, device=dev, generator=gen), torch.ones(N, 1, device=dev), torch.zeros(N, 11, device=dev)], 1)
+    t_rand, u = torch.rand(N, nc, device=dev, generator=gen), torch.rand(N, nf, device=dev, generator=gen)
+    noise_c, noise_f = torch.randn(N, nc, device=dev, generator=gen) * 0.1, torch.randn(N, nc + nf, device=dev, generator=gen) * 0.1
+    A = [torch.randn(N, 15, device=dev, generator=gen) for _ in range(2)]
+    target = torch.rand(N, 3, device=dev, generator=gen)
+    mask = torch.zeros(N, 12, device=dev)
+    mask.scatter_(1, torch.randint(0, 12, (N, 1), device=dev, generator=gen), 1.0)
+    cw = pkg("training").sample_prob_weights(dev)
+    res = {}
+    for one in (True, False):
+        if one:
+            monkeypatch.setenv("SAHS_BWD_ONE_STREAM", "1")
+        else:
+            monkeypatch.delenv("SAHS_BWD_ONE_STREAM", raising=False)
+        flat = torch.from_numpy(fw).to(dev).requires_grad_(True)
+        d = drv.clone().requires_grad_(True)
+        packed = ops.pack_weights(flat.detach(), arch=arch)
+        extra = (target, mask, cw) if with_loss else ()
+        outs = ops.RenderRaysFn.apply(flat, d, pose, rays, bg, t_rand, noise_c, u, noise_f, packed, nc, nf, False, False, arch, *extra)
+        if with_loss:
+            loss = outs[8]
+        else:
+            loss = (outs[0] * A[0]).sum() + (outs[3] * A[1]).sum() + 0.3 * outs[7].sum() + 0.2 * outs[6].sum() + 0.1 * outs[1].sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        res[one] = (flat.grad.clone(), d.grad.clone())
+    for k, nm in ((0, "parameters"), (1, "driving input")):
+        a, b = res[True][k], res[False][k]
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-6 * scale, (nm, float((a - b).abs().max()), scale)
+    off = 0
+    for name, shape in weights_mod.canonical_spec(model_name):      # per tensor: a small tensor must not hide behind the global scale
+        n = int(np.prod(shape))
+        ga, gb = res[True][0][off:off + n], res[False][0][off:off + n]
+        sc = float(ga.abs().max())
+        assert float((ga - gb).abs().max()) <= 2e-5 * sc + 1e-12, (name, float((ga - gb).abs().max()), sc)
+        off += n
