@@ -18,6 +18,7 @@
 #include "sahs_common.hpp"
 #include "sahs_layout.hpp"
 #include "bf16_pipe.hpp"
+#include "bf16x3_pipe.hpp"      // Blk, dense_x, dense_x_out, the conversion ticks and their epilogue policies
 
 #if SAHS_MODEL == 2
 #error "field_bf16x3.hip: the model without deformation nets has no use for it (its whole net is the plain-bf16 radiance kernel)"
@@ -27,270 +28,6 @@
 
 namespace SAHS_NS {
 namespace hx3 {
-using namespace hb;      // the bf16 layer program of sahs_layout.hpp (layers, blocks, bias offsets); offsets of the doubled stream derived below
-using namespace bfp;     // vector types, hand-issued LDS reads + retiring waits, bias helpers, the LDS-DMA chunk context (bf16_pipe.hpp)
-
-struct Blk { u32x4 s[2]; u32x4 l[2]; };            // 32 features of this lane's sample: hi (s) and lo (l) bf16x8 fragments per k-step (as dwords)
-
-constexpr int X_THREADS = 256;
-constexpr int X_PTS_PER_WAVE = 32;
-constexpr int X_PTS_PER_WG = (X_THREADS / WAVE) * X_PTS_PER_WAVE;     // 128
-constexpr int LDS_BUF_BYTES = CHUNK_HW_MAX * 2;                       // 64 KB each, two of them
-constexpr int LDS_BIAS_BYTE_OFF = 2 * LDS_BUF_BYTES;
-constexpr int LDS_STASH_BYTE_OFF = LDS_BIAS_BYTE_OFF + ((BIAS_FLOATS + 3) / 4) * 16;
-constexpr int STASH_FLOATS = 8;                                       // per sample: x'[3], w[2] (+pad)
-constexpr int LDS_BYTES = LDS_STASH_BYTE_OFF + X_PTS_PER_WG * STASH_FLOATS * 4;
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-constexpr int AP = 4;                                                  // k-steps whose A fragments (hi and lo) are in flight ahead of their MFMAs
-constexpr int PIECE_HW = X_THREADS * 8;                                // one LDS-DMA piece: 4 KB = 2048 halfwords (1 KB per wave)
-constexpr int DMA_PIECES = LDS_BUF_BYTES / (X_THREADS * 16);           // 16
-constexpr int FRAG_BYTES = 1024;                                       // one fragment of 64 lanes x 8 halfwords
-constexpr int STEP_BYTES = 2 * FRAG_BYTES;                             // hi + lo
-// chunking of the doubled stream: a k-step of a tile is 2 KB, a chunk at most 64 KB
-constexpr int pick_GX(int KB32, int NT32)
-{
-    int g = (CHUNK_HW_MAX / 2) / (KB32 * 1024);
-    if (g < 1) g = 1;
-    if (g > NT32) g = NT32;
-    while (NT32 % g) --g;
-    return g;
-}
-constexpr long STREAM_HWX = 2 * STREAM_HW;                             // halfwords per level; layer i starts at 2 * kProgH.layer[i].stream_off
-static_assert(11 * 2048 * 2 <= LDS_BUF_BYTES, "one tile of the widest layer (11 k-blocks) must fit a buffer");
-
-#ifdef SAHS_X3_NODMA            // timing-only experiments (tools/ablate.py x3*): results wrong by construction
-constexpr bool kNoDma = true;
-#else
-constexpr bool kNoDma = false;
-#endif
-#ifdef SAHS_X3_NOBARRIER
-constexpr bool kNoBarrier = true;
-#else
-constexpr bool kNoBarrier = false;
-#endif
-typedef PipeCtx<X_THREADS, LDS_BUF_BYTES, LDS_BIAS_BYTE_OFF, kNoDma, kNoBarrier> Ctx;
-
-// hi/lo split of a pair of fp32 values: hi = bf16 pair (RNE), lo = bf16 pair of the remainders
-__device__ __forceinline__ uint32_t cvt_pair(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2)); }
-__device__ __forceinline__ void split_pair(float a, float b, uint32_t &hi, uint32_t &lo)
-{
-    hi = cvt_pair(a, b);
-    lo = cvt_pair(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u));
-}
-
-// ---- activation + hi/lo conversion of a finished accumulator tile, software-pipelined (field_bf16w.hip: pack_tick) -------------------
-// 16 values per lane and tile.  tick T:  A(T)    m = v_{T,T+1} * slope              (leaky only, T even)
-//                                        B(T-1)  r = max(v, m) | v
-//                                        C(T-2)  hi dword = cvt_pk(r_{T-3}, r_{T-2})                       when T-2 is odd
-//                                        D(T-3)  e = r - float(hi) for both values of the pair              when T-3 is odd
-//                                        E(T-4)  lo dword = cvt_pk(e0, e1)                                  when T-4 is odd
-struct PackState { f32x2 m2[2]; float r[4]; uint32_t hi[2]; float e[2][2]; };
-constexpr int NV = 16;
-constexpr int PACK_TICKS = NV + 5;
-template <int T>
-__device__ __forceinline__ void pack_tick(const f32x16 &acc, Blk &o, float slope, PackState &ps)
-{
-    if constexpr (T >= 0 && T < NV && !(T & 1)) {           // A(T), T even: both values of the pair
-        constexpr int P = T >> 1;
-        if (slope != 1.0f) ps.m2[P & 1] = f32x2{acc[2 * P], acc[2 * P + 1]} * f32x2{slope, slope};
-    }
-    if constexpr (T - 1 >= 0 && T - 1 < NV) {               // B(T-1)
-        constexpr int U = T - 1, P = U >> 1, e = U & 1;
-        const float v = acc[2 * P + e];
-        ps.r[U & 3] = slope == 1.0f ? v : fmaxf(v, ps.m2[P & 1][e]);
-    }
-    if constexpr (T - 2 >= 1 && T - 2 < NV && ((T - 2) & 1)) {    // C(T-2): the pair (U-1, U) is complete -> hi
-        constexpr int U = T - 2, P = U >> 1, s = P >> 2, jp = P & 3;
-        ps.hi[P & 1] = cvt_pair(ps.r[(U - 1) & 3], ps.r[U & 3]);
-        o.s[s][jp] = ps.hi[P & 1];
-    }
-    if constexpr (T - 3 >= 1 && T - 3 < NV && ((T - 3) & 1)) {    // D(T-3): remainders (r[U-1], r[U] are still theirs: B has since
-        constexpr int U = T - 3, P = U >> 1;                      //          written r[(U+1)&3] and r[(U+2)&3] only)
-        ps.e[P & 1][0] = ps.r[(U - 1) & 3] - __builtin_bit_cast(float, ps.hi[P & 1] << 16);
-        ps.e[P & 1][1] = ps.r[U & 3] - __builtin_bit_cast(float, ps.hi[P & 1] & 0xffff0000u);
-    }
-    if constexpr (T - 4 >= 1 && T - 4 < NV && ((T - 4) & 1)) {    // E(T-4): lo
-        constexpr int U = T - 4, P = U >> 1, s = P >> 2, jp = P & 3;
-        o.l[s][jp] = cvt_pair(ps.e[P & 1][0], ps.e[P & 1][1]);
-    }
-}
-template <int LO, int HI>
-__device__ __forceinline__ void pack_ticks(const f32x16 &acc, Blk &o, float slope, PackState &ps)
-{
-    [&]<int... Is>(std::integer_sequence<int, Is...>) { (pack_tick<LO + Is>(acc, o, slope, ps), ...); }(std::make_integer_sequence<int, HI - LO>{});
-}
-
-// LGKM bookkeeping as in field_bf16w.hip (Sched), with TWO A reads (hi, lo) per k-step: step I issues [wait] [3 MFMAs] [bias batch of the
-// next tile: 4 reads, when I starts a tile that has a successor] [A reads of step I+AP: hi then lo]; the wait of step I allows exactly
-// the reads issued after A_lo(I).
-template <int STEPS, int TOTAL, int NT32, int T0>
-struct Sched {
-    static constexpr bool bias_at(int s) { return s >= 0 && s < TOTAL && (s % STEPS == 0) && (T0 + s / STEPS + 1 < NT32); }
-    static constexpr bool aread_at(int s) { return s >= 0 && s + AP < TOTAL; }
-    static constexpr int cnt(int I)
-    {
-        int n = 0, lo = 0;
-        if (I < AP) n += 2 * ((AP < TOTAL ? AP : TOTAL) - 1 - I);   // read in the prologue: the later prologue reads, then steps 0..I-1
-        else lo = I - AP + 1;                                        // read at the END of step I-AP (after that step's bias batch)
-        for (int s = lo; s < I; ++s) n += (aread_at(s) ? 2 : 0) + (bias_at(s) ? 4 : 0);
-        return n;
-    }
-    static constexpr int max_cnt()
-    {
-        int m = 0;
-        for (int i = 0; i < TOTAL; ++i) m = cnt(i) > m ? cnt(i) : m;
-        return m;
-    }
-};
-
-struct St {
-    f32x16 acc[2];       // two accumulator sets: tile t accumulates into one while tile t-1 is converted from the other
-    PackState ps;
-};
-
-// hidden layer: NT32 output tiles of 32 rows.  The layer's last tile stays in st.acc[1]; the NEXT layer converts it (PEND) into
-// in0[K0-1] with activation slope pslope under its own first MFMAs, before the step that first reads that block.
-template <int K0, int K1, int K2, int NT32, int NEXT_HW, bool PEND>
-__device__ __forceinline__ void dense_x(Ctx &cx, St &st, Blk *in0, const Blk *in1, const Blk *in2, Blk *out, int bias_off, float slope, float pslope)
-{
-    constexpr int KB = K0 + K1 + K2;
-    constexpr int G = pick_GX(KB, NT32);
-    constexpr int STEPS = KB * 2, TOTAL = G * STEPS, NCH = NT32 / G;
-    static_assert(NT32 % 2 == 0, "the last tile of a layer must land in accumulator set 1");
-    static_assert(TOTAL * STEP_BYTES <= LDS_BUF_BYTES, "chunk does not fit its buffer");
-    const uint32_t baddr = cx.bias_addr + 4u * (uint32_t)bias_off;
-    f32x4 braw[2][4];
-    bias_read<0>(braw[0], baddr);
-
-    auto chunk = [&]<int C>() {
-        constexpr int T0 = C * G;
-        constexpr int nhw = (C + 1 < NCH) ? G * KB * 2048 : NEXT_HW;
-        constexpr int npieces = (nhw + PIECE_HW - 1) / PIECE_HW;
-        constexpr int PSTEP = (TOTAL * 3 / 4) / (npieces > 0 ? npieces : 1) > 0 ? (TOTAL * 3 / 4) / (npieces > 0 ? npieces : 1) : 1;
-        using S = Sched<STEPS, TOTAL, NT32, T0>;
-        static_assert(S::max_cnt() <= 15, "lgkmcnt is a 4-bit counter");
-        cx.begin_chunk(nhw);
-        const uint32_t abase = cx.cur_addr();
-        u32x4 ah[AP], al[AP];
-        [&]<int... Is>(std::integer_sequence<int, Is...>) {
-            ((lds_read16<Is * STEP_BYTES>(ah[Is], abase), lds_read16<Is * STEP_BYTES + FRAG_BYTES>(al[Is], abase)), ...);
-        }(std::make_integer_sequence<int, (AP < TOTAL ? AP : TOTAL)>{});
-        fence();
-        auto step = [&]<int I>() {
-            constexpr int g = I / STEPS, k = I % STEPS, b = k >> 1, st_ = k & 1, t = T0 + g, set = t & 1;
-            const Blk &x = (b < K0) ? in0[b] : ((b < K0 + K1) ? in1[b - K0] : in2[b - K0 - K1]);
-            // retires A_hi(I), A_lo(I) and, at a tile's first step, the tile's bias batch (bf16_pipe.hpp: wait_retire)
-            if constexpr (k == 0) wait_retire<S::cnt(I)>(ah[I % AP], al[I % AP], braw[set]);
-            else wait_retire<S::cnt(I)>(ah[I % AP], al[I % AP]);
-            fence();
-            f32x16 cb;
-            if constexpr (k == 0) cb = bias_as_c(braw[set]);
-            // this step's share of the conversion ticks, dealt over its THREE MFMA gaps (a gap hides ~6 VALU instructions, not more):
-            // the finished tile t-1 -> out[t-1] over steps 1..STEPS-1, or the previous layer's last tile -> in0[K0-1] over steps 1..2K0-3
-            auto ticks = [&]<int J>() {
-                if constexpr (t > 0 && k >= 1) {
-                    constexpr int NSLOT = 3 * (STEPS - 1), slot = 3 * (k - 1) + J;
-                    constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
-                    if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[set ^ 1], out[t - 1], slope, st.ps);
-                } else if constexpr (PEND && t == 0 && k >= 1 && k <= 2 * K0 - 3) {
-                    constexpr int NSLOT = 3 * (2 * K0 - 3), slot = 3 * (k - 1) + J;
-                    constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
-                    if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[1], in0[K0 - 1], pslope, st.ps);
-                }
-            };
-            // W x ~= W_hi x_hi + W_hi x_lo + W_lo x_hi on ONE accumulator: back-to-back dependent MFMAs of this shape run at the pipe's rate
-            // (three separate accumulation chains were measured: 59.6 against 56.8 ms per fine launch -- slower, not faster)
-            if constexpr (k == 0) st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.s[st_]), cb, 0, 0, 0);
-            else st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.s[st_]), st.acc[set], 0, 0, 0);
-            fence();
-            if constexpr (S::bias_at(I)) bias_read<128 * (t + 1)>(braw[set ^ 1], baddr);
-            ticks.template operator()<0>();
-            fence();
-            st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.l[st_]), st.acc[set], 0, 0, 0);
-            fence();
-            ticks.template operator()<1>();
-            fence();
-            st.acc[set] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(al[I % AP]), frag(x.s[st_]), st.acc[set], 0, 0, 0);
-            fence();
-#ifndef SAHS_X3_NOAREAD
-            if constexpr (S::aread_at(I)) {
-                lds_read16<(I + AP) * STEP_BYTES>(ah[I % AP], abase);
-                lds_read16<(I + AP) * STEP_BYTES + FRAG_BYTES>(al[I % AP], abase);
-            }
-#endif
-            if constexpr (I % PSTEP == 0 && I / PSTEP < npieces) cx.issue_piece(I / PSTEP);
-            ticks.template operator()<2>();
-            fence();
-        };
-        [&]<int... Is>(std::integer_sequence<int, Is...>) { (step.template operator()<Is>(), ...); }(std::make_integer_sequence<int, TOTAL>{});
-        [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
-            ((Ps >= (TOTAL + PSTEP - 1) / PSTEP && Ps < npieces ? cx.issue_piece(Ps) : (void)0), ...);
-        }(std::make_integer_sequence<int, DMA_PIECES>{});
-        cx.end_chunk();
-    };
-    [&]<int... Cs>(std::integer_sequence<int, Cs...>) { (chunk.template operator()<Cs>(), ...); }(std::make_integer_sequence<int, NCH>{});
-}
-
-// 16-row output layer (ALPHA -> RGB -> SEG into one tile) accumulated in fp32: first = start from the bias, else from the running tile.
-template <int K0, int NEXT_HW>
-__device__ __forceinline__ void dense_x_out(Ctx &cx, St &st, Blk *in0, f32x16 &acc, int bias_off, bool first, float pslope)
-{
-    constexpr int TOTAL = K0 * 2;
-    constexpr int npieces = (NEXT_HW + PIECE_HW - 1) / PIECE_HW;
-    static_assert(TOTAL * STEP_BYTES <= LDS_BUF_BYTES, "chunk does not fit its buffer");
-    cx.begin_chunk(NEXT_HW);
-    const uint32_t abase = cx.cur_addr();
-    if (first) {       // rows 0..15 of the 32-row tile carry the layer's bias (registers 0..7), rows 16..31 are unused
-        const uint32_t baddr = cx.bias_addr + 4u * (uint32_t)bias_off;
-        f32x4 t0, t1;
-        lds_read16<0>(t0, baddr);
-        lds_read16<32>(t1, baddr);
-        wait_retire<0>(t0, t1);
-        fence();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { acc[r] = t0[r]; acc[4 + r] = t1[r]; }
-#pragma unroll
-        for (int r = 8; r < 16; ++r) acc[r] = 0.0f;
-    }
-    u32x4 ah[AP], al[AP];
-    [&]<int... Is>(std::integer_sequence<int, Is...>) {
-        ((lds_read16<Is * STEP_BYTES>(ah[Is], abase), lds_read16<Is * STEP_BYTES + FRAG_BYTES>(al[Is], abase)), ...);
-    }(std::make_integer_sequence<int, (AP < TOTAL ? AP : TOTAL)>{});
-    fence();
-    auto step = [&]<int I>() {
-        wait_retire<2 * ((TOTAL - 1 - I) < (AP - 1) ? (TOTAL - 1 - I) : (AP - 1))>(ah[I % AP], al[I % AP]);
-        fence();
-        const Blk &x = in0[I >> 1];
-        auto ticks = [&]<int J>() {      // the previous layer's last tile -> in0[K0-1], before step 2 (K0 - 1) reads it
-            if constexpr (I >= 1 && I <= 2 * K0 - 3) {
-                constexpr int NSLOT = 3 * (2 * K0 - 3), slot = 3 * (I - 1) + J;
-                constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
-                if constexpr (hi > lo) pack_ticks<lo, hi>(st.acc[1], in0[K0 - 1], pslope, st.ps);
-            }
-        };
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.s[I & 1]), acc, 0, 0, 0);
-        fence();
-        ticks.template operator()<0>();
-        fence();
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(ah[I % AP]), frag(x.l[I & 1]), acc, 0, 0, 0);
-        fence();
-        ticks.template operator()<1>();
-        fence();
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(al[I % AP]), frag(x.s[I & 1]), acc, 0, 0, 0);
-        fence();
-        if constexpr (I + AP < TOTAL) {
-            lds_read16<(I + AP) * STEP_BYTES>(ah[I % AP], abase);
-            lds_read16<(I + AP) * STEP_BYTES + FRAG_BYTES>(al[I % AP], abase);
-        }
-        if constexpr (I < npieces) cx.issue_piece(I);
-        ticks.template operator()<2>();
-        fence();
-    };
-    [&]<int... Is>(std::integer_sequence<int, Is...>) { (step.template operator()<Is>(), ...); }(std::make_integer_sequence<int, TOTAL>{});
-    [&]<int... Ps>(std::integer_sequence<int, Ps...>) { ((Ps >= TOTAL && Ps < npieces ? cx.issue_piece(Ps) : (void)0), ...); }(
-        std::make_integer_sequence<int, DMA_PIECES>{});
-    cx.end_chunk();
-}
 
 // ---- positional encoding (v_sin_f32 on an fp32 revolution count reduced exactly: the value keeps ~fp32 accuracy, then hi/lo split) ------
 struct PeSlot { float scale; float phase; int axis; int kind; };   // kind: 0 zero pad, 1 raw input, 2 sinusoid
@@ -446,25 +183,25 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
                 const float xp[3] = {stash[0], stash[1], stash[2]}, amb[3] = {stash[3], stash[4], 0.0f};
                 pe_blocks_x<3, 10, 2>(xp, h, in_tr);
                 pe_blocks_x<2, 4, 1>(amb, h, in_tr + 2);
-                dense_x<2, 1, 0, 8, CHX(H_T1), false>(cx, st, in_tr, in_tr + 2, nullptr, A, Ly[H_T0].bias_off, 0.01f, 1.0f);
+                dense_x<2, 1, 0, 8, CHX(H_T1), false>(cx, st, in_tr, in_tr + 2, nullptr, A, Ly[H_T0].bias_off, FwdAct{0.01f}, FwdAct{1.0f});
             }
-            dense_x<8, 0, 0, 8, CHX(H_T2), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T1].bias_off, 0.01f, 0.01f);
-            dense_x<8, 0, 0, 8, CHX(H_T3), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T2].bias_off, 0.01f, 0.01f);
+            dense_x<8, 0, 0, 8, CHX(H_T2), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T1].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
+            dense_x<8, 0, 0, 8, CHX(H_T3), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T2].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
             {   // the re-injected encoding [PE(x') | PE(w)] is rebuilt at the skip layer instead of staying live
                 Blk in_tr[3];
                 const float xp[3] = {stash[0], stash[1], stash[2]}, amb[3] = {stash[3], stash[4], 0.0f};
                 pe_blocks_x<3, 10, 2>(xp, h, in_tr);
                 pe_blocks_x<2, 4, 1>(amb, h, in_tr + 2);
-                dense_x<8, 2, 1, 8, CHX(H_T4), true>(cx, st, A, in_tr, in_tr + 2, B, Ly[H_T3].bias_off, 0.01f, 0.01f);
+                dense_x<8, 2, 1, 8, CHX(H_T4), true>(cx, st, A, in_tr, in_tr + 2, B, Ly[H_T3].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
             }
 #pragma unroll 1
             for (int j = 0; j < 2; ++j) {     // T4, T5 | T6, T7 (identical shapes: one copy of the code, run twice)
-                dense_x<8, 0, 0, 8, CHX(H_T5), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T4].bias_off + 512 * j, 0.01f, 0.01f);
-                dense_x<8, 0, 0, 8, CHX(H_T5), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T4].bias_off + 512 * j + 256, 0.01f, 0.01f);
+                dense_x<8, 0, 0, 8, CHX(H_T5), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T4].bias_off + 512 * j, FwdAct{0.01f}, FwdAct{0.01f});
+                dense_x<8, 0, 0, 8, CHX(H_T5), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T4].bias_off + 512 * j + 256, FwdAct{0.01f}, FwdAct{0.01f});
             }
-            dense_x<8, 0, 0, 8, CHX(H_ALPHA), true>(cx, st, B, nullptr, nullptr, A, Ly[H_FEAT].bias_off, 1.0f, 0.01f);
+            dense_x<8, 0, 0, 8, CHX(H_ALPHA), true>(cx, st, B, nullptr, nullptr, A, Ly[H_FEAT].bias_off, FwdAct{1.0f}, FwdAct{0.01f});
         }
-        dense_x_out<8, CHX(H_D0)>(cx, st, A, fin, Ly[H_ALPHA].bias_off, true, 1.0f);
+        dense_x_out<8, CHX(H_D0)>(cx, st, A, fin, Ly[H_ALPHA].bias_off, true, FwdAct{1.0f});
         {   // colour branch
             Blk in_d[2];
             {
@@ -474,19 +211,19 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
                 grid_block_x(grid, stash[0], stash[1], stash[2], h, in_d[1]);
             }
             Blk c[4], cn[4];
-            dense_x<8, 1, 1, 4, CHX(H_D1), false>(cx, st, A, in_d, in_d + 1, c, Ly[H_D0].bias_off, 0.01f, 1.0f);
-            dense_x<4, 0, 0, 4, CHX(H_D1), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D1].bias_off, 0.01f, 0.01f);
-            dense_x<4, 0, 0, 4, CHX(H_D1), true>(cx, st, cn, nullptr, nullptr, c, Ly[H_D1].bias_off + 128, 0.01f, 0.01f);
-            dense_x<4, 0, 0, 4, CHX(H_RGB), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D3].bias_off, 0.01f, 0.01f);
-            dense_x_out<4, CHX(H_S0)>(cx, st, cn, fin, 0, false, 0.01f);
+            dense_x<8, 1, 1, 4, CHX(H_D1), false>(cx, st, A, in_d, in_d + 1, c, Ly[H_D0].bias_off, FwdAct{0.01f}, FwdAct{1.0f});
+            dense_x<4, 0, 0, 4, CHX(H_D1), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D1].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
+            dense_x<4, 0, 0, 4, CHX(H_D1), true>(cx, st, cn, nullptr, nullptr, c, Ly[H_D1].bias_off + 128, FwdAct{0.01f}, FwdAct{0.01f});
+            dense_x<4, 0, 0, 4, CHX(H_RGB), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D3].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
+            dense_x_out<4, CHX(H_S0)>(cx, st, cn, fin, 0, false, FwdAct{0.01f});
         }
         {   // seg branch
             Blk s[4], sn[4];
-            dense_x<8, 0, 0, 4, CHX(H_S1), false>(cx, st, A, nullptr, nullptr, s, Ly[H_S0].bias_off, 0.01f, 1.0f);
-            dense_x<4, 0, 0, 4, CHX(H_S1), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S1].bias_off, 0.01f, 0.01f);
-            dense_x<4, 0, 0, 4, CHX(H_S1), true>(cx, st, sn, nullptr, nullptr, s, Ly[H_S1].bias_off + 128, 0.01f, 0.01f);
-            dense_x<4, 0, 0, 4, CHX(H_SEG), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S3].bias_off, 0.01f, 0.01f);
-            dense_x_out<4, CHX(H_T0)>(cx, st, sn, fin, 0, false, 0.01f);
+            dense_x<8, 0, 0, 4, CHX(H_S1), false>(cx, st, A, nullptr, nullptr, s, Ly[H_S0].bias_off, FwdAct{0.01f}, FwdAct{1.0f});
+            dense_x<4, 0, 0, 4, CHX(H_S1), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S1].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
+            dense_x<4, 0, 0, 4, CHX(H_S1), true>(cx, st, sn, nullptr, nullptr, s, Ly[H_S1].bias_off + 128, FwdAct{0.01f}, FwdAct{0.01f});
+            dense_x<4, 0, 0, 4, CHX(H_SEG), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S3].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
+            dense_x_out<4, CHX(H_T0)>(cx, st, sn, fin, 0, false, FwdAct{0.01f});
         }
         if (p_raw < P) {   // rows 4h..4h+3 and 8+4h..8+4h+3 of [rgb3 | seg12 | sigma]
             *reinterpret_cast<f32x4 *>(raw + p_raw * D_RAW + 4 * h) = f32x4{fin[0], fin[1], fin[2], fin[3]};
@@ -552,28 +289,28 @@ field_deform_bf16x3_kernel(const float *__restrict__ packed, const float *__rest
         pe_blocks_x<3, L_XYZ, KX32>(x, h, pe_x);
         {   // warp field (models.py:296-305; layers alternate between two register sets)
             Blk A[4], B[4];
-            dense_x<KX32, 0, 0, 4, CHX(H_W1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_W0].bias_off, 0.0f, 0.0f);
-            dense_x<4, 0, 0, 4, CHX(H_W1), true>(cx, st, A, nullptr, nullptr, B, Ly[H_W1].bias_off, 0.0f, 0.0f);
-            dense_x<4, 0, 0, 4, CHX(H_W1), true>(cx, st, B, nullptr, nullptr, A, Ly[H_W1].bias_off + 128, 0.0f, 0.0f);
-            dense_x<4, 0, 0, 4, CHX(H_W4), true>(cx, st, A, nullptr, nullptr, B, Ly[H_W3].bias_off, 0.0f, 0.0f);
-            dense_x<4, KX32, 0, 4, CHX(H_W5), true>(cx, st, B, pe_x, nullptr, A, Ly[H_W4].bias_off, 0.0f, 0.0f);
-            dense_x<4, 0, 0, 4, CHX(H_WF), true>(cx, st, A, nullptr, nullptr, B, Ly[H_W5].bias_off, 0.0f, 0.0f);
+            dense_x<KX32, 0, 0, 4, CHX(H_W1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_W0].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
+            dense_x<4, 0, 0, 4, CHX(H_W1), true>(cx, st, A, nullptr, nullptr, B, Ly[H_W1].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
+            dense_x<4, 0, 0, 4, CHX(H_W1), true>(cx, st, B, nullptr, nullptr, A, Ly[H_W1].bias_off + 128, FwdAct{0.0f}, FwdAct{0.0f});
+            dense_x<4, 0, 0, 4, CHX(H_W4), true>(cx, st, A, nullptr, nullptr, B, Ly[H_W3].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
+            dense_x<4, KX32, 0, 4, CHX(H_W5), true>(cx, st, B, pe_x, nullptr, A, Ly[H_W4].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
+            dense_x<4, 0, 0, 4, CHX(H_WF), true>(cx, st, A, nullptr, nullptr, B, Ly[H_W5].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
             f32x16 o;
-            dense_x_out<4, CHX(H_H0)>(cx, st, B, o, Ly[H_WF].bias_off, true, 0.0f);
+            dense_x_out<4, CHX(H_H0)>(cx, st, B, o, Ly[H_WF].bias_off, true, FwdAct{0.0f});
             xp[0] = x[0] + tanhf(o[0]);            // models.py:305 (rows 0..2 live in lane half 0)
             xp[1] = x[1] + tanhf(o[1]);
             xp[2] = x[2] + tanhf(o[2]);
         }
         {   // hyper sheet (models.py:307-314)
             Blk A[2], B[2];
-            dense_x<KX32, 0, 0, 2, CHX(H_H1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_H0].bias_off, 0.0f, 0.0f);
-            dense_x<2, 0, 0, 2, CHX(H_H1), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H1].bias_off, 0.0f, 0.0f);
-            dense_x<2, 0, 0, 2, CHX(H_H1), true>(cx, st, B, nullptr, nullptr, A, Ly[H_H1].bias_off + 64, 0.0f, 0.0f);
-            dense_x<2, 0, 0, 2, CHX(H_H4), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H3].bias_off, 0.0f, 0.0f);
-            dense_x<2, KX32, 0, 2, CHX(H_H5), true>(cx, st, B, pe_x, nullptr, A, Ly[H_H4].bias_off, 0.0f, 0.0f);
-            dense_x<2, 0, 0, 2, CHX(H_HF), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H5].bias_off, 0.0f, 0.0f);
+            dense_x<KX32, 0, 0, 2, CHX(H_H1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_H0].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
+            dense_x<2, 0, 0, 2, CHX(H_H1), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H1].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
+            dense_x<2, 0, 0, 2, CHX(H_H1), true>(cx, st, B, nullptr, nullptr, A, Ly[H_H1].bias_off + 64, FwdAct{0.0f}, FwdAct{0.0f});
+            dense_x<2, 0, 0, 2, CHX(H_H4), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H3].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
+            dense_x<2, KX32, 0, 2, CHX(H_H5), true>(cx, st, B, pe_x, nullptr, A, Ly[H_H4].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
+            dense_x<2, 0, 0, 2, CHX(H_HF), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H5].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
             f32x16 o;
-            dense_x_out<2, CHX(H_W0)>(cx, st, B, o, Ly[H_HF].bias_off, true, 0.0f);
+            dense_x_out<2, CHX(H_W0)>(cx, st, B, o, Ly[H_HF].bias_off, true, FwdAct{0.0f});
             amb[0] = o[0];
             amb[1] = AMB_DIM > 1 ? o[1] : 0.0f;      // (NeRFaceModel: one ambient coordinate)
         }
