@@ -251,6 +251,24 @@ int sahs_model_field_backward_split(int model, const float *flat_params, const f
                                     float *workspace, void *stream);
 int sahs_route_xw_grad(long N, int Sc, int nf, const int32_t *src, const float *g_fine, float *g_coarse, float *g_new, void *stream);
 
+/* The fused backward walk (round 4; SAHS_MODEL_AUDIO, split-operand arithmetic = sahs_backward_gemm_precision SAHS_BF16X3).  Replaces the
+ * ~38 GEMM launches sahs_model_field_backward_split makes per part -- autograd of modules.py:254-295 (NeRFMLP), :371-390 (WarpFieldMLP),
+ * :444-462 (HyperSheetMLP) as driven by train_stage_rays_auto.py:437-499 -- by two: one sample-major data-gradient chain and one
+ * weight-gradient launch over a job table.  The (leaky-)ReLU masks come from SIGN BITS the saving forward writes beside the activations:
+ * sahs_model_field_forward_split_save_bits = sahs_model_field_forward_split_save that also fills bits_out, N*S*sahs_model_bits_words_part(
+ * model, mode) 32-bit words (mode 0: [deformation planes | radiance planes]).  sahs_model_field_backward_fused takes the same arguments as
+ * sahs_model_field_backward_split plus bits_in (the planes of `part`; part 3: both, as written by a mode-0 save); workspace:
+ * sahs_model_field_backward_fused_workspace_words(model, part, P) floats (-1: not built for the model).  Same results as the per-layer
+ * walk up to summation order (tests/test_gpu_training.py). */
+long sahs_model_bits_words_part(int model, int part);
+int sahs_model_field_forward_split_save_bits(int model, const void *packed, const float *frame, int level, int mode, long N, int S, const float *rays,
+                                             int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src,
+                                             float *act_out, uint32_t *bits_out, void *stream);
+long sahs_model_field_backward_fused_workspace_words(int model, int part, long P);
+int sahs_model_field_backward_fused(int model, const float *flat_params, const float *frame, int level, int part, long P, const float *act_in,
+                                    const uint32_t *bits_in, const float *d_raw, const float *xw_grad_in, float *xw_grad_out, float *grad_flat,
+                                    float *grad_cond, float *workspace, void *stream);
+
 /* sahs_model_render_rays writing rows[r * row_ld + column] instead of eight dense arrays (row_ld >= 36; columns 17..33 are
  * left untouched when nf == 0).  Workspace and draws as sahs_render_rays.  Optional extra workspace xw (N,Sc+nf,8) floats, src
  * (N,Sc+nf) int32, z_new (N,nf) floats: when all three are given (nf > 0; any model with deformation nets, SAHS_F32 or SAHS_BF16 -- required for the mixed-precision

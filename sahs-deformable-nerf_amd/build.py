@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsahs_nerf.so")
-SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "spade_ops.hip", "field_f32.hip", "field_bf16w.hip", "field_bf16x3.hip", "field_bwd.hip", "train_bwd.hip"]
+SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "spade_ops.hip", "field_f32.hip", "field_bf16w.hip", "field_bf16x3.hip", "field_bwd.hip", "field_bwd_chain.hip", "train_bwd.hip"]
 # A/B kernels (the round-1 bf16 kernel and the 16x16x32 port, both slower than the shipped one): only in development builds made with
 # build(defines=["SAHS_AB_KERNELS"], out=...) by tools/cmp_*.py -- never in libsahs_nerf.so or the public header
 AB_SOURCES = ["ab/field_bf16.hip", "ab/field_bf16q.hip"]
@@ -28,13 +28,15 @@ FIELD_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
 # kernel (audio model, no activation saving) is held to zero scratch as a performance guard (a reload's wait also drains its in-flight
 # weight prefetch); its activation-saving and NeRFace builds do spill a little (build/<library>.resource_usage.txt).
 NO_SCRATCH = {"gemm_dma_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb0E": 0, "field_forward_bf16w_kernel": 0,
-              "field_radiance_bf16x3_kernel": 0, "field_deform_bf16x3_kernel": 0, "gemm_tn_split_kernel": 0}
+              "field_radiance_bf16x3_kernel": 0, "field_deform_bf16x3_kernel": 0, "gemm_tn_split_kernel": 0, "gemm_tn_jobs_kernel": 0,
+              "field_backward_chain_rad_kernel": 0, "field_backward_chain_def_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb1E": 0}
 # Kernels with hand-issued `asm volatile ds_read_b128` + counted waits (csrc/bf16_pipe.hpp): (source, SAHS_MODEL, kernel name pattern).
 # Every build compiles these to ISA as well and runs tools/check_lds_inflight.py on it: an object in which anything touches a read's
 # destination before the wait that retires it is never linked.
 HAND_SCHEDULED = [("field_bf16w.hip", 0, "field_forward_bf16w_kernel"), ("field_bf16w.hip", 1, "field_forward_bf16w_kernel"),
                   ("field_bf16w.hip", 2, "field_forward_bf16w_kernel"), ("field_bf16x3.hip", 0, "field_radiance_bf16x3_kernel"),
-                  ("field_bf16x3.hip", 0, "field_deform_bf16x3_kernel"), ("field_bf16x3.hip", 1, "field_deform_bf16x3_kernel")]
+                  ("field_bf16x3.hip", 0, "field_deform_bf16x3_kernel"), ("field_bf16x3.hip", 1, "field_deform_bf16x3_kernel"),
+                  ("field_bwd_chain.hip", 0, "field_backward_chain_rad_kernel"), ("field_bwd_chain.hip", 0, "field_backward_chain_def_kernel")]
 # field_bf16w.hip (one wave per SIMD, 512 registers): MFMA accumulators must live in ARCH VGPRs.  Left to its heuristics the compiler
 # puts them in AGPRs, and every accumulator value the activation code touches then costs a v_accvgpr_read -- which, unlike plain VALU
 # work, does NOT hide under the wave's own MFMAs (tools/micro/mfma_valu_overlap.hip: 2 reads per MFMA = 55 cycles per MFMA instead of 36).
@@ -43,6 +45,7 @@ HAND_SCHEDULED = [("field_bf16w.hip", 0, "field_forward_bf16w_kernel"), ("field_
 # The forward kernels measure neutral (+-0.5 %) and keep the default.
 PER_FILE_FLAGS = {"field_bwd.hip": ["-fno-slp-vectorize"],
                   "field_bf16w.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "field_bf16x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+                  "field_bwd_chain.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                   "ab/field_bf16q.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-fno-math-errno", "-Wall", "-Wno-unused-function"]
 

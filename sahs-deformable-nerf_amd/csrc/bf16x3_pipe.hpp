@@ -163,6 +163,7 @@ __device__ __forceinline__ void dense_x(Ctx &cx, St &st, Blk *in0, const Blk *in
     static_assert(NT32 % 2 == 0, "the last tile of a layer must land in accumulator set 1");
     static_assert(TOTAL * STEP_BYTES <= LDS_BUF_BYTES, "chunk does not fit its buffer");
     static_assert(!PEND || 2 * K0 - 3 >= 1, "no room for the pending tile's conversion");
+    static_assert(STEPS >= AP || NT32 == 1, "the counted waits assume a tile's bias batch is issued before the A reads of the next tile's first step");
     const uint32_t baddr = cx.bias_addr + 4u * (uint32_t)bias_off;
     f32x4 braw[2][4];
     bias_read<0>(braw[0], baddr);

@@ -61,6 +61,11 @@ int sahs_spade_modulate_launch(long planes, long hw, const float *x, const float
     long sahs_field_backward_ws_words##sfx(long P);                                                                                 \
     int sahs_layout_act_part_words##sfx(int part);                                                                                  \
     int sahs_layout_act_part_col0##sfx(int part);                                                                                   \
+    int sahs_layout_bits_part_words##sfx(int part);                                                                                 \
+    int sahs_field_forward_f32_split_bits_launch##sfx(const float *packed, const float *frame, int level, int mode, long P, int S, \
+                                                      const float *rays, int ray_stride, const float *zvals, float *raw, float *xw, \
+                                                      int xw_row, int xw_col0, const int *src, float *actbuf, uint32_t *bits,       \
+                                                      int num_cu, hipStream_t stream);                                              \
     int sahs_field_backward_split_launch##sfx(const float *flat, const float *frame, int level, int part, long P, const float *actbuf, \
                                               const float *d_raw, const float *xwg_in, float *xwg_out, float *grad_flat,            \
                                               float *grad_cond, float *ws, hipStream_t stream);                                     \
@@ -80,6 +85,11 @@ int sahs_spade_modulate_launch(long planes, long hw, const float *x, const float
 SAHS_DECLARE_MODEL()
 SAHS_DECLARE_MODEL(_nf)
 SAHS_DECLARE_MODEL(_ns)
+// the fused backward walk (field_bwd.hip + field_bwd_chain.hip): AudioFaceModel only
+long sahs_field_backward_fused_ws_words(int part, long P);
+int sahs_field_backward_fused_launch(const float *flat, const float *frame, int level, int part, long P, const float *actbuf, const uint32_t *bits,
+                                     const float *d_raw, const float *xwg_in, float *xwg_out, float *grad_flat, float *grad_cond, float *ws,
+                                     int num_cu, hipStream_t stream);
 // NeRFaceModel (with deformation) in mixed precision: bf16 radiance nets (field_bf16w.hip built with SAHS_MODEL=1), fp32 deformation nets
 long sahs_layout_packed_words_bf16_nf(void);
 int sahs_pack_weights_bf16_launch_nf(const float *flat, float *packed, hipStream_t stream);
@@ -752,6 +762,57 @@ int sahs_model_field_backward_split(int model, const float *flat_params, const f
                                                                                 grad_flat, grad_cond, workspace, (hipStream_t)stream)
                                           : sahs_field_backward_split_launch_ns(flat_params, frame, level, part, P, base, d_raw, xw_grad_in, xw_grad_out,
                                                                                 grad_flat, grad_cond, workspace, (hipStream_t)stream);
+    return e ? hip_fail(who, e) : 0;
+}
+
+long sahs_model_bits_words_part(int model, int part)
+{
+    if (model != SAHS_MODEL_AUDIO || part < 0 || part > 3) return 0;      // only the AudioFaceModel's (fused) backward reads sign bits
+    return sahs_layout_bits_part_words(part == 3 ? 0 : part);
+}
+
+int sahs_model_field_forward_split_save_bits(int model, const void *packed, const float *frame, int level, int mode, long N, int S, const float *rays,
+                                             int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src,
+                                             float *act_out, uint32_t *bits_out, void *stream)
+{
+    const char *who = "sahs_model_field_forward_split_save_bits";
+    REQUIRE(model == SAHS_MODEL_AUDIO, "sahs_model_field_forward_split_save_bits(AudioFaceModel only)");
+    if (N == 0) return 0;
+    REQUIRE(packed && frame && rays && xw && act_out && bits_out && (level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8 && mode >= 0 && mode <= 2, who);
+    REQUIRE((mode == 1 || raw) && (mode == 2 || z) && (mode != 2 || src), "sahs_model_field_forward_split_save_bits(buffers of the mode)");
+    REQUIRE(xw_col0 >= 0 && xw_row >= xw_col0 + (mode == 2 ? 0 : S) && ALIGNED16(xw) && ALIGNED16(packed) && ALIGNED16(frame) && (!raw || ALIGNED16(raw)) &&
+            ALIGNED16(act_out) && ALIGNED16(bits_out), "sahs_model_field_forward_split_save_bits(xw layout / alignment)");
+    const long P = N * S;
+    REQUIRE(P <= 4000000L, "sahs_model_field_forward_split_save_bits(at most 4e6 samples per call)");
+    float *base = act_out - act_col0(model, mode) * P;
+    int e = sahs_field_forward_f32_split_bits_launch((const float *)packed, frame, level, mode, P, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0, src, base,
+                                                     bits_out, num_cus(), (hipStream_t)stream);
+    return e ? hip_fail(who, e) : 0;
+}
+
+long sahs_model_field_backward_fused_workspace_words(int model, int part, long P)
+{
+    if (model != SAHS_MODEL_AUDIO || part < 1 || part > 3 || P < 0) return -1;
+    return sahs_field_backward_fused_ws_words(part, P);
+}
+
+int sahs_model_field_backward_fused(int model, const float *flat_params, const float *frame, int level, int part, long P, const float *act_in,
+                                    const uint32_t *bits_in, const float *d_raw, const float *xw_grad_in, float *xw_grad_out, float *grad_flat,
+                                    float *grad_cond, float *workspace, void *stream)
+{
+    const char *who = "sahs_model_field_backward_fused";
+    REQUIRE(model == SAHS_MODEL_AUDIO, "sahs_model_field_backward_fused(AudioFaceModel only)");
+    REQUIRE(flat_params && frame && act_in && bits_in && grad_flat && grad_cond && workspace && part >= 1 && part <= 3, who);
+    REQUIRE((level == 0 || level == 1) && P >= 0 && P <= 4000000L, "sahs_model_field_backward_fused(0 <= P <= 4e6 samples per call)");
+    REQUIRE(((part & 2) ? d_raw != nullptr : xw_grad_in != nullptr) && (part != 2 || xw_grad_out != nullptr),
+            "sahs_model_field_backward_fused(d_raw for the radiance part, xw_grad_in for the deformation part alone, xw_grad_out for the radiance part alone)");
+    REQUIRE(ALIGNED16(act_in) && ALIGNED16(bits_in) && ALIGNED16(workspace) && (!d_raw || ALIGNED16(d_raw)) && (!xw_grad_in || ALIGNED16(xw_grad_in)) &&
+            (!xw_grad_out || ALIGNED16(xw_grad_out)), "sahs_model_field_backward_fused(alignment)");
+    REQUIRE(sahs_bwd_gemm_precision_state(-1) != 0, "sahs_model_field_backward_fused(split-operand arithmetic only: sahs_backward_gemm_precision is SAHS_F32)");
+    if (P == 0) return 0;
+    const float *base = act_in - act_col0(model, part) * P;
+    int e = sahs_field_backward_fused_launch(flat_params, frame, level, part, P, base, bits_in, d_raw, xw_grad_in, xw_grad_out, grad_flat, grad_cond,
+                                             workspace, num_cus(), (hipStream_t)stream);
     return e ? hip_fail(who, e) : 0;
 }
 

@@ -703,32 +703,19 @@ constexpr int TN_FRAG_DWORDS = 2 * 2 * GT * 8;             // [operand][hi | lo]
 constexpr int TN_LDS_BYTES = (TN_RING_FLOATS + TN_FRAG_DWORDS) * 4;
 static_assert(TN_LDS_BYTES == 81920, "two workgroups per CU: 2 x 80 KB = the 160 KB of a gfx950 CU");
 
-__global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) gemm_tn_split_kernel(int M, int N, int K, const float *__restrict__ A, long lda,
-                                                       const float *__restrict__ B, long ldb, float *__restrict__ C, long ldc, int kslab,
-                                                       float *__restrict__ rowsum, int nx, const float *__restrict__ zero,
-                                                       unsigned char *__restrict__ bits)
+// One 128 x 128 tile of C += A^T B over the samples [k_lo, k_hi): the body shared by the per-layer kernel (one tile-slab per workgroup)
+// and the job-table kernel (a workgroup walks many).  Ends on an LDS barrier: the ring and the fragment buffer are free on return.
+__device__ __forceinline__ void tn_tile(float *tn_lds, int M, int N, const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
+                                        float *__restrict__ C, long ldc, long k_lo, long k_hi, float *__restrict__ rowsum, int bx, int by,
+                                        const float *__restrict__ zero, unsigned char *__restrict__ bits)
 {
-    extern __shared__ __attribute__((aligned(16))) float tn_lds[];
     float *ring = tn_lds;                                                    // [TN_DST][2][DTILE]
     uint32_t *frag = reinterpret_cast<uint32_t *>(tn_lds + TN_RING_FLOATS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3, h = lane >> 5, r32 = lane & 31, c32 = lane & 31;
-    // 1-D grid: the nx x ny output tiles of ONE sample slab read the same dY and X rows -- they run on the same XCD (workgroup ids congruent
-    // mod 8, consecutive slots), so that XCD's L2 fetches the slab from HBM once instead of once per tile
-    const int ny = (M + GT - 1) / GT, tiles = nx * ny;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, tile = slot % tiles;
-    const long bz = (long)(slot / tiles) * 8 + xcd;
-    const int bx = tile % nx, by = tile / nx;
-    if (bz * kslab >= K) return;
     const long m0 = (long)by * GT;
     const int n0 = bx * GT;
-    const long k_lo = bz * kslab;
-    const long k_hi = (k_lo + kslab < K) ? k_lo + kslab : K;
     const int T = (int)((k_hi - k_lo + GK - 1) / GK);
     const bool do_sum = rowsum != nullptr && bx == 0;
-#ifdef SAHS_GEMM_STAMP
-    const unsigned long long st_begin = SAHS_STAMP_NOW();
-    unsigned long long st_wait = 0, st_bar = 0, st_split = 0, st_bar2 = 0, st_issue = 0, st_rd = 0, st_frd = 0, st_mfma = 0;
-#endif
 
     // this wave's two DMA instructions per K-step: waves 0..3 move the dY tile, waves 4..7 the X tile; K-major [16 k][128 cols], 32 chunks
     // per row, two rows per instruction, XOR-swizzled by 16 floats on odd rows (kept from gemm_dma_kernel: the sign-bit pass relies on it)
@@ -774,45 +761,22 @@ __global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu
     float cs = 0.0f;
 
     // vmcnt accounting as in gemm_dma_kernel: the wave's only loads are its 2 LDS-DMA instructions per issue(), completing in issue order;
-    // the sign-bit store of the by == 0 workgroups can only make a counted wait stricter
+    // anything older still in flight (the sign-bit stores, a previous tile's atomics) can only make a counted wait stricter
     if (T > 0) issue(0);
     if (T > 1) issue(1);
     if (T > 2) issue(2);
-#ifdef SAHS_GEMM_STAMP
-    const unsigned long long st_loop0 = SAHS_STAMP_NOW();
-#endif
     for (int t = 0; t < T; ++t) {
-#ifdef SAHS_GEMM_STAMP
-        const unsigned long long sa = SAHS_STAMP_NOW();
-        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long sb = SAHS_STAMP_NOW();
-        asm volatile("s_barrier" ::: "memory");
-        const unsigned long long sc = SAHS_STAMP_NOW();
-        st_wait += sb - sa; st_bar += sc - sb;
-#else
         if (t + 2 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
         // (every wave has finished the MFMA phase of step t-1: the fragment buffer and ring stage (t-1) % 4 are free)
         if (t + TN_DST - 1 < T) issue(t + TN_DST - 1);
-#ifdef SAHS_GEMM_STAMP
-        const unsigned long long si = SAHS_STAMP_NOW();
-        st_issue += si - sc;
-#endif
         const float *stage = ring + (t % TN_DST) * 2 * DTILE;
         {
             const float *col = stage + sop * DTILE + 8 * skh * GT;
             float x[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[k] = col[k * GT + ((k & 1) ? spos1 : spos0)];
-#ifdef SAHS_GEMM_STAMP
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
-            const unsigned long long sr = SAHS_STAMP_NOW();
-            st_rd += sr - si;
-#endif
             u32x4_t hi, lo;
             split8(x, hi, lo);
             *reinterpret_cast<u32x4_t *>(fdst) = hi;
@@ -834,14 +798,7 @@ __global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu
                 bits[k * (N >> 3) + (n0 >> 3) + g] = (unsigned char)b8;
             }
         }
-#ifdef SAHS_GEMM_STAMP
-        const unsigned long long sd = SAHS_STAMP_NOW();
         lds_barrier();
-        const unsigned long long se = SAHS_STAMP_NOW();
-        st_split += sd - si; st_bar2 += se - sd;
-#else
-        lds_barrier();
-#endif
         u32x4_t ah[2], al[2], bh, bl;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -850,20 +807,9 @@ __global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         bh = *reinterpret_cast<const u32x4_t *>(fb);
         bl = *reinterpret_cast<const u32x4_t *>(fb + GT * 8);
-#ifdef SAHS_GEMM_STAMP
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(ah[1]), "+v"(al[0]), "+v"(al[1]), "+v"(bh), "+v"(bl));
-        const unsigned long long sf = SAHS_STAMP_NOW();
-        st_frd += sf - se;
-#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) acx[i] = mfma3(ah[i], al[i], bh, bl, acx[i]);
-#ifdef SAHS_GEMM_STAMP
-        st_mfma += SAHS_STAMP_NOW() - sf;
-#endif
     }
-#ifdef SAHS_GEMM_STAMP
-    const unsigned long long st_loop1 = SAHS_STAMP_NOW();
-#endif
     // epilogue through LDS: one atomic instruction covers 256 contiguous bytes of a dW row.  Accumulator tile i register e is
     // row 32 i + (e & 3) + 8 (e >> 2) + 4 h, column r32 of this wave's 64 x 32 block
     constexpr int SLD = GT + 4;
@@ -888,18 +834,59 @@ __global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu
         lds_barrier();
     }
     if (do_sum && sop == 0 && m0 + scol < M) atomicAdd(rowsum + m0 + scol, cs);      // (two partial sums per column: samples 0..7 and 8..15 of every step)
-#ifdef SAHS_GEMM_STAMP
-    if ((threadIdx.x & 63) == 0) {
-        const unsigned long long e = SAHS_STAMP_NOW();
-        unsigned long long *g = g_gemm_stamp[1][(blockIdx.x * 8u + (threadIdx.x >> 6)) % STAMP_SLOTS];
-        atomicAdd(g + 0, st_wait); atomicAdd(g + 1, st_bar + st_bar2); atomicAdd(g + 2, st_loop1 - st_loop0 - st_wait - st_bar - st_bar2);
-        atomicAdd(g + 3, st_loop0 - st_begin); atomicAdd(g + 4, e - st_loop1); atomicAdd(g + 5, e - st_begin); atomicAdd(g + 6, 1ull);
-        atomicAdd(g + 7, (unsigned long long)T);
-        unsigned long long *g2 = g_gemm_stamp3[(blockIdx.x * 8u + (threadIdx.x >> 6)) % STAMP_SLOTS];
-        atomicAdd(g2 + 0, st_issue); atomicAdd(g2 + 1, st_rd); atomicAdd(g2 + 2, st_split - st_rd); atomicAdd(g2 + 3, st_bar2); atomicAdd(g2 + 4, st_frd);
-        atomicAdd(g2 + 5, st_mfma); atomicAdd(g2 + 6, st_wait); atomicAdd(g2 + 7, st_bar);
+}
+
+__global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) gemm_tn_split_kernel(int M, int N, int K, const float *__restrict__ A, long lda,
+                                                       const float *__restrict__ B, long ldb, float *__restrict__ C, long ldc, int kslab,
+                                                       float *__restrict__ rowsum, int nx, const float *__restrict__ zero,
+                                                       unsigned char *__restrict__ bits)
+{
+    extern __shared__ __attribute__((aligned(16))) float tn_lds[];
+    // 1-D grid: the nx x ny output tiles of ONE sample slab read the same dY and X rows -- they run on the same XCD (workgroup ids congruent
+    // mod 8, consecutive slots), so that XCD's L2 fetches the slab from HBM once instead of once per tile
+    const int ny = (M + GT - 1) / GT, tiles = nx * ny;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, tile = slot % tiles;
+    const long bz = (long)(slot / tiles) * 8 + xcd;
+    if (bz * kslab >= K) return;
+    const long k_lo = bz * kslab;
+    const long k_hi = (k_lo + kslab < K) ? k_lo + kslab : K;
+    tn_tile(tn_lds, M, N, A, lda, B, ldb, C, ldc, k_lo, k_hi, rowsum, tile % nx, tile / nx, zero, bits);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ALL weight-gradient GEMMs of a walk in ONE launch (round 4).  Per launch the kernel above pays ring fill, a K loop with one workgroup
+// per CU, 64 KB of atomics per workgroup, ramp and tail -- 35-40 us of a 45-200 us launch, 82 times per training step (DESIGN.md section
+// 7).  Here persistent workgroups (two per CU) walk a job table: job = one layer's dW (+ db) = dY^T X with dY, X dense [P x width]
+// planes; item = (sample range r, job, 128 x 128 tile), ranges of `range` samples (the same for every job: items cost the same), item
+// index = r * tiles_total + tile, so that the tiles of one job and range -- which stream the same dY and X rows -- sit on neighbouring
+// workgroups of ONE XCD (virtual id below) at the same time and share that L2's fetches.  A range is ~10 k samples instead of the 512 of
+// a slab: 20 x fewer atomic epilogues.  The table travels as kernel arguments (no upload, nothing allocated).
+struct TnJob { const float *A; const float *B; float *C; float *rowsum; long lda, ldb, ldc; int M, N; };
+constexpr int MAX_TN_JOBS = 40;
+struct TnBatch { TnJob j[MAX_TN_JOBS]; };
+static_assert(sizeof(TnBatch) <= 3072, "kernel-argument budget");
+
+__global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) gemm_tn_jobs_kernel(TnBatch jobs, int njobs, int tiles_total, long P, long range,
+                                                                                                             const float *__restrict__ zero)
+{
+    extern __shared__ __attribute__((aligned(16))) float tn_lds[];
+    const int G = gridDim.x;                                                  // a multiple of 8
+    const int vid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);          // consecutive virtual ids = consecutive slots of one XCD
+    const long nrange = (P + range - 1) / range;
+    const long items = nrange * tiles_total;
+    for (long it = vid; it < items; it += G) {
+        const long r = it / tiles_total;
+        int tg = (int)(it - r * tiles_total), j = 0;
+        for (; j < njobs - 1; ++j) {
+            const int tj = ((jobs.j[j].N + GT - 1) / GT) * ((jobs.j[j].M + GT - 1) / GT);
+            if (tg < tj) break;
+            tg -= tj;
+        }
+        const TnJob &J = jobs.j[j];
+        const int nx = (J.N + GT - 1) / GT;
+        const long k_lo = r * range, k_hi = (k_lo + range < P) ? k_lo + range : P;
+        tn_tile(tn_lds, J.M, J.N, J.A, J.lda, J.B, J.ldb, J.C, J.ldc, k_lo, k_hi, J.rowsum, tg % nx, tg / nx, zero, nullptr);
     }
-#endif
 }
 
 #if defined(SAHS_GEMM_STAMP) && SAHS_MODEL == 0
@@ -968,22 +955,38 @@ __device__ __forceinline__ void pe_grad(const float *enc, const float *denc, flo
 constexpr int DIN_LD = 16 * (KB_XYZ + KB_AMB);   // row of the gradient wrt [PE(x') blocks | PE(w) blocks]: 96 | 128 | 64
 constexpr int DIN_AMB = 16 * KB_XYZ;             // where the PE(w) part starts
 
-// Per sample: d_in [P x DIN_LD] = gradient wrt [PE(x') blocks | PE(w) blocks].  d_xw [P x 4] += dL/dx' through PE63 (the trilinear
-// part was written by grid_backward_kernel), d_w [P x 4] = dL/dw.
+// Per sample: d_in [P x DIN_LD] = gradient wrt [PE(x') blocks | PE(w) blocks] (d_in2, optional: a second contribution, added).  d_xw [P x 4] +=
+// dL/dx' through PE63 (the trilinear part was written by grid_backward_kernel), d_w [P x 4] = dL/dw; seam8 (optional): the same as (P,8) rows
+// [dx'0 dx'1 dx'2 0 | dw0 dw1 0 0], the form in which the seam gradient leaves the radiance part of a split walk.
 __global__ void __launch_bounds__(256) encode_backward_kernel(long P, const float *__restrict__ actbuf, const float *__restrict__ d_in,
-                                                              float *__restrict__ d_xw, float *__restrict__ d_w)
+                                                              const float *__restrict__ d_in2, float *__restrict__ d_xw, float *__restrict__ d_w,
+                                                              float *__restrict__ seam8)
 {
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
         float gx[3], gw[2];
-        pe_grad<3, L_XYZ, 1>(actbuf + (long)act::PEX * P + p * (16 * KB_XYZ), d_in + p * DIN_LD, gx);
+        float din[DIN_LD];
+#pragma unroll
+        for (int i = 0; i < DIN_LD / 4; ++i) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(d_in + p * DIN_LD + 4 * i);
+            if (d_in2 != nullptr) {
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(d_in2 + p * DIN_LD + 4 * i);
+                v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+            }
+            din[4 * i] = v[0]; din[4 * i + 1] = v[1]; din[4 * i + 2] = v[2]; din[4 * i + 3] = v[3];
+        }
+        pe_grad<3, L_XYZ, 1>(actbuf + (long)act::PEX * P + p * (16 * KB_XYZ), din, gx);
         gw[0] = 0.0f; gw[1] = 0.0f;
 #if SAHS_MODEL != 2
-        pe_grad<AMB_DIM, L_AMB, AMB_INC>(actbuf + (long)act::PEW * P + p * (16 * KB_AMB), d_in + p * DIN_LD + DIN_AMB, gw);
+        pe_grad<AMB_DIM, L_AMB, AMB_INC>(actbuf + (long)act::PEW * P + p * (16 * KB_AMB), din + DIN_AMB, gw);
 #endif
         f32x4 t = *reinterpret_cast<const f32x4 *>(d_xw + p * 4);
         t[0] += gx[0]; t[1] += gx[1]; t[2] += gx[2];
         *reinterpret_cast<f32x4 *>(d_xw + p * 4) = t;
         *reinterpret_cast<f32x4 *>(d_w + p * 4) = f32x4{gw[0], gw[1], 0.0f, 0.0f};
+        if (seam8 != nullptr) {
+            *reinterpret_cast<f32x4 *>(seam8 + p * 8) = f32x4{t[0], t[1], t[2], t[3]};
+            *reinterpret_cast<f32x4 *>(seam8 + p * 8 + 4) = f32x4{gw[0], gw[1], 0.0f, 0.0f};
+        }
     }
 }
 
@@ -1560,7 +1563,7 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
         const long gb = (P + 127) / 128;                // 4 waves x 2 runs of 16 samples per block pass
         grid_backward_kernel<<<(unsigned)(gb < 8192 ? gb : 8192), 256, 0, stream>>>(P, actbuf, dgridf, grid_cl, dgrid_cl, dxw); b.check();
         grid_transpose_kernel<<<tb, 256, 0, stream>>>(dgrid_cl, G(F.grid), 1); b.check();
-        encode_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, din, dxw, dw); b.check();
+        encode_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, din, nullptr, dxw, dw, nullptr); b.check();
         }
     }
     }   // do_rad
@@ -1637,3 +1640,240 @@ extern "C" int SAHS_SYM(sahs_field_backward_split_launch)(const float *flat, con
     b.dry = false;
     return walk();
 }
+
+#if SAHS_MODEL == 0
+// ================================================================================================================================
+// The fused walk (round 4; AudioFaceModel, split-operand arithmetic): per part of the field TWO GEMM-class launches instead of ~38 --
+//   1. field_backward_chain_{rad,def}_kernel (field_bwd_chain.hip): the whole data-gradient chain, sample-major, every layer's dZ stored once
+//      into its plane of `dact` (the act:: layout), masks from the sign bits the saving forward wrote;
+//   2. gemm_tn_jobs_kernel: every layer's dW (+ db) = dZ^T X from those planes and the saved activations, one job table;
+// around them the small kernels of the per-layer walk (feature-grid scatter, encodings, per-frame-constant columns, deferred adds).
+// part 1: deformation nets (seam gradient xwg_in (P,8) -> parameters); part 2: radiance nets of `level` (d_raw (P,16) -> parameters, seam
+// gradient to xwg_out); part 3: part 2, then part 1 on (its seam gradient + xwg_in).  actbuf / bits: the buffers the saving forward of that
+// part wrote (a plane of column c at actbuf + c * P; for part 3 bits = [deformation planes | radiance planes]).
+// ================================================================================================================================
+extern "C" {
+long sahs_bwd_chain_stream_hw(int part);
+int sahs_bwd_chain_pack_launch(const float *flat, void *stream_out, int level, int part, hipStream_t stream);
+int sahs_bwd_chain_rad_launch(const void *bstream, long P, const float *d_raw, const uint32_t *bits, float *dact, float *dgridf, float *din_a,
+                              float *din_b, int num_cu, hipStream_t stream);
+int sahs_bwd_chain_def_launch(const void *bstream, long P, const float *xwg, const float *actbuf, const uint32_t *bits, float *dact, float *g3,
+                              float *dw4, int num_cu, hipStream_t stream);
+}
+
+namespace {
+constexpr long RAD_PLANES = act::STRIDE - act::XW, DEF_PLANES = act::XW;        // floats per sample of the dZ planes of a part
+struct FusedWs {      // workspace of one part, in floats
+    static long rad(long P) { return P * (RAD_PLANES + 32 + 2 * DIN_LD + 8) + DB_SCRATCH + 2 * GRID_FLOATS + sahs_bwd_chain_stream_hw(2) / 2 + HEAD_FLOATS; }
+    static long def(long P) { return P * (DEF_PLANES + 8) + DB_SCRATCH + sahs_bwd_chain_stream_hw(1) / 2; }
+};
+
+__global__ void add_rows8_kernel(long n, const float *__restrict__ a, float *__restrict__ y)      // y[i] += a[i] over (P,8) rows, as float4s
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        f32x4 v = reinterpret_cast<f32x4 *>(y)[i];
+        const f32x4 u = reinterpret_cast<const f32x4 *>(a)[i];
+        v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+        reinterpret_cast<f32x4 *>(y)[i] = v;
+    }
+}
+
+// the job table of one part -> one launch
+struct TnList {
+    TnBatch b; int n = 0, tiles = 0;
+    void add(const float *dY, long ldy, int M, const float *X, long ldx, int N, float *dW, long ldw, float *db = nullptr)
+    {
+        if (n < MAX_TN_JOBS) b.j[n] = TnJob{dY, X, dW, db, ldy, ldx, ldw, M, N};
+        ++n;
+        tiles += ((N + GT - 1) / GT) * ((M + GT - 1) / GT);
+    }
+    int launch(long P, const float *zero, int num_cu, hipStream_t st)
+    {
+        if (n > MAX_TN_JOBS) return (int)hipErrorOutOfMemory;
+        static sahs_once::Flags attr_set;
+        const hipError_t ae = sahs_once::per_device(attr_set, [&]() {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_jobs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+        });
+        if (ae != hipSuccess) return (int)ae;
+        const int G = 2 * num_cu / 8 * 8;                     // two 80-KB workgroups per CU
+        // ~3 rounds of equal items: ranges of >= 1024 samples (a multiple of 16), as many as fill G workgroups three times
+        static const long rounds = getenv("SAHS_BWD_TN_ROUNDS") ? atol(getenv("SAHS_BWD_TN_ROUNDS")) : 3;      // (tuning aid)
+        long nsplit = rounds * G / (tiles > 0 ? tiles : 1);
+        if (nsplit < 1) nsplit = 1;
+        long range = ((P + nsplit - 1) / nsplit + 15) / 16 * 16;
+        if (range < 1024) range = 1024;
+        gemm_tn_jobs_kernel<<<G, TN_THREADS, TN_LDS_BYTES, st>>>(b, n, tiles, P, range, zero);
+        return (int)hipGetLastError();
+    }
+};
+}  // namespace
+
+extern "C" long sahs_field_backward_fused_ws_words(int part, long P)
+{
+    return part == 1 ? FusedWs::def(P) : (part == 2 ? FusedWs::rad(P) : FusedWs::rad(P) + FusedWs::def(P) + P * 8);
+}
+
+static int fused_rad(const float *flat, const float *frame, int level, long P, const float *actbuf, const uint32_t *bits, const float *d_raw,
+                     float *xwg_out, float *grad_flat, float *grad_cond, float *ws, int num_cu, hipStream_t stream)
+{
+    Bwd b{stream, P};
+    const FlatOffsets &F = kFlat;
+    const FlatOffsets::Lvl &Lv = F.lvl[level];
+    float *dact_mem = ws, *dgridf = dact_mem + P * RAD_PLANES, *din_a = dgridf + P * 32, *din_b = din_a + P * DIN_LD, *dxw = din_b + P * DIN_LD,
+          *dw = dxw + P * 4, *db = dw + P * 4, *grid_cl = db + DB_SCRATCH, *dgrid_cl = grid_cl + GRID_FLOATS, *bstream = dgrid_cl + GRID_FLOATS,
+          *heads = bstream + sahs_bwd_chain_stream_hw(2) / 2;
+    float *dact = dact_mem - (long)act::XW * P;              // plane of act:: column c at dact + c * P (columns >= XW are backed)
+    b.zero = db + DB_SCRATCH - 64;
+    if (hipMemsetAsync(db, 0, sizeof(float) * DB_SCRATCH, stream) != hipSuccess) return (int)hipGetLastError();
+    if (hipMemsetAsync(dgrid_cl, 0, sizeof(float) * GRID_FLOATS, stream) != hipSuccess) return (int)hipGetLastError();
+    if (hipMemsetAsync(heads, 0, sizeof(float) * HEAD_FLOATS, stream) != hipSuccess) return (int)hipGetLastError();
+    int e = sahs_bwd_chain_pack_launch(flat, bstream, level, 2, stream);
+    if (e) return e;
+    e = sahs_bwd_chain_rad_launch(bstream, P, d_raw, bits, dact, dgridf, din_a, din_b, num_cu, stream);
+    if (e) return e;
+    // ---- encodings + feature grid -> the seam gradient (what the deformation part waits for) ----
+    {
+        const int tb = (int)(GRID_FLOATS / 32 / 32);
+        grid_transpose_kernel<<<tb, 256, 0, stream>>>(flat + F.grid, grid_cl, 0); b.check();
+        const long gb = (P + 127) / 128;
+        grid_backward_kernel<<<(unsigned)(gb < 8192 ? gb : 8192), 256, 0, stream>>>(P, actbuf, dgridf, grid_cl, dgrid_cl, dxw); b.check();
+        grid_transpose_kernel<<<tb, 256, 0, stream>>>(dgrid_cl, grad_flat + F.grid, 1); b.check();
+        encode_backward_kernel<<<2048, 256, 0, stream>>>(P, actbuf, din_a, din_b, dxw, dw, xwg_out); b.check();
+    }
+    // ---- every weight gradient of the part: one job table ----
+    const float *A = actbuf;
+    auto AC = [&](int c) { return A + (long)c * P; };
+    auto DA = [&](int c) { return dact + (long)c * P; };
+    auto G = [&](long off) { return grad_flat + off; };
+    const float *p36 = frame + FRAME_POSE_OFF, *drv = frame + FRAME_DRV_OFF;
+    const float *trc = TRUNK_SEES_POSE ? p36 : drv;
+    float *d_trc = grad_cond + (TRUNK_SEES_POSE ? 80 : 0);
+    int dbo = 0;
+    auto scratch_db = [&](int n) { float *p = db + dbo; dbo += (n + 3) / 4 * 4; return p; };
+    auto defer_add = [&](const float *src, float *dst, int n) { if (b.naxpy < MAX_AXPY_JOBS) b.axpys.j[b.naxpy++] = AxpyJob{src, dst, n}; else if (!b.err) b.err = (int)hipErrorOutOfMemory; };
+    auto defer_consts = [&](long woff, long ld, int rows, int col0, int cols, const float *dbl, const float *c, float *dc) {
+        if (b.nconst < MAX_CONST_JOBS) {
+            b.consts.j[b.nconst++] = ConstJob{flat + woff, G(woff), dbl, c, dc, ld, rows, cols, col0};
+            b.const_maxcols = cols > b.const_maxcols ? cols : b.const_maxcols;
+        } else if (!b.err) b.err = (int)hipErrorOutOfMemory;
+    };
+    TnList L;
+    // the three heads read the whole d_raw row against 16-row scratch gradients (rows 3..14 fc_seg, 0..2 fc_rgb, 15 fc_alpha)
+    L.add(d_raw, 16, 16, AC(act::S + 384), BR_H, BR_H, heads + HEAD_G_SEG, BR_H, heads + HEAD_DB);
+    L.add(d_raw, 16, 16, AC(act::C + 384), BR_H, BR_H, heads + HEAD_G_RGB, BR_H);
+    L.add(d_raw, 16, 16, AC(act::FEAT), TR_H, TR_H, heads + HEAD_G_ALPHA, TR_H);
+    defer_add(heads + HEAD_G_SEG + 3 * BR_H, G(Lv.segout_w), N_SEG * BR_H);
+    defer_add(heads + HEAD_DB + 3, G(Lv.segout_b), N_SEG);
+    defer_add(heads + HEAD_DB, G(Lv.rgb_b), 3);
+    defer_add(heads + HEAD_DB + 15, G(Lv.alpha_b), 1);
+    defer_add(heads + HEAD_G_RGB, G(Lv.rgb_w), 3 * BR_H);
+    defer_add(heads + HEAD_G_ALPHA + 15 * TR_H, G(Lv.alpha_w), TR_H);
+    for (int i = 3; i >= 1; --i) {
+        L.add(DA(act::S + 128 * i), BR_H, BR_H, AC(act::S + 128 * (i - 1)), BR_H, BR_H, G(Lv.seg_w[i]), BR_H, G(Lv.seg_b[i]));
+        L.add(DA(act::C + 128 * i), BR_H, BR_H, AC(act::C + 128 * (i - 1)), BR_H, BR_H, G(Lv.dir_w[i]), BR_H, G(Lv.dir_b[i]));
+    }
+    L.add(DA(act::S), BR_H, BR_H, AC(act::FEAT), TR_H, TR_H, G(Lv.seg_w[0]), TR_H, G(Lv.seg_b[0]));
+    L.add(DA(act::C), BR_H, BR_H, AC(act::FEAT), TR_H, TR_H, G(Lv.dir_w[0]), D_DIR_IN, G(Lv.dir_b[0]));
+    L.add(DA(act::C), BR_H, BR_H, AC(act::DIR), 32, D_DIR, G(Lv.dir_w[0]) + TR_H, D_DIR_IN);
+    L.add(DA(act::C), BR_H, BR_H, AC(act::GRID), 32, D_GRID, G(Lv.dir_w[0]) + TR_H + D_DIR, D_DIR_IN);
+    L.add(DA(act::FEAT), TR_H, TR_H, AC(act::T + (TR_LAYERS - 1) * 256), TR_H, TR_H, G(Lv.feat_w), TR_H, G(Lv.feat_b));
+    for (int i = TR_LAYERS - 1; i >= 1; --i) {
+        const long ldw = (i == 3) ? TR_H + D_TR_IN : TR_H;
+        float *dl = (i == 3) ? scratch_db(TR_H) : G(Lv.xyz_b[i]);
+        L.add(DA(act::T + 256 * i), TR_H, TR_H, AC(act::T + 256 * (i - 1)), TR_H, TR_H, G(Lv.xyz_w[i]), ldw, dl);
+        if (i == 3) {
+            L.add(DA(act::T + 768), TR_H, TR_H, AC(act::PEX), 16 * KB_XYZ, D_XYZ, G(Lv.xyz_w[3]) + TR_H, ldw);
+            if (D_AMB > 0) L.add(DA(act::T + 768), TR_H, TR_H, AC(act::PEW), 16 * KB_AMB, D_AMB, G(Lv.xyz_w[3]) + TR_H + D_XYZ, ldw);
+            defer_add(dl, G(Lv.xyz_b[3]), TR_H);
+            defer_consts(Lv.xyz_w[3], ldw, TR_H, TR_H + D_XYZ + D_AMB, D_TR_CONST, dl, trc, d_trc);
+        }
+    }
+    {
+        float *dl = scratch_db(TR_H);
+        L.add(DA(act::T), TR_H, TR_H, AC(act::PEX), 16 * KB_XYZ, D_XYZ, G(Lv.xyz_w[0]), D_TR_IN, dl);
+        if (D_AMB > 0) L.add(DA(act::T), TR_H, TR_H, AC(act::PEW), 16 * KB_AMB, D_AMB, G(Lv.xyz_w[0]) + D_XYZ, D_TR_IN);
+        defer_add(dl, G(Lv.xyz_b[0]), TR_H);
+        defer_consts(Lv.xyz_w[0], D_TR_IN, TR_H, D_XYZ + D_AMB, D_TR_CONST, dl, trc, d_trc);
+    }
+    if (b.err) return b.err;
+    e = L.launch(P, b.zero, num_cu, stream);
+    if (e) return e;
+    b.flush_deferred();
+    return b.err;
+}
+
+static int fused_def(const float *flat, const float *frame, long P, const float *actbuf, const uint32_t *bits, const float *xwg, float *grad_flat,
+                     float *grad_cond, float *ws, int num_cu, hipStream_t stream)
+{
+    Bwd b{stream, P};
+    const FlatOffsets &F = kFlat;
+    float *dact = ws, *g3 = dact + P * DEF_PLANES, *dw4 = g3 + P * 4, *db = dw4 + P * 4, *bstream = db + DB_SCRATCH;
+    b.zero = db + DB_SCRATCH - 64;
+    if (hipMemsetAsync(db, 0, sizeof(float) * DB_SCRATCH, stream) != hipSuccess) return (int)hipGetLastError();
+    int e = sahs_bwd_chain_pack_launch(flat, bstream, 0, 1, stream);
+    if (e) return e;
+    e = sahs_bwd_chain_def_launch(bstream, P, xwg, actbuf, bits, dact, g3, dw4, num_cu, stream);
+    if (e) return e;
+    auto AC = [&](int c) { return actbuf + (long)c * P; };
+    auto DA = [&](int c) { return dact + (long)c * P; };
+    auto G = [&](long off) { return grad_flat + off; };
+    const float *p36 = frame + FRAME_POSE_OFF, *drv = frame + FRAME_DRV_OFF;
+    float *d_drv = grad_cond + 0, *d_p36 = grad_cond + 80;
+    int dbo = 0;
+    auto scratch_db = [&](int n) { float *p = db + dbo; dbo += (n + 3) / 4 * 4; return p; };
+    auto defer_add = [&](const float *src, float *dst, int n) { if (b.naxpy < MAX_AXPY_JOBS) b.axpys.j[b.naxpy++] = AxpyJob{src, dst, n}; else if (!b.err) b.err = (int)hipErrorOutOfMemory; };
+    auto defer_consts = [&](long woff, long ld, int rows, int col0, int cols, const float *dbl, const float *c, float *dc) {
+        if (b.nconst < MAX_CONST_JOBS) {
+            b.consts.j[b.nconst++] = ConstJob{flat + woff, G(woff), dbl, c, dc, ld, rows, cols, col0};
+            b.const_maxcols = cols > b.const_maxcols ? cols : b.const_maxcols;
+        } else if (!b.err) b.err = (int)hipErrorOutOfMemory;
+    };
+    TnList L;
+    auto net = [&](const float *head_dy, int head_rows, long fw, long fb, const long *w, const long *bs, int Hn, int col) {
+        L.add(head_dy, 4, head_rows, AC(col + 5 * Hn), Hn, Hn, G(fw), Hn, G(fb));
+        for (int i = 5; i >= 1; --i) {
+            const long ldw = (i == 4) ? Hn + D_DEF_IN : Hn;
+            float *dl = (i == 4) ? scratch_db(Hn) : G(bs[i]);
+            L.add(DA(col + i * Hn), Hn, Hn, AC(col + (i - 1) * Hn), Hn, Hn, G(w[i]), ldw, dl);
+            if (i == 4) {
+                L.add(DA(col + 4 * Hn), Hn, Hn, AC(act::E), 16 * KB_XYZ, D_XYZ, G(w[4]) + Hn, ldw);
+                defer_add(dl, G(bs[4]), Hn);
+                defer_consts(w[4], ldw, Hn, Hn + D_XYZ, D_DRV, dl, drv, d_drv);
+                defer_consts(w[4], ldw, Hn, Hn + D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);
+            }
+        }
+        float *dl = scratch_db(Hn);
+        L.add(DA(col), Hn, Hn, AC(act::E), 16 * KB_XYZ, D_XYZ, G(w[0]), D_DEF_IN, dl);
+        defer_add(dl, G(bs[0]), Hn);
+        defer_consts(w[0], D_DEF_IN, Hn, D_XYZ, D_DRV, dl, drv, d_drv);
+        defer_consts(w[0], D_DEF_IN, Hn, D_XYZ + D_DRV, D_POSE, dl, p36, d_p36);
+    };
+    net(dw4, AMB_DIM, F.hyp_fw, F.hyp_fb, F.hyp_w, F.hyp_b, HYP_H, act::HH);
+    net(g3, 3, F.warp_fw, F.warp_fb, F.warp_w, F.warp_b, WARP_H, act::WH);
+    if (b.err) return b.err;
+    e = L.launch(P, b.zero, num_cu, stream);
+    if (e) return e;
+    b.flush_deferred();
+    return b.err;
+}
+
+extern "C" int sahs_field_backward_fused_launch(const float *flat, const float *frame, int level, int part, long P, const float *actbuf,
+                                                const uint32_t *bits, const float *d_raw, const float *xwg_in, float *xwg_out, float *grad_flat,
+                                                float *grad_cond, float *ws, int num_cu, hipStream_t stream)
+{
+    if (P <= 0) return 0;
+    if (P > 4000000L) return -3;      // 32-bit byte offsets inside a plane (256 floats per sample)
+    if (part == 1) return fused_def(flat, frame, P, actbuf, bits, xwg_in, grad_flat, grad_cond, ws, num_cu, stream);
+    if (part == 2) return fused_rad(flat, frame, level, P, actbuf, bits, d_raw, xwg_out, grad_flat, grad_cond, ws, num_cu, stream);
+    if (part != 3) return -2;
+    // everything: the radiance part's seam gradient (+ xwg_in, the fine pass's share when the deformation was shared) feeds the deformation part
+    float *seam = ws + FusedWs::rad(P), *ws_def = seam + P * 8;
+    int e = fused_rad(flat, frame, level, P, actbuf, bits + (long)sbits::BD_WORDS * P, d_raw, seam, grad_flat, grad_cond, ws, num_cu, stream);
+    if (e) return e;
+    if (xwg_in != nullptr) {
+        add_rows8_kernel<<<2048, 256, 0, stream>>>(P * 2, xwg_in, seam);
+        if ((e = (int)hipGetLastError())) return e;
+    }
+    return fused_def(flat, frame, P, actbuf, bits, seam, grad_flat, grad_cond, ws_def, num_cu, stream);
+}
+#endif      // SAHS_MODEL == 0

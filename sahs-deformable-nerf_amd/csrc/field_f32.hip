@@ -108,9 +108,11 @@ __device__ __forceinline__ f32x4 act4(f32x4 v, float slope)   // slope in [0,1]:
 // two independent accumulation chains alternate (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
 template <int KB0, int KB1, int NT, int NEXT>
 __device__ __forceinline__ void dense(Ctx &cx, const f32x4 *in0, const f32x4 *in1, f32x4 *out, int bias_off, bool accum, float slope,
-                                      float *save = nullptr)   // save: this lane's slot of the layer's saved-activation block, or null
+                                      float *save = nullptr,     // save: this lane's slot of the layer's saved-activation block, or null
+                                      uint32_t *bsave = nullptr) // bsave: this lane's word(s) of the layer's sign-bit plane (sahs_layout.hpp: sbits), or null
 {
     constexpr int KB = KB0 + KB1;
+    uint32_t sgn = 0u;                                 // sign nibble of the even tile of a pair, until its odd partner completes the byte
     constexpr int G = pick_G(KB, NT);
     constexpr int NCH = NT / G;
     constexpr int PAIR = (G >= 2) ? 2 : 1;             // tiles interleaved
@@ -145,6 +147,13 @@ __device__ __forceinline__ void dense(Ctx &cx, const f32x4 *in0, const f32x4 *in
                 asm volatile("" : "+v"(o));     // pin: keep the finished tile from being sunk into the next layer
                 out[t] = o;
                 if (save != nullptr) *reinterpret_cast<f32x4 *>(save + 16 * t) = o;
+                if (bsave != nullptr) {      // nibble t of this lane's sign word(s): bit r = value r of tile t is > 0; one byte store per tile pair
+                    uint32_t nib = 0u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nib |= (o[r] > 0.0f) ? (1u << r) : 0u;
+                    if ((t & 1) == 0 && t + 1 < NT) sgn = nib;
+                    else reinterpret_cast<unsigned char *>(bsave)[t >> 1] = (unsigned char)((t & 1) ? (sgn | (nib << 4)) : nib);
+                }
             }
         }
 #pragma unroll
@@ -268,7 +277,7 @@ __global__ void __launch_bounds__(F32_THREADS, 2)
 field_forward_f32_kernel(const float *__restrict__ packed, const float *__restrict__ frame, int level, long P, int S,
                          const float *__restrict__ rays, int ray_stride, const float *__restrict__ zvals,
                          float *__restrict__ raw, float *__restrict__ dbg, float *__restrict__ actbuf,
-                         float *__restrict__ xw, int xw_row, int xw_col0, const int *__restrict__ src)
+                         float *__restrict__ xw, int xw_row, int xw_col0, const int *__restrict__ src, uint32_t *__restrict__ bits)
 {
 #if SAHS_MODEL == 2
     static_assert(MODE == FIELD_ALL, "this model has no deformation nets to split off");
@@ -317,6 +326,12 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         if constexpr (SAVE) asm volatile("" : "+s"(Psv));
 #define SVP(c, w) (actbuf + (long)(c) * Psv + p * (long)(w) + 4 * q)
 #define SV(c, w) (sv_on ? SVP(c, w) : nullptr)
+        // sign-bit planes (sbits): this lane's NW = w / 128 (at least 1) words of plane b; a whole-network save holds [deformation | radiance] planes
+        const bool sb_on = sv_on && bits != nullptr;
+        uint32_t *const bits_r = bits + (MODE == FIELD_ALL ? (long)sbits::BD_WORDS * Psv : 0L);
+        const uint32_t sb_lane = (uint32_t)(p * 4 + q);      // (a uniform plane base + a 32-bit lane offset: one live register, not a pointer pair)
+#define SBD(b, w) (sb_on ? bits + (long)(b) * Psv + sb_lane * (uint32_t)((w) >= 128 ? (w) / 128 : 1) : nullptr)
+#define SBR(b, w) (sb_on ? bits_r + (long)(b) * Psv + sb_lane * (uint32_t)((w) >= 128 ? (w) / 128 : 1) : nullptr)
         float x[3] = {0.0f, 0.0f, 0.0f};
         if constexpr (MODE != FIELD_RADIANCE) {
             const float *rp = rays + (p / S) * ray_stride;
@@ -348,23 +363,23 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         // ---- warp field: dx = tanh(MLP) (modules.py:371-390) ----
         {
             f32x4 h[8], hn[8];
-            dense<KB_XYZ, 0, 8, CHF(L_W1)>(cx, pe_x, nullptr, h, Ly[L_W0].bias_off, false, 0.0f, SV(act::WH, 128));
+            dense<KB_XYZ, 0, 8, CHF(L_W1)>(cx, pe_x, nullptr, h, Ly[L_W0].bias_off, false, 0.0f, SV(act::WH, 128), SBD(sbits::BD_WH + 4 * (0), 128));
             // W1..W3; the chunk after each is W2, W3, W4B.  One rolled loop where those have the same size (AudioFaceModel: 32 KB)
             constexpr int W_ROLLED = (CHF(L_W4B) == CHF(L_W2)) ? 3 : 2;
 #pragma unroll 1
             for (int l = 0; l < W_ROLLED; ++l) {
-                dense<8, 0, 8, CHF(L_W2)>(cx, h, nullptr, hn, Ly[L_W1].bias_off + 128 * l, false, 0.0f, SV(act::WH + 128 * (l + 1), 128));
+                dense<8, 0, 8, CHF(L_W2)>(cx, h, nullptr, hn, Ly[L_W1].bias_off + 128 * l, false, 0.0f, SV(act::WH + 128 * (l + 1), 128), SBD(sbits::BD_WH + 4 * ((l + 1)), 128));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) h[i] = hn[i];
             }
             if (W_ROLLED == 2) {
-                dense<8, 0, 8, CHF(L_W4B)>(cx, h, nullptr, hn, Ly[L_W3].bias_off, false, 0.0f, SV(act::WH + 128 * 3, 128));
+                dense<8, 0, 8, CHF(L_W4B)>(cx, h, nullptr, hn, Ly[L_W3].bias_off, false, 0.0f, SV(act::WH + 128 * 3, 128), SBD(sbits::BD_WH + 4 * (3), 128));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) h[i] = hn[i];
             }
             dense<KB_XYZ, 0, 8, CHF(L_W4A)>(cx, pe_x, nullptr, hn, Ly[L_W4B].bias_off, false, 1.0f);
-            dense<8, 0, 8, CHF(L_W5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::WH + 4 * 128, 128));
-            dense<8, 0, 8, CHF(L_WF)>(cx, hn, nullptr, h, Ly[L_W5].bias_off, false, 0.0f, SV(act::WH + 5 * 128, 128));
+            dense<8, 0, 8, CHF(L_W5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::WH + 4 * 128, 128), SBD(sbits::BD_WH + 4 * (4), 128));
+            dense<8, 0, 8, CHF(L_WF)>(cx, hn, nullptr, h, Ly[L_W5].bias_off, false, 0.0f, SV(act::WH + 5 * 128, 128), SBD(sbits::BD_WH + 4 * (5), 128));
             f32x4 o[1];
             dense<8, 0, 1, CHF(L_H0)>(cx, h, nullptr, o, Ly[L_WF].bias_off, false, 1.0f);
             if (q == 0) {
@@ -379,22 +394,22 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         // ---- hyper sheet: ambient w (modules.py:444-462) ----
         {
             f32x4 h[4], hn[4];
-            dense<KB_XYZ, 0, 4, CHF(L_H1)>(cx, pe_x, nullptr, h, Ly[L_H0].bias_off, false, 0.0f, SV(act::HH, 64));
+            dense<KB_XYZ, 0, 4, CHF(L_H1)>(cx, pe_x, nullptr, h, Ly[L_H0].bias_off, false, 0.0f, SV(act::HH, 64), SBD(sbits::BD_HH + 4 * (0), 64));
             constexpr int H_ROLLED = (CHF(L_H4B) == CHF(L_H2)) ? 3 : 2;   // H1..H3 (next chunks: H2, H3, H4B)
 #pragma unroll 1
             for (int l = 0; l < H_ROLLED; ++l) {
-                dense<4, 0, 4, CHF(L_H2)>(cx, h, nullptr, hn, Ly[L_H1].bias_off + 64 * l, false, 0.0f, SV(act::HH + 64 * (l + 1), 64));
+                dense<4, 0, 4, CHF(L_H2)>(cx, h, nullptr, hn, Ly[L_H1].bias_off + 64 * l, false, 0.0f, SV(act::HH + 64 * (l + 1), 64), SBD(sbits::BD_HH + 4 * ((l + 1)), 64));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) h[i] = hn[i];
             }
             if (H_ROLLED == 2) {
-                dense<4, 0, 4, CHF(L_H4B)>(cx, h, nullptr, hn, Ly[L_H3].bias_off, false, 0.0f, SV(act::HH + 64 * 3, 64));
+                dense<4, 0, 4, CHF(L_H4B)>(cx, h, nullptr, hn, Ly[L_H3].bias_off, false, 0.0f, SV(act::HH + 64 * 3, 64), SBD(sbits::BD_HH + 4 * (3), 64));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) h[i] = hn[i];
             }
             dense<KB_XYZ, 0, 4, CHF(L_H4A)>(cx, pe_x, nullptr, hn, Ly[L_H4B].bias_off, false, 1.0f);
-            dense<4, 0, 4, CHF(L_H5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::HH + 4 * 64, 64));
-            dense<4, 0, 4, CHF(L_HF)>(cx, hn, nullptr, h, Ly[L_H5].bias_off, false, 0.0f, SV(act::HH + 5 * 64, 64));
+            dense<4, 0, 4, CHF(L_H5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::HH + 4 * 64, 64), SBD(sbits::BD_HH + 4 * (4), 64));
+            dense<4, 0, 4, CHF(L_HF)>(cx, hn, nullptr, h, Ly[L_H5].bias_off, false, 0.0f, SV(act::HH + 5 * 64, 64), SBD(sbits::BD_HH + 4 * (5), 64));
             f32x4 o[1];
             dense<4, 0, 1, (MODE == FIELD_DEFORM ? CHF(L_FIRST) : CHF(L_T0))>(cx, h, nullptr, o, Ly[L_HF].bias_off, false, 1.0f);
             if (q == 0) {      // rows 0..AMB_DIM-1 of the one output tile
@@ -432,14 +447,14 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                     for (int b = 0; b < KB_XYZ + KB_AMB; ++b)
                         *reinterpret_cast<f32x4 *>(b < KB_XYZ ? SVP(act::PEX, 16 * KB_XYZ) + 16 * b : SVP(act::PEW, 16 * KB_AMB) + 16 * (b - KB_XYZ)) = in_tr[b];
                 }
-                dense<KB_XYZ, KB_AMB, 16, CHF(L_T1)>(cx, in_tr, in_tr + KB_XYZ, h, Ly[L_T0].bias_off, false, 0.01f, SV(act::T, 256));
+                dense<KB_XYZ, KB_AMB, 16, CHF(L_T1)>(cx, in_tr, in_tr + KB_XYZ, h, Ly[L_T0].bias_off, false, 0.01f, SV(act::T, 256), SBR(sbits::BR_T + 8 * (0), 256));
             }
             if (dump) dsl[5] = h[0][0];
-            dense<16, 0, 16, CHF(L_T2)>(cx, h, nullptr, feat, Ly[L_T1].bias_off, false, 0.01f, SV(act::T + 256, 256));
+            dense<16, 0, 16, CHF(L_T2)>(cx, h, nullptr, feat, Ly[L_T1].bias_off, false, 0.01f, SV(act::T + 256, 256), SBR(sbits::BR_T + 8 * (1), 256));
             if (dump) dsl[6] = feat[0][0];
 #pragma unroll
             for (int i = 0; i < 16; ++i) h[i] = feat[i];
-            dense<16, 0, 16, CHF(L_T3B)>(cx, h, nullptr, feat, Ly[L_T2].bias_off, false, 0.01f, SV(act::T + 512, 256));
+            dense<16, 0, 16, CHF(L_T3B)>(cx, h, nullptr, feat, Ly[L_T2].bias_off, false, 0.01f, SV(act::T + 512, 256), SBR(sbits::BR_T + 8 * (2), 256));
             if (dump) dsl[7] = feat[0][0];
 #pragma unroll
             for (int i = 0; i < 16; ++i) h[i] = feat[i];
@@ -455,9 +470,9 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                 dense<KB_XYZ, KB_AMB, 16, CHF(L_T3A)>(cx, in_tr, in_tr + KB_XYZ, feat, Ly[L_T3B].bias_off, false, 1.0f);
             }
 #if SAHS_MODEL == 0
-            dense<16, 0, 16, CHF(L_T4)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768, 256));
+            dense<16, 0, 16, CHF(L_T4)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768, 256), SBR(sbits::BR_T + 8 * (3), 256));
 #else           // 4-layer trunk: the skip layer is the last one, fc_feat follows
-            dense<16, 0, 16, CHF(L_FEAT)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768, 256));
+            dense<16, 0, 16, CHF(L_FEAT)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768, 256), SBR(sbits::BR_T + 8 * (3), 256));
 #endif
             if (dump) dsl[8] = feat[0][0];
 #pragma unroll
@@ -465,7 +480,7 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
 #if SAHS_MODEL == 0
 #pragma unroll 1
             for (int l = 4; l <= 7; ++l) {     // T4..T7 (next chunks: T5, T6, T7, FEAT, all 32 KB)
-                dense<16, 0, 16, CHF(L_T5)>(cx, h, nullptr, feat, Ly[L_T4].bias_off + 256 * (l - 4), false, 0.01f, SV(act::T + 256 * l, 256));
+                dense<16, 0, 16, CHF(L_T5)>(cx, h, nullptr, feat, Ly[L_T4].bias_off + 256 * (l - 4), false, 0.01f, SV(act::T + 256 * l, 256), SBR(sbits::BR_T + 8 * (l), 256));
                 if (dump) dsl[5 + l] = feat[0][0];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) h[i] = feat[i];
@@ -496,15 +511,15 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
             }
             f32x4 c[8], cn[8];
             dense<2, 2, 8, CHF(L_D0A)>(cx, in_d, in_d + 2, c, Ly[L_D0B].bias_off, false, 1.0f);
-            dense<16, 0, 8, CHF(L_D1)>(cx, feat, nullptr, c, 0, true, 0.01f, SV(act::C, 128));
+            dense<16, 0, 8, CHF(L_D1)>(cx, feat, nullptr, c, 0, true, 0.01f, SV(act::C, 128), SBR(sbits::BR_C + 4 * (0), 128));
             if (dump) dsl[14] = c[0][0];
 #pragma unroll 1
             for (int l = 0; l < 2; ++l) {      // D1, D2
-                dense<8, 0, 8, CHF(L_D2)>(cx, c, nullptr, cn, Ly[L_D1].bias_off + 128 * l, false, 0.01f, SV(act::C + 128 * (l + 1), 128));
+                dense<8, 0, 8, CHF(L_D2)>(cx, c, nullptr, cn, Ly[L_D1].bias_off + 128 * l, false, 0.01f, SV(act::C + 128 * (l + 1), 128), SBR(sbits::BR_C + 4 * ((l + 1)), 128));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) c[i] = cn[i];
             }
-            dense<8, 0, 8, CHF(L_RGB)>(cx, c, nullptr, cn, Ly[L_D3].bias_off, false, 0.01f, SV(act::C + 384, 128));
+            dense<8, 0, 8, CHF(L_RGB)>(cx, c, nullptr, cn, Ly[L_D3].bias_off, false, 0.01f, SV(act::C + 384, 128), SBR(sbits::BR_C + 4 * (3), 128));
             if (dump) dsl[15] = cn[0][0];
             dense<8, 0, 1, CHF(L_S0)>(cx, cn, nullptr, fin, 0, true, 1.0f);
             if (dbg != nullptr && p_raw < P) *reinterpret_cast<f32x4 *>(dsl + 40 + 4 * q) = fin[0];
@@ -512,15 +527,15 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         // ---- seg branch (modules.py:289-294) ----
         {
             f32x4 s[8], sn[8];
-            dense<16, 0, 8, CHF(L_S1)>(cx, feat, nullptr, s, Ly[L_S0].bias_off, false, 0.01f, SV(act::S, 128));
+            dense<16, 0, 8, CHF(L_S1)>(cx, feat, nullptr, s, Ly[L_S0].bias_off, false, 0.01f, SV(act::S, 128), SBR(sbits::BR_S + 4 * (0), 128));
             if (dump) dsl[16] = s[0][0];
 #pragma unroll 1
             for (int l = 0; l < 2; ++l) {      // S1, S2
-                dense<8, 0, 8, CHF(L_S2)>(cx, s, nullptr, sn, Ly[L_S1].bias_off + 128 * l, false, 0.01f, SV(act::S + 128 * (l + 1), 128));
+                dense<8, 0, 8, CHF(L_S2)>(cx, s, nullptr, sn, Ly[L_S1].bias_off + 128 * l, false, 0.01f, SV(act::S + 128 * (l + 1), 128), SBR(sbits::BR_S + 4 * ((l + 1)), 128));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s[i] = sn[i];
             }
-            dense<8, 0, 8, CHF(L_SEG)>(cx, s, nullptr, sn, Ly[L_S3].bias_off, false, 0.01f, SV(act::S + 384, 128));
+            dense<8, 0, 8, CHF(L_SEG)>(cx, s, nullptr, sn, Ly[L_S3].bias_off, false, 0.01f, SV(act::S + 384, 128), SBR(sbits::BR_S + 4 * (3), 128));
             if (dump) dsl[17] = sn[0][0];
             dense<8, 0, 1, CHF(L_START)>(cx, sn, nullptr, fin, 0, true, 1.0f);
         }
@@ -535,7 +550,8 @@ using namespace SAHS_NS;
 // dbg (optional, may be null): [P x 24: see DBG_STRIDE][P x 32: grid features]
 template <bool SAVE, int MODE>
 static int launch_field(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride, const float *zvals,
-                        float *raw, float *dbg, float *actbuf, float *xw, int xw_row, int xw_col0, const int *src, int num_cu, hipStream_t stream)
+                        float *raw, float *dbg, float *actbuf, float *xw, int xw_row, int xw_col0, const int *src, int num_cu, hipStream_t stream,
+                        uint32_t *bits = nullptr)
 {
     const long ntiles = (P + F32_PTS_PER_WG - 1) / F32_PTS_PER_WG;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
@@ -547,7 +563,7 @@ static int launch_field(const float *packed, const float *frame, int level, long
     });
     if (ae != hipSuccess) return (int)ae;
     field_forward_f32_kernel<SAVE, MODE><<<grid, F32_THREADS, lds_bytes, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, actbuf,
-                                                                                   xw, xw_row, xw_col0, src);
+                                                                                   xw, xw_row, xw_col0, src, bits);
     return (int)hipGetLastError();
 }
 
@@ -566,9 +582,21 @@ extern "C" int SAHS_SYM(sahs_field_forward_f32_launch)(const float *packed, cons
 // actbuf != nullptr: also save the activations of the layers the launch runs (training).  A saved array of act:: column c starts at
 // actbuf + c * P as for whole-network launches, so a radiance-only launch touches columns >= act::XW only and a deformation-only launch
 // columns < act::XW + 16: the caller may pass a base such that only that range is backed by memory (sahs_layout_act_part_words).
+// bits (with actbuf): the sign-bit planes of the layers the launch runs (sahs_layout.hpp: sbits; mode 0: [deformation | radiance] planes),
+// (P * sahs_layout_bits_part_words(mode)) 32-bit words, or null
+extern "C" int SAHS_SYM(sahs_field_forward_f32_split_bits_launch)(const float *packed, const float *frame, int level, int mode, long P, int S,
+                                                   const float *rays, int ray_stride, const float *zvals, float *raw, float *xw, int xw_row,
+                                                   int xw_col0, const int *src, float *actbuf, uint32_t *bits, int num_cu, hipStream_t stream);
 extern "C" int SAHS_SYM(sahs_field_forward_f32_split_launch)(const float *packed, const float *frame, int level, int mode, long P, int S,
                                                    const float *rays, int ray_stride, const float *zvals, float *raw, float *xw, int xw_row,
                                                    int xw_col0, const int *src, float *actbuf, int num_cu, hipStream_t stream)
+{
+    return SAHS_SYM(sahs_field_forward_f32_split_bits_launch)(packed, frame, level, mode, P, S, rays, ray_stride, zvals, raw, xw, xw_row, xw_col0, src, actbuf,
+                                                              nullptr, num_cu, stream);
+}
+extern "C" int SAHS_SYM(sahs_field_forward_f32_split_bits_launch)(const float *packed, const float *frame, int level, int mode, long P, int S,
+                                                   const float *rays, int ray_stride, const float *zvals, float *raw, float *xw, int xw_row,
+                                                   int xw_col0, const int *src, float *actbuf, uint32_t *bits, int num_cu, hipStream_t stream)
 {
     if (P <= 0) return 0;
 #if SAHS_MODEL == 2
@@ -576,11 +604,11 @@ extern "C" int SAHS_SYM(sahs_field_forward_f32_split_launch)(const float *packed
 #else
     if (actbuf != nullptr) {
         if (mode == FIELD_ALL)
-            return launch_field<true, FIELD_ALL>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, nullptr, actbuf, xw, xw_row, xw_col0, nullptr, num_cu, stream);
+            return launch_field<true, FIELD_ALL>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, nullptr, actbuf, xw, xw_row, xw_col0, nullptr, num_cu, stream, bits);
         if (mode == FIELD_DEFORM)
-            return launch_field<true, FIELD_DEFORM>(packed, frame, level, P, S, rays, ray_stride, zvals, nullptr, nullptr, actbuf, xw, xw_row, xw_col0, nullptr, num_cu, stream);
+            return launch_field<true, FIELD_DEFORM>(packed, frame, level, P, S, rays, ray_stride, zvals, nullptr, nullptr, actbuf, xw, xw_row, xw_col0, nullptr, num_cu, stream, bits);
         if (mode == FIELD_RADIANCE)
-            return launch_field<true, FIELD_RADIANCE>(packed, frame, level, P, S, rays, ray_stride, nullptr, raw, nullptr, actbuf, xw, xw_row, 0, src, num_cu, stream);
+            return launch_field<true, FIELD_RADIANCE>(packed, frame, level, P, S, rays, ray_stride, nullptr, raw, nullptr, actbuf, xw, xw_row, 0, src, num_cu, stream, bits);
         return -2;
     }
     if (mode == FIELD_ALL)
@@ -597,3 +625,5 @@ extern "C" int SAHS_SYM(sahs_field_forward_f32_split_launch)(const float *packed
 // range: part 0 whole network [0, STRIDE); 1 deformation nets [0, XW + 16); 2 radiance nets [XW, STRIDE)
 extern "C" int SAHS_SYM(sahs_layout_act_part_words)(int part) { return part == 1 ? act::XW + 16 : (part == 2 ? act::STRIDE - act::XW : act::STRIDE); }
 extern "C" int SAHS_SYM(sahs_layout_act_part_col0)(int part) { return part == 2 ? act::XW : 0; }
+// 32-bit words per sample of the sign-bit planes of `part` (0: both, deformation planes first)
+extern "C" int SAHS_SYM(sahs_layout_bits_part_words)(int part) { return part == 1 ? sbits::BD_WORDS : (part == 2 ? sbits::BR_WORDS : sbits::BD_WORDS + sbits::BR_WORDS); }

@@ -426,3 +426,26 @@ constexpr int S = C + 4 * 128;          // seg hidden s0..s3, 4 x 128
 constexpr int STRIDE = S + 4 * 128;     // sum of the array widths; AudioFaceModel: 4752 floats = 19 KB per sample
 }  // namespace act
 }  // namespace SAHS_NS
+
+// =============================================================================================
+// Sign-bit planes (round 4): field_forward_f32_kernel<SAVE> also writes, for every (leaky-)ReLU layer, which of its outputs are > 0 --
+// the derivative mask of the backward chain (field_bwd_fused.hip), 1 bit instead of the 32 of the saved activation.  One plane per
+// layer, [P][4 q][NW] 32-bit words: the lane that holds features 16 t + 4 q + r (r = 0..3) of every 16-row tile t of its sample sets
+// bit 4 t + r of ITS OWN word(s) -- no cross-lane work in the forward; NW = NT / 8 words (at least 1).  The chain kernel's lane
+// (sample, h) reads words q = h and q = 2 + h: its 16 values of 32-row tile T are features 32 T + 8 g + 4 h + i, i.e. 16-row tile
+// 2 T + (g >> 1), q = 2 (g & 1) + h, r = i: bit 8 T + 4 (g >> 1) + i of word (g & 1 ? 2 + h : h).
+// A part's planes start at word offset B*_ * P of that part's bits buffer (deformation nets / radiance nets; a whole-network save
+// holds [deformation planes][radiance planes]).
+// =============================================================================================
+namespace SAHS_NS {
+namespace sbits {
+constexpr int words(int width) { return 4 * ((width / 16 + 7) / 8); }      // per sample: 256 -> 8, 128 -> 4, 64 -> 4
+constexpr int BD_WH = 0;                                                    // warp hidden h0..h5
+constexpr int BD_HH = BD_WH + (USE_DEFORM ? 6 * words(WARP_H) : 0);         // hyper hidden g0..g5
+constexpr int BD_WORDS = BD_HH + (USE_DEFORM ? 6 * words(HYP_H) : 0);       // 48 words per sample
+constexpr int BR_T = 0;                                                     // trunk t0..
+constexpr int BR_C = BR_T + TR_LAYERS * words(TR_H);                        // colour hidden c0..c3
+constexpr int BR_S = BR_C + 4 * words(BR_H);                                // seg hidden s0..s3
+constexpr int BR_WORDS = BR_S + 4 * words(BR_H);                            // 96 words per sample (AudioFaceModel)
+}  // namespace sbits
+}  // namespace SAHS_NS

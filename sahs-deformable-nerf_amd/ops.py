@@ -386,9 +386,18 @@ def field_backward(flat, frame, level, act, d_raw, grad_flat, grad_cond, arch="a
     check(f(_p(flat), _p(frame), int(level), P, _p(act), _p(d_raw), _p(grad_flat), _p(grad_cond), _p(ws), _stream()), name)
 
 
-def field_forward_split_save(packed, frame, level, mode, rays, xw, z=None, src=None, xw_col0=0, arch="audio"):
+def alloc_sign_bits(num_samples, mode, arch, device):
+    """Buffer for the sign-bit planes a saving forward of `mode` writes beside the activations (include/sahs_nerf.h:
+    sahs_model_field_forward_split_save_bits) -- the derivative masks of the fused backward walk; None where the architecture's backward
+    does not read them."""
+    words = int(_fn("bits_words_part", arch)[0](int(mode)))
+    return torch.empty(int(num_samples), words, dtype=torch.int32, device=device) if words > 0 else None
+
+
+def field_forward_split_save(packed, frame, level, mode, rays, xw, z=None, src=None, xw_col0=0, arch="audio", bits=None):
     """field_forward_split (fp32) that also keeps the activations of the layers it runs -> (raw or None, act).  act is the part's
-    own buffer, (P, act_words_part(mode)) floats as dense per-layer planes; only field_backward_split of the same part reads it."""
+    own buffer, (P, act_words_part(mode)) floats as dense per-layer planes; only field_backward_split of the same part reads it.
+    bits (from alloc_sign_bits, same mode): also filled -- hand it to field_backward_split with act."""
     packed, frame, rays, z = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays"), _req(z, "z")
     src, xw = _req(src, "src", torch.int32), _req(xw, "xw")
     N = rays.shape[0]
@@ -397,13 +406,34 @@ def field_forward_split_save(packed, frame, level, mode, rays, xw, z=None, src=N
         raise _lib.SahsError("xw must be (N, row, 8)")
     raw = None if mode == FIELD_DEFORM else torch.empty(N, S, 16, dtype=torch.float32, device=rays.device)
     act = torch.empty(N * S, _fn("act_words_part", arch)[0](int(mode)), dtype=torch.float32, device=rays.device)
+    if bits is not None:
+        bits = _req(bits, "bits", torch.int32)
+        if tuple(bits.shape) != (N * S, int(_fn("bits_words_part", arch)[0](int(mode)))):
+            raise _lib.SahsError("field_forward_split_save: bits must come from alloc_sign_bits(N * S, mode, arch, device)")
+        f, name = _fn("field_forward_split_save_bits", arch)
+        check(f(_p(packed), _p(frame), int(level), int(mode), N, int(S), _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(xw), int(xw.shape[1]), int(xw_col0),
+                _p(src), _p(act), _p(bits), _stream()), name)
+        return raw, act
     f, name = _fn("field_forward_split_save", arch)
     check(f(_p(packed), _p(frame), int(level), int(mode), N, int(S), _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(xw), int(xw.shape[1]), int(xw_col0),
             _p(src), _p(act), _stream()), name)
     return raw, act
 
 
-def field_backward_split(flat, frame, level, part, act, grad_flat, grad_cond, d_raw=None, xw_grad_in=None, arch="audio", full_act=False):
+def fused_backward(enable=None):
+    """The fused backward walk (one data-gradient chain launch + one weight-gradient launch per part: include/sahs_nerf.h,
+    sahs_model_field_backward_fused) is taken whenever a backward is given sign bits, the architecture has it and the backward arithmetic is
+    "bf16x3"; fused_backward(False) keeps the per-layer walk (the A/B reference).  None queries."""
+    global _FUSED_BACKWARD
+    if enable is not None:
+        _FUSED_BACKWARD = bool(enable)
+    return _FUSED_BACKWARD
+
+
+_FUSED_BACKWARD = os.environ.get("SAHS_BWD_FUSED", "1") != "0"
+
+
+def field_backward_split(flat, frame, level, part, act, grad_flat, grad_cond, d_raw=None, xw_grad_in=None, arch="audio", full_act=False, bits=None):
     """Backward of `part` (FIELD_DEFORM, FIELD_RADIANCE, or 3 = everything) of the field over activations saved by the forward of that
     part.  The seam is d loss / d (x', w), (P,8): FIELD_RADIANCE returns it (the only part that writes one), FIELD_DEFORM starts from
     xw_grad_in, 3 adds xw_grad_in.  full_act: `act` was saved by a WHOLE-network forward and only `part` of it is walked (a saved array of
@@ -423,6 +453,20 @@ def field_backward_split(flat, frame, level, part, act, grad_flat, grad_cond, d_
     if xw_grad_in is not None and xw_grad_in.numel() != P * 8:
         raise _lib.SahsError("field_backward_split: xw_grad_in must hold (P,8)")
     out = torch.empty(P, 8, dtype=torch.float32, device=act.device) if part == FIELD_RADIANCE else None
+    if bits is not None and _FUSED_BACKWARD and arch == "audio" and backward_gemm_precision() == "bf16x3":
+        bits = _req(bits, "bits", torch.int32)
+        bw = lambda m: int(_fn("bits_words_part", arch)[0](int(m)))
+        saved_mode = 0 if (full_act or int(part) == 3) else int(part)
+        if tuple(bits.shape) != (P, bw(saved_mode)):
+            raise _lib.SahsError("field_backward_split: bits were not written by the forward that saved these activations")
+        # a whole-network save holds [deformation planes | radiance planes]; part 3 takes both, a part of it its own
+        bits_ptr = ctypes.c_void_p(bits.data_ptr() + (4 * bw(FIELD_DEFORM) * P if (full_act and int(part) == FIELD_RADIANCE) else 0))
+        words = int(_fn("field_backward_fused_workspace_words", arch)[0](int(part), P))
+        ws = torch.empty(words, dtype=torch.float32, device=act.device)
+        f, name = _fn("field_backward_fused", arch)
+        check(f(_p(flat), _p(frame), int(level), int(part), P, act_ptr, bits_ptr, _p(d_raw), _p(xw_grad_in), _p(out), _p(grad_flat), _p(grad_cond), _p(ws),
+                _stream()), name)
+        return out
     ws = torch.empty(_fn("field_backward_workspace_words", arch)[0](P), dtype=torch.float32, device=act.device)
     f, name = _fn("field_backward_split", arch)
     check(f(_p(flat), _p(frame), int(level), int(part), P, act_ptr, _p(d_raw), _p(xw_grad_in), _p(out), _p(grad_flat), _p(grad_cond), _p(ws), _stream()), name)
@@ -614,16 +658,20 @@ class RenderRaysFn(torch.autograd.Function):
             N = rays.shape[0]
             z_c = stratified_depths(rays, num_coarse, lindisp, t_rand)
             xw = torch.empty(N, num_coarse + num_fine, 8, dtype=torch.float32, device=rays.device)
-            raw_c, act_c = field_forward_split_save(packed, frame, 0, FIELD_ALL, rays, xw, z=z_c, arch=arch)
+            sb = lambda samples, mode: alloc_sign_bits(samples, mode, arch, rays.device)      # (None: this architecture's backward reads none)
+            bits_c, bits_d, bits_r = sb(N * num_coarse, FIELD_ALL), sb(N * num_fine, FIELD_DEFORM), sb(N * (num_coarse + num_fine), FIELD_RADIANCE)
+            raw_c, act_c = field_forward_split_save(packed, frame, 0, FIELD_ALL, rays, xw, z=z_c, arch=arch, bits=bits_c)
             rgb_c, disp_c, acc_c, w_c, _ = composite_forward(raw_c, z_c, rays, noise_c, bg, white_background)
             z_f, z_new, src = resample_merge(z_c, w_c, num_fine, u=u)
-            _, act_d = field_forward_split_save(packed, frame, 1, FIELD_DEFORM, rays, xw, z=z_new, xw_col0=num_coarse, arch=arch)
-            raw_f, act_r = field_forward_split_save(packed, frame, 1, FIELD_RADIANCE, rays, xw, src=src, arch=arch)
+            _, act_d = field_forward_split_save(packed, frame, 1, FIELD_DEFORM, rays, xw, z=z_new, xw_col0=num_coarse, arch=arch, bits=bits_d)
+            raw_f, act_r = field_forward_split_save(packed, frame, 1, FIELD_RADIANCE, rays, xw, src=src, arch=arch, bits=bits_r)
             del xw
             rgb_f, disp_f, acc_f, w_f, depth_f = composite_forward(raw_f, z_f, rays, noise_f, bg, white_background)
             outs = (rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_f[:, -1].contiguous(), depth_f)
+            ctx.has_bits = bits_c is not None
             return with_loss(outs, (flat.detach(), audio.detach(), rays, z_c, z_f, frame, packed,
-                                    *[t if t is not None else none for t in (bg, noise_c, noise_f)], raw_c, act_c, raw_f, act_r, act_d, src))
+                                    *[t if t is not None else none for t in (bg, noise_c, noise_f)], raw_c, act_c, raw_f, act_r, act_d, src,
+                                    *((bits_c, bits_r, bits_d) if bits_c is not None else ())))
         if ctx.kept:     # the same launch chain as sahs_render_rays, with the field activations kept
             z_c = stratified_depths(rays, num_coarse, lindisp, t_rand)
             raw_c, act_c = field_forward_save(packed, frame, 0, rays, z_c, arch)
@@ -650,6 +698,8 @@ class RenderRaysFn(torch.autograd.Function):
             gscale = g_loss.detach().float().reshape(1).contiguous()
         kept = dict(zip((0, 1), (ctx.saved_tensors[10:12], ctx.saved_tensors[12:14]))) if ctx.kept else None
         act_d, src = (ctx.saved_tensors[14], ctx.saved_tensors[15]) if ctx.shared else (None, None)
+        bits_c, bits_r, bits_d = ctx.saved_tensors[16:19] if (ctx.shared and getattr(ctx, "has_bits", False)) else (None, None, None)
+        kept_bits = {0: bits_c, 1: bits_r}
         xwg_coarse = None      # shared deformation: the fine pass's seam gradient that belongs to the coarse samples
         nc, nf, white, has_bg, has_nc, has_nf = ctx.cfg
         bg = bg if has_bg else None
@@ -678,18 +728,19 @@ class RenderRaysFn(torch.autograd.Function):
             grad_cond_side = torch.zeros_like(grad_cond)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                g_c0 = field_backward_split(flat, frame, 0, FIELD_RADIANCE, act0, grad_flat, grad_cond_side, d_raw=d_raw0.view(-1, 16), arch=ctx.arch, full_act=True)
-            g_f = field_backward_split(flat, frame, 1, FIELD_RADIANCE, act1, grad_flat, grad_cond, d_raw=d_raw1.view(-1, 16), arch=ctx.arch)
+                g_c0 = field_backward_split(flat, frame, 0, FIELD_RADIANCE, act0, grad_flat, grad_cond_side, d_raw=d_raw0.view(-1, 16), arch=ctx.arch, full_act=True,
+                                            bits=bits_c)
+            g_f = field_backward_split(flat, frame, 1, FIELD_RADIANCE, act1, grad_flat, grad_cond, d_raw=d_raw1.view(-1, 16), arch=ctx.arch, bits=bits_r)
             xwg_coarse, g_new = route_xw_grad(src, g_f, nc)
             main.wait_stream(side)
             xwg0 = g_c0 + xwg_coarse          # the seam gradient of the coarse samples: their own radiance walk's + the fine pass's share
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                field_backward_split(flat, frame, 0, FIELD_DEFORM, act0, grad_flat, grad_cond_side, xw_grad_in=xwg0, arch=ctx.arch, full_act=True)
-            field_backward_split(flat, frame, 1, FIELD_DEFORM, act_d, grad_flat, grad_cond, xw_grad_in=g_new, arch=ctx.arch)
+                field_backward_split(flat, frame, 0, FIELD_DEFORM, act0, grad_flat, grad_cond_side, xw_grad_in=xwg0, arch=ctx.arch, full_act=True, bits=bits_c)
+            field_backward_split(flat, frame, 1, FIELD_DEFORM, act_d, grad_flat, grad_cond, xw_grad_in=g_new, arch=ctx.arch, bits=bits_d)
             main.wait_stream(side)
             grad_cond += grad_cond_side
-            for t in (d_raw0, xwg0, grad_cond_side, act0, grad_flat, flat, frame):      # made on this stream, used on the side stream: the
+            for t in (d_raw0, xwg0, grad_cond_side, act0, grad_flat, flat, frame) + ((bits_c,) if bits_c is not None else ()):      # made on this stream, used on the side stream: the
                 t.record_stream(side)                                                     # allocator must not hand them out again before it is done
             g_c0.record_stream(main)                                                      # (and the other way round)
             N = 0                             # (the block loop below has nothing left to do)
@@ -716,12 +767,13 @@ class RenderRaysFn(torch.autograd.Function):
                 d_raw = composite_backward(raw, zb, rb, nb, bgb, white, *gb, loss=lvl_loss)
                 if ctx.shared:      # (kept path: one block, sl covers every ray)
                     if level == 1:
-                        g_f = field_backward_split(flat, frame, 1, FIELD_RADIANCE, act, grad_flat, grad_cond, d_raw=d_raw.view(-1, 16), arch=ctx.arch)
+                        g_f = field_backward_split(flat, frame, 1, FIELD_RADIANCE, act, grad_flat, grad_cond, d_raw=d_raw.view(-1, 16), arch=ctx.arch, bits=kept_bits[1])
                         xwg_coarse, g_new = route_xw_grad(src, g_f, nc)
-                        field_backward_split(flat, frame, 1, FIELD_DEFORM, act_d, grad_flat, grad_cond, xw_grad_in=g_new, arch=ctx.arch)
+                        field_backward_split(flat, frame, 1, FIELD_DEFORM, act_d, grad_flat, grad_cond, xw_grad_in=g_new, arch=ctx.arch, bits=bits_d)
                         del g_f, g_new
                     else:
-                        field_backward_split(flat, frame, 0, 3, act, grad_flat, grad_cond, d_raw=d_raw.view(-1, 16), xw_grad_in=xwg_coarse, arch=ctx.arch)
+                        field_backward_split(flat, frame, 0, 3, act, grad_flat, grad_cond, d_raw=d_raw.view(-1, 16), xw_grad_in=xwg_coarse, arch=ctx.arch,
+                                             bits=kept_bits[0])
                 else:
                     field_backward(flat, frame, level, act, d_raw.view(-1, 16), grad_flat, grad_cond, ctx.arch)
                 del raw, act, d_raw

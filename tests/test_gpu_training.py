@@ -624,3 +624,89 @@ def test_two_stream_backward_matches_one_stream(arch, with_loss, weights_mod, mo
         sc = float(ga.abs().max())
         assert float((ga - gb).abs().max()) <= 2e-5 * sc + 1e-12, (name, float((ga - gb).abs().max()), sc)
         off += n
+
+
+def test_fused_backward_vs_per_layer_walks(weights_mod):
+    """The fused backward walk (one sample-major data-gradient chain + one weight-gradient launch per part, masks from the sign bits of
+    the saving forward: include/sahs_nerf.h, sahs_model_field_backward_fused) against the per-layer walk on the SAME saved activations and
+    upstream gradients -- its split-operand form (same arithmetic, other summation order) and its f32-MFMA form (the reference's
+    precision): every parameter gradient, the conditioning gradient and the seam gradients within 1e-4 of the tensor's largest entry.
+    Every part the training step uses: radiance / deformation parts of a radiance-only and a deformation-only save, both parts of a
+    whole-network save (full_act), and part 3.  Ragged sample counts (1,480 and 2,849 against 128-sample tiles and 1,024-sample ranges)."""
+    ops = pkg("ops")
+    W = weights_mod
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(19)
+    flat = torch.from_numpy(W.flatten_state_dict(W.hash_state_dict(0, 2.0, 30.0, hdr=True))).to(dev)
+    packed = ops.pack_weights(flat)
+    driving = torch.randn(16, 29, device=dev, generator=gen)
+    near, far, cam = 0.48, 1.08, 0.8
+    pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [cam]]], 1).astype(np.float32)).to(dev)
+    frame = ops.fold_conditioning(flat, driving, pose)
+    N, nc, nf = 37, 40, 37
+    Sf = nc + nf
+    rays = torch.zeros(N, 8, device=dev)
+    rays[:, 2] = cam
+    rays[:, 3:6] = torch.randn(N, 3, device=dev, generator=gen) * 0.15 + torch.tensor([0, 0, -1.0], device=dev)
+    zs = lambda S: torch.sort(torch.rand(N, S, device=dev, generator=gen) * (far - near) + near, dim=1).values
+    z_c, z_new = zs(nc), zs(nf)
+    xw = torch.empty(N, Sf, 8, device=dev)
+    src = torch.stack([torch.randperm(Sf, device=dev, generator=gen) for _ in range(N)]).to(torch.int32)
+    sb = lambda samples, mode: ops.alloc_sign_bits(samples, mode, "audio", dev)
+    bits_c, bits_d, bits_r = sb(N * nc, ops.FIELD_ALL), sb(N * nf, ops.FIELD_DEFORM), sb(N * Sf, ops.FIELD_RADIANCE)
+    assert bits_c is not None and bits_c.shape[1] == bits_d.shape[1] + bits_r.shape[1]
+    raw_c, act_c = ops.field_forward_split_save(packed, frame, 0, ops.FIELD_ALL, rays, xw, z=z_c, bits=bits_c)
+    _, act_d = ops.field_forward_split_save(packed, frame, 1, ops.FIELD_DEFORM, rays, xw, z=z_new, xw_col0=nc, bits=bits_d)
+    raw_f, act_r = ops.field_forward_split_save(packed, frame, 1, ops.FIELD_RADIANCE, rays, xw, src=src, bits=bits_r)
+    d_raw_c = torch.randn(N * nc, 16, device=dev, generator=gen)
+    d_raw_f = torch.randn(N * Sf, 16, device=dev, generator=gen)
+    seam = lambda P_: torch.randn(P_, 8, device=dev, generator=gen) * torch.tensor([1, 1, 1, 0, 1, 1, 0, 0.0], device=dev)
+    xwg_new, xwg_c = seam(N * nf), seam(N * nc)
+
+    def run(fused, prec):
+        ops.backward_gemm_precision(prec)
+        ops.fused_backward(fused)
+        out = {}
+        for name in ("split", "whole"):
+            gf, gc = torch.zeros_like(flat), torch.zeros(128, device=dev)
+            g_f = ops.field_backward_split(flat, frame, 1, ops.FIELD_RADIANCE, act_r, gf, gc, d_raw=d_raw_f, bits=bits_r)
+            ops.field_backward_split(flat, frame, 1, ops.FIELD_DEFORM, act_d, gf, gc, xw_grad_in=xwg_new, bits=bits_d)
+            if name == "split":
+                g_c = ops.field_backward_split(flat, frame, 0, ops.FIELD_RADIANCE, act_c, gf, gc, d_raw=d_raw_c, full_act=True, bits=bits_c)
+                ops.field_backward_split(flat, frame, 0, ops.FIELD_DEFORM, act_c, gf, gc, xw_grad_in=xwg_c + g_c, full_act=True, bits=bits_c)
+            else:
+                g_c = torch.zeros(1, device=dev)
+                ops.field_backward_split(flat, frame, 0, 3, act_c, gf, gc, d_raw=d_raw_c, xw_grad_in=xwg_c, bits=bits_c)
+            out[name] = (gf, gc, g_f, g_c)
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        ref32 = run(False, "fp32")
+        refx3 = run(False, "bf16x3")
+        fused = run(True, "bf16x3")
+    finally:
+        ops.backward_gemm_precision("bf16x3")
+        ops.fused_backward(True)
+    off = W.canonical_offsets("audio")
+    worst = {}
+    for other, tag in ((refx3, "x3"), (ref32, "f32")):
+        for name in ("split", "whole"):
+            a, b = fused[name], other[name]
+            for k, (o, shape) in off.items():
+                n = int(np.prod(shape))
+                scale = float(b[0][o:o + n].abs().max())
+                if scale == 0.0:
+                    assert float(a[0][o:o + n].abs().max()) == 0.0, k
+                    continue
+                worst[(tag, name, k)] = float((a[0][o:o + n] - b[0][o:o + n]).abs().max()) / scale
+            worst[(tag, name, "grad_cond")] = float((a[1] - b[1]).abs().max()) / (float(b[1].abs().max()) + 1e-30)
+            worst[(tag, name, "seam_fine")] = float((a[2] - b[2]).abs().max()) / float(b[2].abs().max())
+            if name == "split":
+                worst[(tag, name, "seam_coarse")] = float((a[3] - b[3]).abs().max()) / float(b[3].abs().max())
+    # the whole walk must equal the split walk of the same mode (same kernels, the seam added in another place)
+    a, b = fused["split"][0], fused["whole"][0]
+    assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    print("fused backward vs per-layer walks, worst |delta| / scale:", ", ".join("%s %.2e" % (str(k), v) for k, v in top))
+    assert top[0][1] <= 1e-4, top
