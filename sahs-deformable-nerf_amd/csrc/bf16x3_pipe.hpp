@@ -11,6 +11,8 @@
 //     ep.slope                      the factor of the "other" branch (A stage: m = v * slope, skipped when slope == 1)
 //     ep.value<TILE, U>(v, m)       the value that is converted (B stage): forward max(v, m); backward bit ? v : m
 //     ep.done4<TILE, G>(r)          called once values 4G .. 4G+3 of tile TILE are final (r[0..3]): backward stores them
+//     EP::stores(tile)              constexpr: done4 of that tile is ONE vector-memory store (so that a chunk's closing wait can be a COUNTED
+//                                   vmcnt that retires the next chunk's LDS-DMA but not the younger stores: end_chunk below)
 // Derived from field_bf16w.hip (one wave per SIMD: chunked weight stream through LDS-DMA, hand-issued A reads with counted lgkmcnt, bias
 // as the C operand of a tile's first MFMA, conversion "ticks" dealt into the MFMA gaps).
 #pragma once
@@ -75,6 +77,7 @@ __device__ __forceinline__ void split_pair(float a, float b, uint32_t &hi, uint3
 
 // the forward's epilogue: (leaky-)ReLU as max(v, slope v); slope 1 = no activation
 struct FwdAct {
+    static constexpr bool stores(int) { return false; }      // done4 issues no vector-memory instruction
     float slope;
     template <int TILE, int U> __device__ __forceinline__ float value(float v, float m) const { return slope == 1.0f ? v : fmaxf(v, m); }
     template <int TILE, int G> __device__ __forceinline__ void done4(const float (&)[4]) const {}
@@ -146,6 +149,26 @@ struct Sched {
     }
 };
 
+// the conversion ticks a (step, gap) pair is dealt: slot of NSLOT -> [lo, hi)
+constexpr int tick_lo(int slot, int nslot) { return PACK_TICKS * slot / nslot; }
+constexpr int tick_hi(int slot, int nslot) { return PACK_TICKS * (slot + 1) / nslot; }
+// done4 calls among ticks [lo, hi): tick T finishes value T - 1; every fourth value (T = 4, 8, 12, 16) ends a group
+constexpr int groups_done(int lo, int hi)
+{
+    int n = 0;
+    for (int T = lo; T < hi; ++T) n += (T >= 1 && T - 1 < NV && ((T - 1) & 3) == 3) ? 1 : 0;
+    return n;
+}
+// end of a chunk when the layer's epilogue stores: the wave's LDS-DMA pieces of the next chunk must have landed, the N vector-memory
+// instructions it issued AFTER the last of them (stores, in issue order behind it: MI355X_MICROARCH.md, vmcnt) may stay in flight --
+// __syncthreads() would drain them all (vmcnt(0)) once per chunk, and a store-heavy kernel then runs compute and stores in turns
+template <int N>
+__device__ __forceinline__ void barrier_after_dma()
+{
+    static_assert(N >= 0, "count");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N < 63 ? N : 63) : "memory");
+}
+
 struct St {
     f32x16 acc[2];       // two accumulator sets: tile t accumulates into one while tile t-1 is converted from the other
     PackState ps;
@@ -164,6 +187,8 @@ __device__ __forceinline__ void dense_x(Ctx &cx, St &st, Blk *in0, const Blk *in
     static_assert(TOTAL * STEP_BYTES <= LDS_BUF_BYTES, "chunk does not fit its buffer");
     static_assert(!PEND || 2 * K0 - 3 >= 1, "no room for the pending tile's conversion");
     static_assert(STEPS >= AP || NT32 == 1, "the counted waits assume a tile's bias batch is issued before the A reads of the next tile's first step");
+    constexpr bool STORING = EP::stores(0) || EP::stores(NT32 - 1) || PEP::stores(PTILE);      // the epilogue issues vector-memory stores
+    constexpr int PPS = 4;                                                                     // DMA pieces per step when front-loaded
     const uint32_t baddr = cx.bias_addr + 4u * (uint32_t)bias_off;
     f32x4 braw[2][4];
     bias_read<0>(braw[0], baddr);
@@ -175,6 +200,7 @@ __device__ __forceinline__ void dense_x(Ctx &cx, St &st, Blk *in0, const Blk *in
         constexpr int PSTEP = (TOTAL * 3 / 4) / (npieces > 0 ? npieces : 1) > 0 ? (TOTAL * 3 / 4) / (npieces > 0 ? npieces : 1) : 1;
         using S = Sched<STEPS, TOTAL, NT32, T0>;
         static_assert(S::max_cnt() <= 15, "lgkmcnt is a 4-bit counter");
+        static_assert(!STORING || (npieces + PPS - 1) / PPS <= TOTAL, "front-loaded DMA pieces must fit the chunk's steps");
         cx.begin_chunk(nhw);
         const uint32_t abase = cx.cur_addr();
         u32x4 ah[AP], al[AP];
@@ -196,11 +222,11 @@ __device__ __forceinline__ void dense_x(Ctx &cx, St &st, Blk *in0, const Blk *in
             auto ticks = [&]<int J>() {
                 if constexpr (t > 0 && k >= 1) {
                     constexpr int NSLOT = 3 * (STEPS - 1), slot = 3 * (k - 1) + J;
-                    constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
+                    constexpr int lo = tick_lo(slot, NSLOT), hi = tick_hi(slot, NSLOT);
                     if constexpr (hi > lo) pack_ticks<lo, hi, t - 1>(st.acc[set ^ 1], out[t - 1], ep, st.ps);
                 } else if constexpr (PEND && t == 0 && k >= 1 && k <= 2 * K0 - 3) {
                     constexpr int NSLOT = 3 * (2 * K0 - 3), slot = 3 * (k - 1) + J;
-                    constexpr int lo = PACK_TICKS * slot / NSLOT, hi = PACK_TICKS * (slot + 1) / NSLOT;
+                    constexpr int lo = tick_lo(slot, NSLOT), hi = tick_hi(slot, NSLOT);
                     if constexpr (hi > lo) pack_ticks<lo, hi, PTILE>(st.acc[1], in0[K0 - 1], pep, st.ps);
                 }
             };
@@ -224,15 +250,50 @@ __device__ __forceinline__ void dense_x(Ctx &cx, St &st, Blk *in0, const Blk *in
                 lds_read16<(I + AP) * STEP_BYTES + FRAG_BYTES>(al[I % AP], abase);
             }
 #endif
-            if constexpr (I % PSTEP == 0 && I / PSTEP < npieces) cx.issue_piece(I / PSTEP);
+            if constexpr (STORING) {      // front-loaded: PPS pieces per step from step 0 (see `after` below)
+                [&]<int... Qs>(std::integer_sequence<int, Qs...>) { ((I * PPS + Qs < npieces ? cx.issue_piece(I * PPS + Qs) : (void)0), ...); }(
+                    std::make_integer_sequence<int, PPS>{});
+            } else {
+                if constexpr (I % PSTEP == 0 && I / PSTEP < npieces) cx.issue_piece(I / PSTEP);
+            }
             ticks.template operator()<2>();
             fence();
         };
         [&]<int... Is>(std::integer_sequence<int, Is...>) { (step.template operator()<Is>(), ...); }(std::make_integer_sequence<int, TOTAL>{});
-        [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
-            ((Ps >= (TOTAL + PSTEP - 1) / PSTEP && Ps < npieces ? cx.issue_piece(Ps) : (void)0), ...);
-        }(std::make_integer_sequence<int, DMA_PIECES>{});
-        cx.end_chunk();
+        if constexpr (!STORING) {
+            [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
+                ((Ps >= (TOTAL + PSTEP - 1) / PSTEP && Ps < npieces ? cx.issue_piece(Ps) : (void)0), ...);
+            }(std::make_integer_sequence<int, DMA_PIECES>{});
+        }
+        // A storing epilogue and the single in-order vmcnt: the wait that retires the next chunk's LDS-DMA also waits for every OLDER store.
+        // So the DMA pieces go out at the START of the chunk (PPS per step), ahead of the chunk's own stores: what the closing wait then has
+        // to see finished, besides the pieces, are only stores of EARLIER chunks, which have had a whole chunk's MFMAs to drain -- with the
+        // pieces spread over the chunk (the forward's schedule) every chunk stalled for most of a store's round trip.  `after` = the stores
+        // this chunk issues behind its last piece (the same dealing of ticks as in `ticks` above, evaluated at compile time; a lower bound).
+        constexpr int after = [] {
+            if (npieces == 0) return 63;                                                       // nothing was fetched
+            const int LP = (npieces - 1) / PPS;                                                // the step that issues the last piece (before its gap 2)
+            int n = 0;
+            for (int I = LP; I < TOTAL; ++I) {
+                const int g = I / STEPS, k = I % STEPS, t = T0 + g;
+                for (int J = (I == LP ? 2 : 0); J < 3; ++J) {
+                    if (t > 0 && k >= 1) {
+                        const int NSLOT = 3 * (STEPS - 1), slot = 3 * (k - 1) + J;
+                        if (EP::stores(t - 1)) n += groups_done(tick_lo(slot, NSLOT), tick_hi(slot, NSLOT));
+                    } else if (PEND && t == 0 && k >= 1 && k <= 2 * K0 - 3) {
+                        const int NSLOT = 3 * (2 * K0 - 3), slot = 3 * (k - 1) + J;
+                        if (PEP::stores(PTILE)) n += groups_done(tick_lo(slot, NSLOT), tick_hi(slot, NSLOT));
+                    }
+                }
+            }
+            return n;
+        }();
+        if constexpr (STORING) {
+            barrier_after_dma<after>();
+            cx.buf ^= 1;
+        } else {
+            cx.end_chunk();
+        }
     };
     [&]<int... Cs>(std::integer_sequence<int, Cs...>) { (chunk.template operator()<Cs>(), ...); }(std::make_integer_sequence<int, NCH>{});
 }

@@ -1067,7 +1067,8 @@ __global__ void __launch_bounds__(256) grid_backward_kernel(long P, const float 
     }
 }
 
-// channel-first [32][vox] <-> channel-last [vox][32] (mode 0: dst_cl = src_cf;  mode 1: dst_cf += src_cl)
+// channel-first [32][vox] <-> channel-last [vox][32] (mode 0: dst_cl = src_cf;  mode 1: dst_cf += src_cl, skipping blocks of 32 voxels that
+// received no gradient: the rays of a batch cross a few per cent of the grid, and 4 MB of float atomics per walk cost 0.3-1.6 ms)
 __global__ void __launch_bounds__(256) grid_transpose_kernel(const float *__restrict__ src, float *__restrict__ dst, int mode)
 {
     __shared__ float t[32][33];
@@ -1081,11 +1082,16 @@ __global__ void __launch_bounds__(256) grid_transpose_kernel(const float *__rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int vv = j + 8 * r; dst[(v0 + vv) * 32 + i] = t[i][vv]; }
     } else {
+        int any = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int vv = j + 8 * r; t[vv][i] = src[(v0 + vv) * 32 + i]; }
-        __syncthreads();
+        for (int r = 0; r < 4; ++r) { const int vv = j + 8 * r; const float v = src[(v0 + vv) * 32 + i]; t[vv][i] = v; any |= (v != 0.0f); }
+        if (!__syncthreads_or(any)) return;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int ch = j + 8 * r; atomicAdd(dst + (long)ch * vox + v0 + i, t[i][ch]); }      // (both levels' walks add here, possibly at once)
+        for (int r = 0; r < 4; ++r) {      // (both levels' walks add here, possibly at once)
+            const int ch = j + 8 * r;
+            const float v = t[i][ch];
+            if (v != 0.0f) atomicAdd(dst + (long)ch * vox + v0 + i, v);
+        }
     }
 }
 
@@ -1176,24 +1182,29 @@ __global__ void __launch_bounds__(256) copy2d_batch_kernel(CopyBatch b, int phas
     }
 }
 
+// one workgroup per job: thread (g, k) walks rows g, g + ngroups, ... of column k -- the reads of W and the atomics into dW are contiguous
+// along k (a block per column made them 256 strided accesses each), dc[k] is reduced over the row groups through LDS
 __global__ void __launch_bounds__(256) const_cols_batch_kernel(ConstBatch b)
 {
-    const ConstJob &j = b.j[blockIdx.y];
-    const int k = blockIdx.x;
-    if (k >= j.cols) return;
-    const float ck = j.c[k];
+    const ConstJob &j = b.j[blockIdx.x];
+    __shared__ float part[256];
+    const int cols = j.cols, ngroups = 256 / cols, g = threadIdx.x / cols, k = threadIdx.x - g * cols;
     float s = 0.0f;
-    for (int r = threadIdx.x; r < j.rows; r += blockDim.x) {
-        const float g = j.db[r];
-        s += j.W[(long)r * j.ld + j.col0 + k] * g;
-        atomicAdd(j.dW + (long)r * j.ld + j.col0 + k, g * ck);
+    if (g < ngroups) {
+        const float ck = j.c[k];
+        for (int r = g; r < j.rows; r += ngroups) {
+            const float gr = j.db[r];
+            s += j.W[(long)r * j.ld + j.col0 + k] * gr;
+            atomicAdd(j.dW + (long)r * j.ld + j.col0 + k, gr * ck);
+        }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    __shared__ float red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    part[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(j.dc + k, (red[0] + red[1]) + (red[2] + red[3]));   // several jobs share a dc (d driving, d pose)
+    if (threadIdx.x < cols) {
+        float t = 0.0f;
+        for (int q = 0; q < ngroups; ++q) t += part[q * cols + threadIdx.x];
+        atomicAdd(j.dc + threadIdx.x, t);      // several jobs share a dc (d driving, d pose)
+    }
 }
 
 __global__ void __launch_bounds__(256) axpy_batch_kernel(AxpyBatch b)
@@ -1251,7 +1262,7 @@ struct Bwd {
     }
     void flush_deferred()
     {
-        if (nconst > 0) { const_cols_batch_kernel<<<dim3(const_maxcols, nconst), 256, 0, st>>>(consts); check(); }
+        if (nconst > 0) { const_cols_batch_kernel<<<nconst, 256, 0, st>>>(consts); check(); }      // (cols <= 256: D_DRV 76, D_POSE 36)
         if (naxpy > 0) { axpy_batch_kernel<<<dim3(1, naxpy), 256, 0, st>>>(axpys); check(); }
         nconst = naxpy = 0;
     }

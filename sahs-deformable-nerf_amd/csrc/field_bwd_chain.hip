@@ -190,12 +190,31 @@ __global__ void __launch_bounds__(256) pack_bwd_stream_kernel(const float *__res
 // This lane (sample, h) of 32-row tile TILE holds, as value U = 4 g + i, feature 32 TILE + 8 g + 4 h + i: bit 8 TILE + 4 (g >> 1) + i of
 // sign word q = h (g even) or q = 2 + h (g odd) -- sahs_layout.hpp: sbits.  MASKED = false: no activation behind this gradient (d feat, the
 // encodings' gradient).  Tiles >= NVALID are padding (not stored).  dst = (uniform plane base, this lane's byte offset of its row + 4 h).
-template <bool MASKED, int NVALID>
+// Where a finished group of four values goes: NOT straight to memory -- the accumulator layout would make every store instruction write 32
+// bytes into each of 32 rows (quarter cache lines; measured: the chain kernel then runs at 2.4 TB/s of stores, compute and stores adding up) --
+// but through a per-wave 32 x 32 staging tile in LDS: the lane writes its four values (ds_write_b128), and once the tile's fourth group is in,
+// the wave reads the tile back row-major and stores it as WHOLE 128-byte lines: lane l -> rows (l >> 3) + 8 i, i = 0..3, 16 bytes (l & 7).
+struct StageCtx {
+    uint32_t wr, rd;          // LDS byte addresses: this lane's row (+16 h) for writing; row l >> 3, piece l & 7 for reading back
+    uint32_t pc;              // 16 (l & 7): the piece's byte offset inside a 128-byte tile row
+    uint32_t prow[4];         // the sample index of read-back row i (clamped to P - 1 like the lane's own sample)
+    uint32_t np;              // P
+};
+constexpr int STAGE_ROW_BYTES = 144;                                      // 32 floats + 4 of padding: 16-byte aligned rows, spread over the banks
+constexpr int STAGE_WAVE_BYTES = 32 * STAGE_ROW_BYTES;
+typedef __attribute__((address_space(3))) f32x4 *lds_f4_t;
+
+template <bool MASKED, int NVALID, int WIDTH>
 struct BwdEp {
+#if defined(SAHS_DIAG) && (defined(SAHS_BWC_NOSTORE) || defined(SAHS_BWC_NOGSTORE))
+    static constexpr bool stores(int) { return false; }
+#else
+    static constexpr bool stores(int tile) { return tile < NVALID; }      // (the counted wait of bf16x3_pipe.hpp: at least one store per group)
+#endif
     float slope;
     uint32_t mh[2], m2[2];
-    float *base;
-    uint32_t off;
+    float *base;              // the layer's dZ plane (uniform)
+    StageCtx sc;
     template <int TILE, int U> __device__ __forceinline__ float value(float v, float m) const
     {
         if constexpr (!MASKED) {
@@ -210,11 +229,34 @@ struct BwdEp {
     }
     template <int TILE, int G> __device__ __forceinline__ void done4(const float (&r)[4]) const
     {
-        if constexpr (TILE < NVALID)
-            *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(base) + off + 4 * (32 * TILE + 8 * G)) = f32x4{r[0], r[1], r[2], r[3]};
+#if defined(SAHS_DIAG) && defined(SAHS_BWC_NOSTORE)      // timing-only: results wrong by construction
+        asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
+#else
+        if constexpr (TILE < NVALID) {
+            *(lds_f4_t)(uintptr_t)(sc.wr + 32 * G) = f32x4{r[0], r[1], r[2], r[3]};
+            if constexpr (G == 3) {
+                f32x4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = *(lds_f4_t)(uintptr_t)(sc.rd + i * 8 * STAGE_ROW_BYTES);
+#if defined(SAHS_DIAG) && defined(SAHS_BWC_NOGSTORE)      // timing-only: the staging round trip without the global stores
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(v[i]));
+#elif defined(SAHS_DIAG) && defined(SAHS_BWC_TILEMAJOR)      // timing-only: the same bytes as 4 KB contiguous runs per wave and tile (the weight-gradient launch would read garbage)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(base) + (size_t)TILE * (sc.np * 128u) + (sc.prow[i] * 128u + sc.pc)) = v[i];
+#else
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(base) + (sc.prow[i] * (uint32_t)(WIDTH * 4) + sc.pc + 128u * TILE)) = v[i];
+#endif
+            }
+        }
+#endif
     }
 };
 struct NoEp {      // (the pending-tile policy of a layer that has none)
+    static constexpr bool stores(int) { return false; }
     float slope;
     template <int TILE, int U> __device__ __forceinline__ float value(float v, float) const { return v; }
     template <int TILE, int G> __device__ __forceinline__ void done4(const float (&)[4]) const {}
@@ -229,8 +271,27 @@ __device__ __forceinline__ void flush_x(St &st, const PEP pep)
     fence();
 }
 
+constexpr int BWC_ZERO_BYTES_ = 2048;
+constexpr int BWC_STAGE_OFF_ = LDS_BIAS_BYTE_OFF + BWC_ZERO_BYTES_;
+// this lane's part in staging its wave's tiles (StageCtx): the wave's 32 samples are consecutive, p0 = 128 tile + 32 wave
+__device__ __forceinline__ StageCtx make_stage(const char *lds, int wave, int lane, long tile, long P)
+{
+    StageCtx sc;
+    const uint32_t base = lds_addr_of(lds) + BWC_STAGE_OFF_ + (uint32_t)wave * STAGE_WAVE_BYTES;
+    sc.wr = base + (uint32_t)(lane & 31) * STAGE_ROW_BYTES + 16u * (lane >> 5);
+    sc.rd = base + (uint32_t)(lane >> 3) * STAGE_ROW_BYTES + 16u * (lane & 7);
+    sc.pc = 16u * (lane & 7);
+    const long p0 = tile * X_PTS_PER_WG + wave * X_PTS_PER_WAVE + (lane >> 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sc.prow[i] = (uint32_t)(p0 + 8 * i < P ? p0 + 8 * i : P - 1);
+    sc.np = (uint32_t)P;
+    return sc;
+}
+
 constexpr int BWC_ZERO_BYTES = 2048;                                       // the "bias" of every backward layer: zeros
-constexpr int BWC_LDS_BYTES = LDS_BIAS_BYTE_OFF + BWC_ZERO_BYTES;
+constexpr int BWC_STAGE_BYTE_OFF = LDS_BIAS_BYTE_OFF + BWC_ZERO_BYTES;
+static_assert(BWC_STAGE_BYTE_OFF == BWC_STAGE_OFF_, "staging tiles behind the zero bias page");
+constexpr int BWC_LDS_BYTES = BWC_STAGE_BYTE_OFF + (X_THREADS / WAVE) * STAGE_WAVE_BYTES;
 static_assert(BWC_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // a (P,4)/(P,16) gradient row as the one 32-feature block of a head layer: k-step 0 = columns 4 h .. 4 h + 3 and 8 + 4 h .. 8 + 4 h + 3
@@ -292,23 +353,33 @@ field_backward_chain_rad_kernel(const unsigned short *__restrict__ stream, long 
         const long p_raw = tile * X_PTS_PER_WG + cx.wave * X_PTS_PER_WAVE + col;
         const long p = p_raw < P ? p_raw : P - 1;      // lanes past the end redo the last sample: identical values to identical addresses
         const uint32_t pl = (uint32_t)p;
-        // policies: sign words of plane (word offset b, NW words per q) + the dZ plane at act:: column c, row width w floats
+        const StageCtx sc = make_stage(lds_x, cx.wave, cx.lane, tile, P);
+        // policies: sign words of plane (word offset b, NW words per q) + the dZ plane at act:: column c
         auto ep128 = [&](int b, int c) {
-            BwdEp<true, 4> e;
+            BwdEp<true, 4, 128> e;
             e.slope = 0.01f;
             const uint32_t *a = bits + (long)b * Pq + ((long)pl * 4 + h);
-            e.mh[0] = a[0]; e.m2[0] = a[2]; e.mh[1] = 0u; e.m2[1] = 0u;
+#if defined(SAHS_DIAG) && defined(SAHS_BWC_NOMASK)       // timing-only
+            e.mh[0] = pl; e.m2[0] = pl + h; (void)a;
+#else
+            e.mh[0] = a[0]; e.m2[0] = a[2];
+#endif
+            e.mh[1] = 0u; e.m2[1] = 0u;
             e.base = dact + (long)c * Pq;
-            e.off = (pl * 128u + 4u * h) * 4u;
+            e.sc = sc;
             return e;
         };
         auto ep256 = [&](int b, int c) {
-            BwdEp<true, 8> e;
+            BwdEp<true, 8, 256> e;
             e.slope = 0.01f;
             const uint32_t *a = bits + (long)b * Pq + ((long)pl * 4 + h) * 2;
+#if defined(SAHS_DIAG) && defined(SAHS_BWC_NOMASK)
+            e.mh[0] = pl; e.mh[1] = pl ^ 5u; e.m2[0] = pl + h; e.m2[1] = pl * 3u; (void)a;
+#else
             e.mh[0] = a[0]; e.mh[1] = a[1]; e.m2[0] = a[4]; e.m2[1] = a[5];
+#endif
             e.base = dact + (long)c * Pq;
-            e.off = (pl * 256u + 4u * h) * 4u;
+            e.sc = sc;
             return e;
         };
         Blk draw[2];
@@ -328,12 +399,12 @@ field_backward_chain_rad_kernel(const unsigned short *__restrict__ stream, long 
             auto e0 = ep128(sbits::BR_C + 0, act::C + 0);
             dense_x<4, 0, 0, 4, CHR(R_D1), true, 3>(cx, st, dC0, nullptr, nullptr, cA, 0, e1, e2);
             dense_x<4, 0, 0, 4, CHR(R_GRIDF), true, 3>(cx, st, cA, nullptr, nullptr, dC0, 0, e0, e1);
-            BwdEp<false, 1> eg;
-            eg.slope = 1.0f; eg.base = dgridf; eg.off = (pl * 32u + 4u * h) * 4u;
+            BwdEp<false, 1, 32> eg;
+            eg.slope = 1.0f; eg.base = dgridf; eg.sc = sc;
             Blk dummy[2];
             dense_x<4, 0, 0, 2, CHR(R_SEGH), true, 3>(cx, st, dC0, nullptr, nullptr, dummy, 0, eg, e0);
         }
-        BwdEp<true, 4> es0;
+        BwdEp<true, 4, 128> es0;
         {   // seg branch: d_raw -> dS3 -> dS2 -> dS1 -> dS0
             Blk sA[4];
             auto e3 = ep128(sbits::BR_S + 12, act::S + 384);
@@ -347,8 +418,8 @@ field_backward_chain_rad_kernel(const unsigned short *__restrict__ stream, long 
         }
         Blk F[8], G[8];
         {   // d feat (no activation behind it), then the trunk
-            BwdEp<false, 8> ef;
-            ef.slope = 1.0f; ef.base = dact + (long)act::FEAT * Pq; ef.off = (pl * 256u + 4u * h) * 4u;
+            BwdEp<false, 8, 256> ef;
+            ef.slope = 1.0f; ef.base = dact + (long)act::FEAT * Pq; ef.sc = sc;
             auto e7 = ep256(sbits::BR_T + 8 * 7, act::T + 7 * 256);
             dense_x<4, 4, 1, 8, CHR(R_FEAT), true, 3>(cx, st, dS0, dC0, draw, F, 0, ef, es0);
             auto e6 = ep256(sbits::BR_T + 8 * 6, act::T + 6 * 256);
@@ -361,8 +432,8 @@ field_backward_chain_rad_kernel(const unsigned short *__restrict__ stream, long 
             dense_x<8, 0, 0, 8, CHR(R_T4), true, 7>(cx, st, G, nullptr, nullptr, F, 0, e4, e5);
             auto e2 = ep256(sbits::BR_T + 8 * 2, act::T + 2 * 256);
             dense_x<8, 0, 0, 8, CHR(R_T3IN), true, 7>(cx, st, F, nullptr, nullptr, G, 0, e3, e4);      // G = dT3 (last tile pending)
-            BwdEp<false, 3> ea;
-            ea.slope = 1.0f; ea.base = din_a; ea.off = (pl * 96u + 4u * h) * 4u;
+            BwdEp<false, 3, 96> ea;
+            ea.slope = 1.0f; ea.base = din_a; ea.sc = sc;
             {
                 Blk dummy[4];
                 dense_x<8, 0, 0, 4, CHR(R_T3), true, 7>(cx, st, G, nullptr, nullptr, dummy, 0, ea, e3);  // d [PE(x') | PE(w)] through the skip layer
@@ -372,8 +443,8 @@ field_backward_chain_rad_kernel(const unsigned short *__restrict__ stream, long 
             auto e0 = ep256(sbits::BR_T + 0, act::T + 0);
             dense_x<8, 0, 0, 8, CHR(R_T1), true, 7>(cx, st, F, nullptr, nullptr, G, 0, e1, e2);
             dense_x<8, 0, 0, 8, CHR(R_T0IN), true, 7>(cx, st, G, nullptr, nullptr, F, 0, e0, e1);      // F = dT0
-            BwdEp<false, 3> eb;
-            eb.slope = 1.0f; eb.base = din_b; eb.off = (pl * 96u + 4u * h) * 4u;
+            BwdEp<false, 3, 96> eb;
+            eb.slope = 1.0f; eb.base = din_b; eb.sc = sc;
             {
                 Blk dummy[4];
                 dense_x<8, 0, 0, 4, CHR(R_RGBH), true, 7>(cx, st, F, nullptr, nullptr, dummy, 0, eb, e0);
@@ -419,15 +490,15 @@ field_backward_chain_def_kernel(const unsigned short *__restrict__ stream, long 
         const long p_raw = tile * X_PTS_PER_WG + cx.wave * X_PTS_PER_WAVE + col;
         const long p = p_raw < P ? p_raw : P - 1;
         const uint32_t pl = (uint32_t)p;
-        auto epw = [&](int b, int c, int width) {      // one sign word per q for the 128- and the 64-wide nets alike
-            BwdEp<true, 4> e;
+        const StageCtx sc = make_stage(lds_x, cx.wave, cx.lane, tile, P);
+        auto fill = [&](auto &e, int b, int c) {       // one sign word per q for the 128- and the 64-wide nets alike
             e.slope = 0.0f;
             const uint32_t *a = bits + (long)b * Pq + ((long)pl * 4 + h);
             e.mh[0] = a[0]; e.m2[0] = a[2]; e.mh[1] = 0u; e.m2[1] = 0u;
             e.base = dact + (long)c * Pq;
-            e.off = (pl * (uint32_t)width + 4u * h) * 4u;
-            return e;
+            e.sc = sc;
         };
+        auto epw = [&](int b, int c) { BwdEp<true, 4, 128> e; fill(e, b, c); return e; };
         Blk hd_w[2], hd_x[2];
         {
             const f32x4 *r = reinterpret_cast<const f32x4 *>(xwg + p * 8);
@@ -448,8 +519,7 @@ field_backward_chain_def_kernel(const unsigned short *__restrict__ stream, long 
         }
         {   // hyper sheet: dw -> dG5 -> ... -> dG0 (the 64-wide layers: two 32-row tiles)
             Blk A[2], B[2];
-            auto mk = [&](int i) { BwdEp<true, 2> e; const auto s = epw(sbits::BD_HH + 4 * i, act::HH + 64 * i, 64);
-                                   e.slope = 0.0f; e.mh[0] = s.mh[0]; e.mh[1] = 0u; e.m2[0] = s.m2[0]; e.m2[1] = 0u; e.base = s.base; e.off = s.off; return e; };
+            auto mk = [&](int i) { BwdEp<true, 2, 64> e; fill(e, sbits::BD_HH + 4 * i, act::HH + 64 * i); return e; };
             auto e5 = mk(5);
             auto e4 = mk(4);
             dense_x<2, 0, 0, 2, CHD(D_H5), false>(cx, st, hd_w, nullptr, nullptr, A, 0, e5, NoEp{1.0f});
@@ -466,16 +536,16 @@ field_backward_chain_def_kernel(const unsigned short *__restrict__ stream, long 
         }
         {   // warp field: dx' (1 - dx^2) -> dH5 -> ... -> dH0
             Blk A[4], B[4];
-            auto e5 = epw(sbits::BD_WH + 4 * 5, act::WH + 128 * 5, 128);
-            auto e4 = epw(sbits::BD_WH + 4 * 4, act::WH + 128 * 4, 128);
+            auto e5 = epw(sbits::BD_WH + 4 * 5, act::WH + 128 * 5);
+            auto e4 = epw(sbits::BD_WH + 4 * 4, act::WH + 128 * 4);
             dense_x<2, 0, 0, 4, CHD(D_W5), false>(cx, st, hd_x, nullptr, nullptr, A, 0, e5, NoEp{1.0f});
-            auto e3 = epw(sbits::BD_WH + 4 * 3, act::WH + 128 * 3, 128);
+            auto e3 = epw(sbits::BD_WH + 4 * 3, act::WH + 128 * 3);
             dense_x<4, 0, 0, 4, CHD(D_W4), true, 3>(cx, st, A, nullptr, nullptr, B, 0, e4, e5);
-            auto e2 = epw(sbits::BD_WH + 4 * 2, act::WH + 128 * 2, 128);
+            auto e2 = epw(sbits::BD_WH + 4 * 2, act::WH + 128 * 2);
             dense_x<4, 0, 0, 4, CHD(D_W3), true, 3>(cx, st, B, nullptr, nullptr, A, 0, e3, e4);
-            auto e1 = epw(sbits::BD_WH + 4 * 1, act::WH + 128 * 1, 128);
+            auto e1 = epw(sbits::BD_WH + 4 * 1, act::WH + 128 * 1);
             dense_x<4, 0, 0, 4, CHD(D_W2), true, 3>(cx, st, A, nullptr, nullptr, B, 0, e2, e3);
-            auto e0 = epw(sbits::BD_WH + 0, act::WH + 0, 128);
+            auto e0 = epw(sbits::BD_WH + 0, act::WH + 0);
             dense_x<4, 0, 0, 4, CHD(D_W1), true, 3>(cx, st, B, nullptr, nullptr, A, 0, e1, e2);
             dense_x<4, 0, 0, 4, CHD(D_HF), true, 3>(cx, st, A, nullptr, nullptr, B, 0, e0, e1);
             flush_x<3>(st, e0);

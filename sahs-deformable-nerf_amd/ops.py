@@ -713,7 +713,11 @@ class RenderRaysFn(torch.autograd.Function):
         N = rays.shape[0]
         both_levels = loss_ops is not None or (any(g is not None for g in (g_rgb_f, g_disp_f, g_acc_f, g_depth_f, g_wbg)) and
                                                any(g is not None for g in (g_rgb_c, g_disp_c, g_acc_c)))
-        if ctx.shared and nf > 0 and kept is not None and N <= RenderRaysFn.BLOCK_RAYS and both_levels and not os.environ.get("SAHS_BWD_ONE_STREAM"):
+        # the fused walk is two full-chip persistent launches per part: run side by side they starve each other (measured: 14.0 ms per step on two
+        # streams, 13.3 on one), so the pairwise two-stream issue below is for the per-layer walks only (fp32 backward products, NeRFaceModels)
+        fused_walk = bits_c is not None and _FUSED_BACKWARD and ctx.arch == "audio" and backward_gemm_precision() == "bf16x3"
+        if (ctx.shared and nf > 0 and kept is not None and N <= RenderRaysFn.BLOCK_RAYS and both_levels and not fused_walk
+                and not os.environ.get("SAHS_BWD_ONE_STREAM")):
             # The two levels' radiance walks are independent of each other, and so are the two deformation walks that follow them (coarse
             # depths / new depths): each pair runs on two streams.  A walk is ~75 dependent GEMM launches whose fixed costs (ring fill, a
             # K loop with one workgroup per CU, the atomic epilogue, ramp and tail: DESIGN.md section 7) leave most of the chip idle for

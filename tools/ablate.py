@@ -25,6 +25,8 @@ VARIANTS = {"base": [],  "nope": ["SAHS_ABLATE_NOPE"], "nobarrier": ["SAHS_ABLAT
             # round 3: backward GEMM (gemm_dma_kernel<*, X3>) -- what the K loop waits for (tools/ab_bwd.sh runs them under rocprofv3)
             "gnocompute": ["SAHS_GEMM_ABL_NOCOMPUTE"], "gnodma": ["SAHS_GEMM_ABL_NODMA"], "gnosplit": ["SAHS_GEMM_ABL_NOSPLIT"], "gnomfma": ["SAHS_GEMM_ABL_NOMFMA"],
             "gnobarrier": ["SAHS_GEMM_ABL_NOBARRIER"], "gstamp": ["SAHS_GEMM_STAMP"], "gstamp_nocompute": ["SAHS_GEMM_STAMP", "SAHS_GEMM_ABL_NOCOMPUTE"], "gstamp_nodma": ["SAHS_GEMM_STAMP", "SAHS_GEMM_ABL_NODMA"], "gnodma_nobarrier": ["SAHS_GEMM_ABL_NODMA", "SAHS_GEMM_ABL_NOBARRIER"],
+            # round 4: the backward chain kernels (field_bwd_chain.hip) -- what they wait for (tools/time_bwd_parts.py under rocprofv3)
+            "cnostore": ["SAHS_DIAG", "SAHS_BWC_NOSTORE"], "cnogstore": ["SAHS_DIAG", "SAHS_BWC_NOGSTORE"], "ctilemajor": ["SAHS_DIAG", "SAHS_BWC_TILEMAJOR"], "cnomask": ["SAHS_DIAG", "SAHS_BWC_NOMASK"], "cnostore_nomask": ["SAHS_DIAG", "SAHS_BWC_NOSTORE", "SAHS_BWC_NOMASK"],
             "w4": ["SAHS_BF16_WAVES=4"], "w4apf6": ["SAHS_BF16_WAVES=4", "SAHS_BF16_APF=6"]}
 
 
