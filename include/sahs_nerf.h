@@ -251,6 +251,12 @@ int sahs_model_field_backward_split(int model, const float *flat_params, const f
                                     float *workspace, void *stream);
 int sahs_route_xw_grad(long N, int Sc, int nf, const int32_t *src, const float *g_fine, float *g_coarse, float *g_new, void *stream);
 
+/* SAHS_BF16 field kernels: NeRFMLP's LeakyReLU(0.01) (modules.py:252) is by default applied to the packed bf16 bit patterns (slope 0.0095 ..
+ * 0.0106 depending on the mantissa: 15 % of a launch faster, PSNR cost measured in bench.py); sahs_bf16_exact_leaky(1) selects the kernel
+ * instance that computes max(v, 0.01 v) in fp32 before rounding, as the reference would in bf16 -- e.g. to A/B a real checkpoint.
+ * Process-wide; enable < 0 queries; SAHS_BF16_EXACT_LEAKY=1 in the environment selects it at first use.  Returns the state in force. */
+int sahs_bf16_exact_leaky(int enable);
+
 /* The fused backward walk (round 4; SAHS_MODEL_AUDIO, split-operand arithmetic = sahs_backward_gemm_precision SAHS_BF16X3).  Replaces the
  * ~38 GEMM launches sahs_model_field_backward_split makes per part -- autograd of modules.py:254-295 (NeRFMLP), :371-390 (WarpFieldMLP),
  * :444-462 (HyperSheetMLP) as driven by train_stage_rays_auto.py:437-499 -- by two: one sample-major data-gradient chain and one

@@ -85,6 +85,9 @@ int sahs_spade_modulate_launch(long planes, long hw, const float *x, const float
 SAHS_DECLARE_MODEL()
 SAHS_DECLARE_MODEL(_nf)
 SAHS_DECLARE_MODEL(_ns)
+int sahs_bf16w_exact_leaky_state(int set);
+int sahs_bf16w_exact_leaky_state_nf(int set);
+int sahs_bf16w_exact_leaky_state_ns(int set);
 // the fused backward walk (field_bwd.hip + field_bwd_chain.hip): AudioFaceModel only
 long sahs_field_backward_fused_ws_words(int part, long P);
 int sahs_field_backward_fused_launch(const float *flat, const float *frame, int level, int part, long P, const float *actbuf, const uint32_t *bits,
@@ -358,6 +361,14 @@ int sahs_backward_gemm_precision(int precision)
     sahs_bwd_gemm_precision_state_nf(v);
     sahs_bwd_gemm_precision_state_ns(v);
     return precision;
+}
+
+int sahs_bf16_exact_leaky(int enable)
+{
+    if (enable < 0) return sahs_bf16w_exact_leaky_state(-1);
+    sahs_bf16w_exact_leaky_state_nf(enable);
+    sahs_bf16w_exact_leaky_state_ns(enable);
+    return sahs_bf16w_exact_leaky_state(enable);
 }
 
 long sahs_act_words_per_sample(void) { return act::STRIDE; }

@@ -16,6 +16,8 @@
 // Numerics: the products, k order and bf16 roundings of field_bf16.hip; the bias enters as the chain's initial value instead of being
 // added to the finished sum (one fp32 rounding placed differently).
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdlib>
 #include <utility>
 #include "sahs_common.hpp"
 #include "sahs_layout.hpp"
@@ -108,6 +110,8 @@ __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float
 #ifdef SAHS_X_EXTRAVALU
     if constexpr (T >= 0 && T < NV) { float dmy; asm volatile("v_max_f32 %0, %1, %1" : "=v"(dmy) : "v"(acc[0][T & 15])); }
 #endif
+    const bool exact = slope < 0.0f;       // (-0.01: the reference's fp32 LeakyReLU, see the kernel's EXACT)
+    if (exact) slope = -slope;
 #ifndef SAHS_BF16W_EXACT_LEAKY
     // LeakyReLU on the packed bf16 BIT PATTERNS, after rounding: 1.5 VALU instructions per value instead of the 2.5 of multiply + max +
     // half a convert in fp32 (build with -DSAHS_BF16W_EXACT_LEAKY for that form; tools/ablate.py "wexact").  The conversion work beside
@@ -119,7 +123,7 @@ __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float
     // systematic one: this precision's contract is the PSNR bound of BASELINE.json (0.05 dB), not the activation function bit for bit,
     // and bench.py / tests/test_gpu_bf16.py measure it with this arithmetic.  Positive values pass unchanged:
     //   tick T:  C'(T-2) d = cvt_pk_bf16(v_{T-3}, v_{T-2});  D'(T-3) s = d >> 15 (arithmetic, per half: 0 | -1);  E'(T-4) dword = sat_i16(s * K + d)
-    if (slope != 0.0f && slope != 1.0f) {
+    if (!exact && slope != 0.0f && slope != 1.0f) {
         if constexpr (T - 2 >= 1 && T - 2 < NV && ((T - 2) & 1)) {
             constexpr int U = T - 2, P = U >> 1, hh = P % NH, q = P / NH;
             ps.d[P & 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{acc[hh][2 * q], acc[hh][2 * q + 1]}, bf16x2));
@@ -436,7 +440,10 @@ __device__ __forceinline__ void grid_block_w(const float *__restrict__ grid, flo
 // MODE (the split evaluation of field_f32.hip, same contract): FIELD_ALL = whole network, additionally writing x', w of every sample
 // to xw when xw != nullptr; FIELD_DEFORM = warp + hyper nets only, on the depths zvals, results to xw columns xw_col0..; FIELD_RADIANCE =
 // radiance nets only, (x', w) of sample p read from xw column src[p].  xw: (rays, xw_row, 8) floats [x'0 x'1 x'2 w0 w1 . . .].
-template <int MODE>
+// EXACT: LeakyReLU as the reference's max(v, 0.01 v) in fp32 (2.5 VALU instructions per value) instead of the packed-integer form on the bf16
+// bit patterns (1.5; slope 0.0095 .. 0.0106): selected at run time (sahs_bf16_exact_leaky / SAHS_BF16_EXACT_LEAKY=1), e.g. to A/B a real
+// checkpoint.  The kernel hands pack_tick the slope as -0.01 for "exact" (a compile-time constant either way).
+template <int MODE, bool EXACT>
 __global__ void __launch_bounds__(W_THREADS, 1)
 field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__restrict__ frame, int level, long P, int S,
                            const float *__restrict__ rays, int ray_stride, const float *__restrict__ zvals,
@@ -444,6 +451,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                            const int *__restrict__ src)
 {
     constexpr uint32_t RAD_OFF = (uint32_t)kProgH.layer[H_T0].stream_off;      // first radiance-net chunk
+    constexpr float LK = EXACT ? -0.01f : 0.01f;                                // NeRFMLP's LeakyReLU (modules.py:252), see pack_tick
 #if SAHS_MODEL == 2      // no deformation nets (config/expression/person_1.yml): the whole network is the radiance net, queried at the raw point
     static_assert(MODE == FIELD_ALL, "this model has no deformation nets to split off");
     constexpr int L_FIRST = H_T0, AFTER_RADIANCE = H_T0;
@@ -614,12 +622,12 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                 pe_blocks_w<3, L_XYZ, KX32>(xw, h, in_tr);
                 if constexpr (KA32 > 0) pe_blocks_w<(AMB_DIM > 0 ? AMB_DIM : 1), L_AMB, KA32, AMB_INC>(amb, h, in_tr + KX32);
                 cx.stamp();                           // 4 PE(x'), PE(w)
-                dense_w<KX32, KA32, 0, 8, CH(H_T1), false>(cx, st, in_tr, in_tr + KX32, nullptr, A, Ly[H_T0].bias_off, 0.01f, 0.0f);
+                dense_w<KX32, KA32, 0, 8, CH(H_T1), false>(cx, st, in_tr, in_tr + KX32, nullptr, A, Ly[H_T0].bias_off, LK, 0.0f);
                 cx.stamp();                           // 5 T0
             }
-            dense_w<8, 0, 0, 8, CH(H_T2), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T1].bias_off, 0.01f, 0.01f);
+            dense_w<8, 0, 0, 8, CH(H_T2), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T1].bias_off, LK, LK);
             cx.stamp();                               // 6 T1
-            dense_w<8, 0, 0, 8, CH(H_T3), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T2].bias_off, 0.01f, 0.01f);
+            dense_w<8, 0, 0, 8, CH(H_T3), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T2].bias_off, LK, LK);
             cx.stamp();                               // 7 T2
             {   // the re-injected encoding [PE(x') | PE(w)] is rebuilt at the skip layer instead of staying live
                 Blk in_tr[KX32 + KA32];
@@ -633,24 +641,24 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
                 if constexpr (KA32 > 0) pe_blocks_w<(AMB_DIM > 0 ? AMB_DIM : 1), L_AMB, KA32, AMB_INC>(amb, h, in_tr + KX32);
                 cx.stamp();                           // 8 PE again
 #if SAHS_MODEL == 0
-                dense_w<8, KX32, KA32, 8, CH(H_T4), true>(cx, st, A, in_tr, in_tr + KX32, B, Ly[H_T3].bias_off, 0.01f, 0.01f);
+                dense_w<8, KX32, KA32, 8, CH(H_T4), true>(cx, st, A, in_tr, in_tr + KX32, B, Ly[H_T3].bias_off, LK, LK);
 #else           // NeRFaceModel: a 4-layer trunk, the skip layer is its last (modules.py:176)
-                dense_w<8, KX32, KA32, 8, CH(H_FEAT), true>(cx, st, A, in_tr, in_tr + KX32, B, Ly[H_T3].bias_off, 0.01f, 0.01f);
+                dense_w<8, KX32, KA32, 8, CH(H_FEAT), true>(cx, st, A, in_tr, in_tr + KX32, B, Ly[H_T3].bias_off, LK, LK);
 #endif
                 cx.stamp();                           // 9 T3 (skip)
             }
 #if SAHS_MODEL == 0
 #pragma unroll 1
             for (int j = 0; j < 2; ++j) {     // T4, T5 | T6, T7 (identical shapes: one copy of the code, run twice)
-                dense_w<8, 0, 0, 8, CH(H_T5), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T4].bias_off + 512 * j, 0.01f, 0.01f);
-                dense_w<8, 0, 0, 8, CH(H_T5), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T4].bias_off + 512 * j + 256, 0.01f, 0.01f);
+                dense_w<8, 0, 0, 8, CH(H_T5), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T4].bias_off + 512 * j, LK, LK);
+                dense_w<8, 0, 0, 8, CH(H_T5), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T4].bias_off + 512 * j + 256, LK, LK);
 #ifdef SAHS_STAMP_W
                 if (j == 0) cx.stamp();               // (diagnostic only) first pass through the loop body: instruction-cache cold
 #endif
             }
 #endif
             cx.stamp();                               // 10 T4..T7
-            dense_w<8, 0, 0, 8, CH(H_ALPHA), true>(cx, st, B, nullptr, nullptr, A, Ly[H_FEAT].bias_off, 1.0f, 0.01f);
+            dense_w<8, 0, 0, 8, CH(H_ALPHA), true>(cx, st, B, nullptr, nullptr, A, Ly[H_FEAT].bias_off, 1.0f, LK);
             cx.stamp();                               // 11 feat
         }
         dense_w_out<8, CH(H_D0)>(cx, st, A, fin, Ly[H_ALPHA].bias_off, true, 1.0f);
@@ -673,20 +681,20 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
             }
             cx.stamp();                               // 13 PE(dir) + grid lookup
             Blk c[4], cn[4];
-            dense_w<8, 1, 1, 4, CH(H_D1), false>(cx, st, A, in_d, in_d + 1, c, Ly[H_D0].bias_off, 0.01f, 0.0f);
-            dense_w<4, 0, 0, 4, CH(H_D1), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D1].bias_off, 0.01f, 0.01f);
-            dense_w<4, 0, 0, 4, CH(H_D1), true>(cx, st, cn, nullptr, nullptr, c, Ly[H_D1].bias_off + 128, 0.01f, 0.01f);
-            dense_w<4, 0, 0, 4, CH(H_RGB), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D3].bias_off, 0.01f, 0.01f);
-            dense_w_out<4, CH(H_S0)>(cx, st, cn, fin, 0, false, 0.01f);
+            dense_w<8, 1, 1, 4, CH(H_D1), false>(cx, st, A, in_d, in_d + 1, c, Ly[H_D0].bias_off, LK, 0.0f);
+            dense_w<4, 0, 0, 4, CH(H_D1), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D1].bias_off, LK, LK);
+            dense_w<4, 0, 0, 4, CH(H_D1), true>(cx, st, cn, nullptr, nullptr, c, Ly[H_D1].bias_off + 128, LK, LK);
+            dense_w<4, 0, 0, 4, CH(H_RGB), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D3].bias_off, LK, LK);
+            dense_w_out<4, CH(H_S0)>(cx, st, cn, fin, 0, false, LK);
         }
         cx.stamp();                                   // 14 colour branch
         {   // seg branch
             Blk s[4], sn[4];
-            dense_w<8, 0, 0, 4, CH(H_S1), false>(cx, st, A, nullptr, nullptr, s, Ly[H_S0].bias_off, 0.01f, 0.0f);
-            dense_w<4, 0, 0, 4, CH(H_S1), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S1].bias_off, 0.01f, 0.01f);
-            dense_w<4, 0, 0, 4, CH(H_S1), true>(cx, st, sn, nullptr, nullptr, s, Ly[H_S1].bias_off + 128, 0.01f, 0.01f);
-            dense_w<4, 0, 0, 4, CH(H_SEG), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S3].bias_off, 0.01f, 0.01f);
-            dense_w_out<4, CH(AFTER_RADIANCE)>(cx, st, sn, fin, 0, false, 0.01f);
+            dense_w<8, 0, 0, 4, CH(H_S1), false>(cx, st, A, nullptr, nullptr, s, Ly[H_S0].bias_off, LK, 0.0f);
+            dense_w<4, 0, 0, 4, CH(H_S1), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S1].bias_off, LK, LK);
+            dense_w<4, 0, 0, 4, CH(H_S1), true>(cx, st, sn, nullptr, nullptr, s, Ly[H_S1].bias_off + 128, LK, LK);
+            dense_w<4, 0, 0, 4, CH(H_SEG), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S3].bias_off, LK, LK);
+            dense_w_out<4, CH(AFTER_RADIANCE)>(cx, st, sn, fin, 0, false, LK);
         }
         cx.stamp();                                   // 15 seg branch
         for_halves([&](auto Q) {
@@ -706,21 +714,44 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
 using namespace SAHS_NS;
 using namespace SAHS_NS::hw;
 
-template <int MODE>
-static int launch_w(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride, const float *zvals,
-                    float *raw, float *dbg, float *xw, int xw_row, int xw_col0, const int *src, int num_cu, hipStream_t stream)
+// Process-wide: 0 = packed-integer LeakyReLU (default), 1 = the reference's fp32 form; SAHS_BF16_EXACT_LEAKY=1 in the environment selects 1
+// at first use.  set < 0 queries.  (One state per model build; sahs_bf16_exact_leaky of the C ABI sets all three.)
+extern "C" int SAHS_SYM(sahs_bf16w_exact_leaky_state)(int set)
+{
+    static std::atomic<int> state{-1};
+    int cur = state.load(std::memory_order_relaxed);
+    if (cur < 0) {
+        const char *e = getenv("SAHS_BF16_EXACT_LEAKY");
+        cur = (e != nullptr && e[0] == '1') ? 1 : 0;
+        state.store(cur, std::memory_order_relaxed);
+    }
+    if (set >= 0) { cur = set ? 1 : 0; state.store(cur, std::memory_order_relaxed); }
+    return cur;
+}
+
+template <int MODE, bool EXACT>
+static int launch_w2(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride, const float *zvals,
+                     float *raw, float *dbg, float *xw, int xw_row, int xw_col0, const int *src, int num_cu, hipStream_t stream)
 {
     if (P <= 0) return 0;
     const long ntiles = (P + W_PTS_PER_WG - 1) / W_PTS_PER_WG;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     static sahs_once::Flags attr_set;       // the large-LDS attribute is per device (and per kernel instance)
     hipError_t ae = sahs_once::per_device(attr_set, [&]() {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_bf16w_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_forward_bf16w_kernel<MODE, EXACT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     });
     if (ae != hipSuccess) return (int)ae;
-    field_forward_bf16w_kernel<MODE><<<grid, W_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, xw, xw_row,
-                                                                            xw_col0, src);
+    field_forward_bf16w_kernel<MODE, EXACT><<<grid, W_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, xw, xw_row,
+                                                                                   xw_col0, src);
     return (int)hipGetLastError();
+}
+template <int MODE>
+static int launch_w(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride, const float *zvals,
+                    float *raw, float *dbg, float *xw, int xw_row, int xw_col0, const int *src, int num_cu, hipStream_t stream)
+{
+    return SAHS_SYM(sahs_bf16w_exact_leaky_state)(-1)
+               ? launch_w2<MODE, true>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, xw, xw_row, xw_col0, src, num_cu, stream)
+               : launch_w2<MODE, false>(packed, frame, level, P, S, rays, ray_stride, zvals, raw, dbg, xw, xw_row, xw_col0, src, num_cu, stream);
 }
 
 #if SAHS_MODEL != 1      // whole-network launches: AudioFaceModel, and NeRFaceModel without deformation nets (all of it is the radiance net)

@@ -507,6 +507,12 @@ def backward_gemm_precision(precision=None):
     return names[code]
 
 
+def bf16_exact_leaky(enable=None):
+    """The SAHS_BF16 kernels' LeakyReLU: False (default) = packed-integer form on the bf16 bit patterns (slope 0.0095 .. 0.0106), True = the
+    reference's max(v, 0.01 v) in fp32 before rounding (include/sahs_nerf.h: sahs_bf16_exact_leaky).  None queries.  Process-wide."""
+    return bool(_lib.lib().sahs_bf16_exact_leaky(-1 if enable is None else int(bool(enable))))
+
+
 LOSS_STATS_WORDS = 64      # include/sahs_nerf.h: [0] loss, [1] last level's mse, [2:14] new sample_prob, [14:26] class counts, [26] rays
 
 

@@ -235,3 +235,38 @@ def test_bf16x3_w512_frame_vs_fp32(weights_mod):
                fine_bad=float(bad[:, 17:].any(dim=1).float().mean()), psnr_rgb_fine=psnr(a[:, 17:20], b[:, 17:20]), w_bg_mean=float(a[:, 34].mean()))
     print(json.dumps(res))
     assert res["coarse_bad"] == 0.0 and res["fine_bad"] <= 0.10 and res["psnr_rgb_fine"] >= 60.0 and 0.02 < res["w_bg_mean"] < 0.9, res
+
+
+def test_bf16_exact_leaky_is_selectable_at_run_time(flat_weights):
+    """The SAHS_BF16 kernels' LeakyReLU: the packed-integer form on the bf16 bit patterns (default; slope 0.0095 .. 0.0106) or, selected at run
+    time (include/sahs_nerf.h: sahs_bf16_exact_leaky, ops.bf16_exact_leaky), the reference's max(v, 0.01 v) in fp32 before rounding -- so
+    that a user with a real checkpoint can A/B the two without rebuilding.  Both forms must stay inside the bf16 error bounds against the
+    fp32 oracle; they are different kernels (outputs differ), and the exact form is the one nearer the oracle."""
+    from conftest import VARIANT_KW
+    ops, lib = pkg("ops"), pkg("_lib")
+    g = load_golden("cond")
+    fw = flat_weights(**VARIANT_KW["hdr"])
+    flat = T(fw)
+    packed = ops.pack_weights(flat, lib.SAHS_BF16)
+    frame = ops.fold_conditioning(flat, T(g["audio"]), T(g["pose"]))
+    rng = np.random.default_rng(12)
+    N, S = 64, 64
+    rays = np.zeros((N, 8), np.float32)
+    rays[:, 0:3] = rng.normal(0, 0.05, (N, 3)) + np.array([0, 0, 0.8])
+    rays[:, 3:6] = rng.normal(0, 0.15, (N, 3)) + np.array([0, 0, -1.0])
+    z = np.sort(rng.uniform(0.48, 1.08, (N, S)).astype(np.float32), axis=1)
+    x6 = np.concatenate([rays[:, None, 0:3] + rays[:, None, 3:6] * z[..., None], np.broadcast_to(rays[:, None, 3:6], (N, S, 3))], -1).reshape(-1, 6)
+    ref = oracle.field_forward(fw, 1, x6.astype(np.float32), oracle.audionet(fw, g["audio"]), oracle.pose_encoding(g["pose"]))
+    assert ops.bf16_exact_leaky() is False
+    out = {}
+    try:
+        for exact in (False, True):
+            assert ops.bf16_exact_leaky(exact) is exact
+            out[exact] = ops.field_forward(packed, frame, 1, T(rays), T(z), precision=lib.SAHS_BF16).view(-1, 16).cpu().numpy()
+    finally:
+        ops.bf16_exact_leaky(False)
+    rms = {k: float(np.sqrt(((v[:, :15] - ref[:, :15]) ** 2).mean())) for k, v in out.items()}
+    print("bf16 colour-logit rms error vs the fp32 oracle: packed-integer LeakyReLU %.4f, exact %.4f" % (rms[False], rms[True]))
+    assert not np.array_equal(out[False], out[True])
+    assert rms[True] < BF16_BOUNDS["hdr"]["col_rms"] and rms[False] < BF16_BOUNDS["hdr"]["col_rms"]
+    assert rms[True] <= rms[False] * 1.05
