@@ -10,7 +10,6 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SAHS_NERF_LIB") or os.path.join(_HERE, "libsahs_nerf.so")   # override: ablation builds (tools/ablate.py)
 SAHS_F32, SAHS_BF16, SAHS_BF16X3 = 0, 1, 3
-SAHS_BF16_2W, SAHS_BF16_Q = 2, 4      # A/B kernels of development builds only (csrc/ab/, build(defines=["SAHS_AB_KERNELS"])): not in the shipped library
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int

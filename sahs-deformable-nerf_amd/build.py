@@ -12,9 +12,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsahs_nerf.so")
 SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "spade_ops.hip", "field_f32.hip", "field_bf16w.hip", "field_bf16x3.hip", "field_bwd.hip", "field_bwd_chain.hip", "train_bwd.hip"]
-# A/B kernels (the round-1 bf16 kernel and the 16x16x32 port, both slower than the shipped one): only in development builds made with
-# build(defines=["SAHS_AB_KERNELS"], out=...) by tools/cmp_*.py -- never in libsahs_nerf.so or the public header
-AB_SOURCES = ["ab/field_bf16.hip", "ab/field_bf16q.hip"]
 # sources built again for the NeRFaceModel architectures (csrc/sahs_model.hpp: -DSAHS_MODEL=1 / 2, symbols suffixed _nf / _ns)
 MODEL_SOURCES = ["pack.hip", "field_f32.hip", "field_bwd.hip"]
 NERFACE_DEFORM_SOURCES = ["field_bf16x3.hip"]      # NeRFaceModel WITH deformation nets (SAHS_MODEL=1): their split-operand kernel (mixed precision)
@@ -45,8 +42,7 @@ HAND_SCHEDULED = [("field_bf16w.hip", 0, "field_forward_bf16w_kernel"), ("field_
 # The forward kernels measure neutral (+-0.5 %) and keep the default.
 PER_FILE_FLAGS = {"field_bwd.hip": ["-fno-slp-vectorize"],
                   "field_bf16w.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "field_bf16x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-                  "field_bwd_chain.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-                  "ab/field_bf16q.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+                  "field_bwd_chain.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-fno-math-errno", "-Wall", "-Wno-unused-function"]
 
 
@@ -85,8 +81,11 @@ def _compile_cmd(hipcc, src, model, defines):
 
 
 def build(force=False, verbose=False, defines=(), out=None, check_inflight=True):
-    """defines/out: ablation and A/B variants (tools/ablate.py, tools/cmp_*.py) -- extra -D flags, separate output .so."""
+    """defines/out: diagnostic variants (tools/ablate.py, tools/stamp_*.py) -- extra -D flags, separate output .so.  Every timing-only
+    ablation or stamp in the sources sits behind SAHS_DIAG, which the shipped library (out=None) refuses."""
     global LIB
+    if out is None and defines:
+        raise RuntimeError("libsahs_nerf.so is built without extra defines (SAHS_DIAG variants go to their own file: out=...)")
     if out is not None:
         LIB, force = out, True
     if not (force or _stale()):
@@ -97,8 +96,7 @@ def build(force=False, verbose=False, defines=(), out=None, check_inflight=True)
     os.makedirs(bdir, exist_ok=True)
     tag = os.path.basename(LIB)
     procs = []
-    ab = AB_SOURCES if "SAHS_AB_KERNELS" in defines else []
-    for src, model in [(s, 0) for s in SOURCES + ab] + [(s, m) for m in (1, 2) for s in MODEL_SOURCES] + [(s, m) for m in (1, 2) for s in MODEL1_SOURCES] + [(s, 1) for s in NERFACE_DEFORM_SOURCES]:
+    for src, model in [(s, 0) for s in SOURCES] + [(s, m) for m in (1, 2) for s in MODEL_SOURCES] + [(s, m) for m in (1, 2) for s in MODEL1_SOURCES] + [(s, 1) for s in NERFACE_DEFORM_SOURCES]:
         obj = os.path.join(bdir, (tag + "." if out else "") + os.path.basename(src).replace(".hip", ".m%d.o" % model if model else ".o"))
         objs.append(obj)
         cmd = _compile_cmd(hipcc, src, model, defines) + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]

@@ -28,10 +28,6 @@ int sahs_conditioning_backward_launch(const float *flat, const float *audio, con
                                       hipStream_t stream);
 int sahs_field_forward_bf16w_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                     const float *zvals, float *raw, float *dbg, int num_cu, hipStream_t stream);
-#ifdef SAHS_AB_KERNELS      // A/B builds only (tools/cmp_*.py): the round-1 two-waves-per-SIMD kernel, SAHS_BF16_2W
-int sahs_field_forward_bf16_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
-                                   const float *zvals, float *raw, float *dbg, int num_cu, hipStream_t stream);
-#endif
 int sahs_field_forward_bf16w_split_launch(const float *packed, const float *frame, int level, int mode, long P, int S, const float *rays,
                                           int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
                                           int num_cu, hipStream_t stream);
@@ -99,12 +95,6 @@ int sahs_pack_weights_bf16_launch_nf(const float *flat, float *packed, hipStream
 int sahs_field_forward_bf16w_split_launch_nf(const float *packed, const float *frame, int level, int mode, long P, int S, const float *rays,
                                              int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
                                              int num_cu, hipStream_t stream);
-#ifdef SAHS_AB_KERNELS      // A/B builds only: SAHS_BF16_Q, the bf16 kernel on the 16x16x32 MFMA shape (field_bf16q.hip)
-int sahs_pack_weights_bf16q_launch(const float *flat, float *packed, hipStream_t stream);
-int sahs_field_forward_bf16q_split_launch(const float *packed, const float *frame, int level, int mode, long P, int S, const float *rays,
-                                          int ray_stride, const float *zvals, float *raw, float *xw, int xw_row, int xw_col0, const int *src,
-                                          int num_cu, hipStream_t stream);
-#endif
 // AudioFaceModel, SAHS_BF16X3: operands split into bf16 hi + lo (field_bf16x3.hip): radiance launch and, since round 3, deformation launch
 long sahs_layout_packed_words_bf16x3(void);
 int sahs_pack_weights_bf16x3_launch(const float *flat, float *packed, hipStream_t stream);
@@ -218,9 +208,6 @@ long sahs_param_count(void) { return kFlat.total; }
 long sahs_packed_words(int precision)
 {
     if (precision == SAHS_BF16X3) return sahs_layout_packed_words_bf16x3() + PACK_FLOATS;     // [hi/lo radiance streams | fp32 pack (deformation nets)]
-#ifdef SAHS_AB_KERNELS
-    if (precision == SAHS_BF16_Q || precision == SAHS_BF16_2W) return hb::PACKH_WORDS;
-#endif
     return precision == SAHS_F32 ? PACK_FLOATS : (precision == SAHS_BF16 ? hb::PACKH_WORDS : -1);
 }
 long sahs_frame_words(void) { return FRAME_FLOATS; }
@@ -229,13 +216,6 @@ int sahs_pack_weights(const float *flat_params, void *packed, int precision, voi
 {
     REQUIRE(flat_params && packed, "sahs_pack_weights");
     REQUIRE(ALIGNED16(packed), "sahs_pack_weights(packed alignment)");
-#ifdef SAHS_AB_KERNELS
-    if (precision == SAHS_BF16_Q) {
-        int e = sahs_pack_weights_bf16q_launch(flat_params, (float *)packed, (hipStream_t)stream);
-        return e ? hip_fail("sahs_pack_weights", e) : 0;
-    }
-    if (precision == SAHS_BF16_2W) precision = SAHS_BF16;      // the same packed stream
-#endif
     if (precision == SAHS_BF16X3) {
         int e = sahs_pack_weights_bf16x3_launch(flat_params, (float *)packed, (hipStream_t)stream);
         if (!e) e = sahs_pack_weights_f32_launch(flat_params, (float *)packed + sahs_layout_packed_words_bf16x3(), (hipStream_t)stream);
@@ -286,18 +266,6 @@ int sahs_field_forward(const void *packed, const float *frame, int level, long N
     REQUIRE((level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8, "sahs_field_forward(shape)");
     REQUIRE(ALIGNED16(packed) && ALIGNED16(frame) && ALIGNED16(raw) && (!dbg || ALIGNED16(dbg)), "sahs_field_forward(alignment)");
     hipStream_t st = (hipStream_t)stream;
-#ifdef SAHS_AB_KERNELS
-    if (precision == SAHS_BF16_Q) {
-        REQUIRE(dbg == nullptr, "sahs_field_forward(SAHS_BF16_Q has no debug outputs)");
-        int e = sahs_field_forward_bf16q_split_launch((const float *)packed, frame, level, 0, N * S, S, rays, ray_stride, z, raw, nullptr, 0, 0, nullptr,
-                                                      num_cus(), st);
-        return e ? hip_fail("sahs_field_forward", e) : 0;
-    }
-    if (precision == SAHS_BF16_2W) {
-        int e = sahs_field_forward_bf16_launch((const float *)packed, frame, level, N * S, S, rays, ray_stride, z, raw, dbg, num_cus(), st);
-        return e ? hip_fail("sahs_field_forward", e) : 0;
-    }
-#endif
     if (precision == SAHS_BF16X3)
         return fail(2, "sahs_field_forward: SAHS_BF16X3 runs through sahs_model_field_forward_split / sahs_model_render_rays_rows (it needs the xw "
                        "workspace)%s%ld", "", 0L);
@@ -526,8 +494,7 @@ static bool x3_deform_on_f32()
 }
 long sahs_model_executed_macs_part(int model, int precision, int part)
 {
-    if (model < 0 || model > 2 || precision < SAHS_F32 || precision > SAHS_BF16_Q || part < 0 || part > 2) return -1;
-    if (precision == SAHS_BF16_Q || precision == SAHS_BF16_2W) precision = SAHS_BF16;      // A/B kernels: the same MFMA work
+    if (model < 0 || model > 2 || precision < SAHS_F32 || precision > SAHS_BF16X3 || part < 0 || part > 2) return -1;
     if (precision == SAHS_BF16X3)       // fp32 deformation nets + three bf16 MFMAs per product of the radiance nets
     {
         if (model != SAHS_MODEL_AUDIO) return -1;
@@ -694,15 +661,6 @@ int sahs_model_field_forward_split(int model, const void *packed, const float *f
             });
         return e ? hip_fail("sahs_model_field_forward_split", e) : 0;
     }
-#ifdef SAHS_AB_KERNELS
-    if (precision == SAHS_BF16_Q && model == SAHS_MODEL_AUDIO) {
-        int e = probed(probe_kind(model, precision, level, mode), N * S, st, [&] {
-            return sahs_field_forward_bf16q_split_launch((const float *)packed, frame, level, mode, N * S, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0,
-                                                         src, num_cus(), st);
-        });
-        return e ? hip_fail("sahs_model_field_forward_split", e) : 0;
-    }
-#endif
     if (precision != SAHS_F32 && !(precision == SAHS_BF16 && model == SAHS_MODEL_AUDIO))
         return fail(4, "sahs_model_field_forward_split: precision %s%ld is not built for this model", "", (long)precision);
     int e = probed(probe_kind(model, precision, level, mode), N * S, st, [&] {
@@ -874,9 +832,6 @@ int sahs_model_render_rays_rows(int model, const void *packed, const float *fram
     }
     if (xw && src && z_new && nf > 0 && model != SAHS_MODEL_NERFACE_STATIC &&
         (precision == SAHS_F32 || precision == SAHS_BF16 || precision == SAHS_BF16X3
-#ifdef SAHS_AB_KERNELS
-         || (precision == SAHS_BF16_Q && model == SAHS_MODEL_AUDIO)
-#endif
          )) {
         // the deformation nets are shared by the two levels and the fine depths contain the coarse ones: evaluate them once per depth
         const char *who = "sahs_model_render_rays_rows";

@@ -57,18 +57,10 @@ __device__ __forceinline__ void for_halves(F &&f)
     [&]<int... Qs>(std::integer_sequence<int, Qs...>) { (f(std::integral_constant<int, Qs>{}), ...); }(std::make_integer_sequence<int, NH>{});
 }
 
-#ifdef SAHS_ABLATE_NODMA        // timing-only ablations (tools/ablate.py): results are wrong by construction
-constexpr bool kNoDma = true;
-#else
 constexpr bool kNoDma = false;
-#endif
-#ifdef SAHS_X_NOBARRIER
-constexpr bool kNoBarrier = true;
-#else
 constexpr bool kNoBarrier = false;
-#endif
 struct Ctx : PipeCtx<W_THREADS, LDS_BUF_BYTES, LDS_BIAS_BYTE_OFF, kNoDma, kNoBarrier> {
-#ifdef SAHS_STAMP_W
+#if defined(SAHS_DIAG) && defined(SAHS_STAMP_W)
     // diagnostic build only (tools/stamp_bf16w.py): s_memtime stamps of wave 0 of workgroup 0 for one sample tile, written to the dbg
     // buffer (which the normal dbg writes then leave alone); no output value is computed from them
     unsigned long long *stamps; int sidx; bool stamp_on;
@@ -100,19 +92,8 @@ struct PackState { f32x2 m2[2]; float r[4]; uint32_t d[2]; };
 template <int T>
 __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float slope, PackState &ps)
 {
-#ifdef SAHS_ABLATE_NOPACK
-    if (T == 0) asm volatile("" :: "v"(acc[0]), "v"(acc[NH - 1]));     // keep the chains alive, convert nothing
-    return;
-#endif
-#ifdef SAHS_X_SLOPE1                // timing-only experiments (results wrong by construction)
-    slope = 1.0f;
-#endif
-#ifdef SAHS_X_EXTRAVALU
-    if constexpr (T >= 0 && T < NV) { float dmy; asm volatile("v_max_f32 %0, %1, %1" : "=v"(dmy) : "v"(acc[0][T & 15])); }
-#endif
     const bool exact = slope < 0.0f;       // (-0.01: the reference's fp32 LeakyReLU, see the kernel's EXACT)
     if (exact) slope = -slope;
-#ifndef SAHS_BF16W_EXACT_LEAKY
     // LeakyReLU on the packed bf16 BIT PATTERNS, after rounding: 1.5 VALU instructions per value instead of the 2.5 of multiply + max +
     // half a convert in fp32 (build with -DSAHS_BF16W_EXACT_LEAKY for that form; tools/ablate.py "wexact").  The conversion work beside
     // the MFMAs is what this kernel is bound by, and this is worth 15 % of a launch.  A negative bf16 value has
@@ -143,8 +124,6 @@ __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float
         }
         return;
     }
-#endif
-#ifndef SAHS_BF16W_FP32_RELU
     if (slope == 0.0f) {
         if constexpr (T - 2 >= 1 && T - 2 < NV && ((T - 2) & 1)) {
             constexpr int U = T - 2, P = U >> 1, hh = P % NH, q = P / NH;
@@ -156,28 +135,18 @@ __device__ __forceinline__ void pack_tick(const f32x16 (&acc)[NH], Blk &o, float
         }
         return;
     }
-#endif
     if constexpr (T >= 0 && T < NV && !(T & 1)) {           // A(T), T even: both values of the pair
         constexpr int P = T >> 1, hh = P % NH, q = P / NH;
         if (slope != 0.0f && slope != 1.0f) {
             const f32x2 pr = f32x2{acc[hh][2 * q], acc[hh][2 * q + 1]}, sl = f32x2{slope, slope};
-#ifdef SAHS_BF16W_PKMUL     // measured SLOWER (23.6 vs 22.3 ms per fine launch) although it halves the multiplies: kept as an experiment
-            asm("v_pk_mul_f32 %0, %1, %2" : "=v"(ps.m2[P & 1]) : "v"(pr), "v"(sl));
-#else
             ps.m2[P & 1] = pr * sl;      // the compiler scalarises this into two v_mul_f32
-#endif
         }
     }
     constexpr int DB = 1, DC = 2;       // stage distances in ticks (2 and 4 measured: no change, 46.1-48.2 vs 46.9-48.0 cycles per MFMA)
     if constexpr (T - DB >= 0 && T - DB < NV) {             // B(T-1)
         constexpr int U = T - DB, P = U >> 1, hh = P % NH, q = P / NH, e = U & 1;
         const float v = acc[hh][2 * q + e];
-#if defined(SAHS_X_MAX_UNUSED) && SAHS_MODEL == 0      // timing experiment (wrong results): the multiply and max are issued, the convert takes the raw value
-        { float dmy = fmaxf(v, ps.m2[P & 1][e]); asm volatile("" :: "v"(dmy)); }
-        ps.r[U & 3] = v;
-#else
         ps.r[U & 3] = slope == 1.0f ? v : (slope == 0.0f ? fmaxf(v, 0.0f) : fmaxf(v, ps.m2[P & 1][e]));
-#endif
     }
     if constexpr (T - DC >= 1 && T - DC < NV && ((T - DC) & 1)) {    // C(T-2): the pair (T-3, T-2) is complete
         constexpr int U = T - DC, P = U >> 1, hh = P % NH, q = P / NH, s = q >> 2, jp = q & 3;
@@ -268,9 +237,7 @@ __device__ __forceinline__ void dense_w(Ctx &cx, St &st, Blk *in0, const Blk *in
                     if constexpr (S::bias_at(I)) bias_read<128 * (t + 1)>(braw[set ^ 1], baddr);
                 }
                 if constexpr (hh == NH - 1) {
-#ifndef SAHS_X_NOAREAD              // timing-only experiment: the A fragments of the prologue are reused (results wrong by construction)
                     if constexpr (S::aread_at(I)) lds_read16<(I + AP) * 1024>(a[I % AP], abase);
-#endif
                     if constexpr (I % PSTEP == 0 && I / PSTEP < npieces) cx.issue_piece(I / PSTEP);
                 }
                 if constexpr (t > 0 && k >= 1) {              // the finished tile t-1 -> out[t-1]: this slot's share of its conversion ticks
@@ -485,13 +452,13 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
     constexpr const LayerH *Ly = kProgH.layer;
 
     const long ntiles = (P + W_PTS_PER_WG - 1) / W_PTS_PER_WG;
-#ifdef SAHS_STAMP_W
+#if defined(SAHS_DIAG) && defined(SAHS_STAMP_W)
     unsigned long long *stamp_base = reinterpret_cast<unsigned long long *>(dbg);
     dbg = nullptr;
     int tile_no = 0;
 #endif
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-#ifdef SAHS_STAMP_W
+#if defined(SAHS_DIAG) && defined(SAHS_STAMP_W)
         cx.stamp_on = stamp_base != nullptr && blockIdx.x == 0 && tile_no == 3 && cx.wave == 0;
         cx.stamps = stamp_base;
         cx.sidx = 0;
@@ -652,7 +619,7 @@ field_forward_bf16w_kernel(const float *__restrict__ packed, const float *__rest
             for (int j = 0; j < 2; ++j) {     // T4, T5 | T6, T7 (identical shapes: one copy of the code, run twice)
                 dense_w<8, 0, 0, 8, CH(H_T5), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T4].bias_off + 512 * j, LK, LK);
                 dense_w<8, 0, 0, 8, CH(H_T5), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T4].bias_off + 512 * j + 256, LK, LK);
-#ifdef SAHS_STAMP_W
+#if defined(SAHS_DIAG) && defined(SAHS_STAMP_W)
                 if (j == 0) cx.stamp();               // (diagnostic only) first pass through the loop body: instruction-cache cold
 #endif
             }

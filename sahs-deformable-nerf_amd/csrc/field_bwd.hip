@@ -222,10 +222,6 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // eight fp32 values (this lane's k = 8h .. 8h+7 of one row/column) -> the bf16x8 MFMA fragments of their hi and lo parts
 __device__ __forceinline__ void split8(const float (&x)[8], u32x4_t &hi, u32x4_t &lo)
 {
-#ifdef SAHS_GEMM_ABL_NOSPLIT
-    for (int p = 0; p < 4; ++p) { hi[p] = __builtin_bit_cast(uint32_t, x[2 * p]); lo[p] = __builtin_bit_cast(uint32_t, x[2 * p + 1]); }
-    return;
-#endif
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{x[2 * p], x[2 * p + 1]}, bf16x2_t));
@@ -236,22 +232,12 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4_t &hi, u32x4_t
 }
 __device__ __forceinline__ f32x16_t mfma3(const u32x4_t &ah, const u32x4_t &al, const u32x4_t &bh, const u32x4_t &bl, f32x16_t c)
 {
-#ifdef SAHS_GEMM_ABL_NOMFMA
-    asm volatile("" :: "v"(ah), "v"(al), "v"(bh), "v"(bl));
-    return c;
-#endif
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bl), c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, al), __builtin_bit_cast(bf16x8_t, bh), c, 0, 0, 0);
     return c;
 }
 
-#ifdef SAHS_GEMM_STAMP      // diagnostic build (tools/stamp_gemm.py): where a wave's cycles go, summed over every wave of every launch
-constexpr int STAMP_SLOTS = 8192;      // spread over many addresses: same-address atomics from every wave would themselves congest the memory system
-__device__ unsigned long long g_gemm_stamp[2][STAMP_SLOTS][8];      // [TA][slot][wait vmcnt | barrier | K-step body | prologue | epilogue | total | waves | K-steps]
-__device__ unsigned long long g_gemm_stamp2[STAMP_SLOTS][8], g_gemm_stamp3[STAMP_SLOTS][8];      // gemm_tn_split_kernel: [DMA issue | stage reads | split + writes (+ bits) | barrier B | fragment reads | MFMA issue | wait vmcnt | barrier A]
-#define SAHS_STAMP_NOW() __builtin_amdgcn_s_memtime()
-#endif
 template <bool TA, bool X3>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA && X3) ? 2 : 3, 3))) gemm_dma_kernel(int M, int N, int K, const float *__restrict__ A, long lda,
                                                        const float *__restrict__ B, long ldb, float *__restrict__ C, long ldc, int mode,
@@ -266,18 +252,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
     constexpr int DST = ring_depth<TA>();
     __shared__ __attribute__((aligned(16))) float smem[DST][2][DTILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c16 = lane & 15;
-#ifdef SAHS_GEMM_STAMP
-    const unsigned long long st_begin = SAHS_STAMP_NOW();
-    unsigned long long st_wait = 0, st_bar = 0, st_body = 0, st_loop0 = 0, st_loop1 = 0, st_steps = 0;
-    auto st_fin = [&]() {
-        if ((threadIdx.x & 63) == 0) {
-            const unsigned long long e = SAHS_STAMP_NOW();
-            unsigned long long *g = g_gemm_stamp[TA ? 1 : 0][(blockIdx.x * 4u + (threadIdx.x >> 6)) % STAMP_SLOTS];
-            atomicAdd(g + 0, st_wait); atomicAdd(g + 1, st_bar); atomicAdd(g + 2, st_body); atomicAdd(g + 3, st_loop0 - st_begin);
-            atomicAdd(g + 4, e - st_loop1); atomicAdd(g + 5, e - st_begin); atomicAdd(g + 6, 1ull); atomicAdd(g + 7, st_steps);
-        }
-    };
-#endif
     const int wm = wave >> 1, wn = wave & 1;
     int bx = blockIdx.x, by = blockIdx.y;
     long bz = blockIdx.z;
@@ -342,11 +316,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float *g = (colok[u] && k0 + krow[u] < k_hi) ? src[u] + (long)t * step[u] : zero;
-#ifdef SAHS_GEMM_ABL_NODMA      // timing-only ablations (SAHS_GEMM_ABL_*): results wrong by construction
-            asm volatile("" :: "v"(g), "v"(dstb));
-#else
             __builtin_amdgcn_global_load_lds((gbl_void_t)g, (lds_void_t)(dstb + u * 256), 16, 0, 0);
-#endif
         }
     };
 
@@ -409,28 +379,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
     if (T > 0) issue(0);      // an empty K slab (k_lo >= K) issues nothing and falls through to a zero contribution
     if (T > 1) issue(1);
     if (DST > 3 && T > 2) issue(2);
-#ifdef SAHS_GEMM_STAMP
-    st_loop0 = SAHS_STAMP_NOW();
-#endif
     for (int t = 0; t < T; ++t) {
-#ifdef SAHS_GEMM_STAMP
-        const unsigned long long sa = SAHS_STAMP_NOW();
-        if (DST > 3 && t + 2 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long sb = SAHS_STAMP_NOW();
-        asm volatile("s_barrier" ::: "memory");
-        const unsigned long long sc = SAHS_STAMP_NOW();
-        st_wait += sb - sa; st_bar += sc - sb;
-#elif defined(SAHS_GEMM_ABL_NOBARRIER)
-        if (DST > 3 && t + 2 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
         if (DST > 3 && t + 2 < T) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
         else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
         if (t + DST - 1 < T) issue(t + DST - 1);          // into the buffer every wave finished reading before the barrier above
         const float *As = &smem[t % DST][0][0], *Bs = &smem[t % DST][1][0];
         if (TA && bits != nullptr && by == 0) {      // thread (kk, g): the 8 columns 8g .. 8g+7 of sample row kk of the X tile -> one byte
@@ -445,9 +397,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
                 bits[k * (N >> 3) + (n0 >> 3) + g] = (unsigned char)b8;
             }
         }
-#ifdef SAHS_GEMM_ABL_NOCOMPUTE
-        if constexpr (X3) { asm volatile("" :: "v"(As), "v"(Bs)); } else
-#endif
         if constexpr (X3) {
             u32x4_t ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -516,11 +465,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
             }
         }
     }
-#ifdef SAHS_GEMM_STAMP
-    st_loop1 = SAHS_STAMP_NOW();
-    st_body = st_loop1 - st_loop0 - st_wait - st_bar;
-    st_steps = (unsigned long long)(T > 0 ? T : 0);
-#endif
     // one accessor for both accumulator layouts: value of row `row` (0..63 of this wave's block, as enumerated below) x column
     // f32 form: tile (i, j) register r  -> row 16 i + 4 q + r,                       column 16 j + c16
     // X3 form : tile (i, j) register e  -> row 32 i + (e & 3) + 8 (e >> 2) + 4 h,    column 32 j + r32
@@ -547,10 +491,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
             for (int e = 0; e < 16; ++e) nibs[e >> 3] |= (((unsigned)pre_raw[e] >> (en & 4)) & 15u) << (4 * (e & 7));
         }
         lds_barrier();
-#ifdef SAHS_GEMM_STAMP
-        unsigned long long ep[6]; int epn = 0;
-        ep[epn++] = SAHS_STAMP_NOW();
-#endif
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -580,9 +520,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
                                 for (int r = 0; r < NR; ++r) stage[row_of(i, r) * SLD + 64 * wn + col_of(j)] = val_of(i, j, r);
                     }
                     lds_barrier();
-#ifdef SAHS_GEMM_STAMP
-                    ep[epn++] = SAHS_STAMP_NOW();
-#endif
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -614,20 +551,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
                     }
                 }
             }
-#ifdef SAHS_GEMM_STAMP
-            ep[epn++] = SAHS_STAMP_NOW();
-#endif
             lds_barrier();
         }
-#ifdef SAHS_GEMM_STAMP
-        if ((threadIdx.x & 63) == 0) {      // [first barrier | stage 0 + barrier | stores 0 | barrier + stage 1 + barrier | stores 1 | last barrier]
-            unsigned long long *g3 = g_gemm_stamp2[(blockIdx.x * 4u + (threadIdx.x >> 6)) % STAMP_SLOTS];
-            const unsigned long long ee = SAHS_STAMP_NOW();
-            atomicAdd(g3 + 0, ep[0] - st_loop1); atomicAdd(g3 + 1, ep[1] - ep[0]); atomicAdd(g3 + 2, ep[2] - ep[1]); atomicAdd(g3 + 3, ep[3] - ep[2]);
-            atomicAdd(g3 + 4, ep[4] - ep[3]); atomicAdd(g3 + 5, ee - ep[4]); atomicAdd(g3 + 6, 1ull);
-        }
-        st_fin();
-#endif
         return;
     }
     if (TA && mode == 2) {
@@ -657,9 +582,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
             __syncthreads();
         }
         if (do_sum && tid < GT && m0 + tid < M) atomicAdd(rowsum + m0 + tid, cs);
-#ifdef SAHS_GEMM_STAMP
-        st_fin();
-#endif
         return;
     }
 #pragma unroll
@@ -680,9 +602,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TA &&
                 }
             }
     if (do_sum && tid < GT && m0 + tid < M) atomicAdd(rowsum + m0 + tid, cs);
-#ifdef SAHS_GEMM_STAMP
-    st_fin();
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -889,29 +808,6 @@ __global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu
     }
 }
 
-#if defined(SAHS_GEMM_STAMP) && SAHS_MODEL == 0
-extern "C" int sahs_dbg_gemm_stamps(unsigned long long *out24, int reset)
-{
-    if (hipDeviceSynchronize() != hipSuccess) return 1;
-    static unsigned long long host[4][STAMP_SLOTS][8];
-    if (out24) {      // 32 values: [data-gradient | weight-gradient | weight-gradient K-step detail | data-gradient epilogue detail]
-        if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamp), 2 * sizeof host[0]) != hipSuccess) return 2;
-        if (hipMemcpyFromSymbol(host[2], HIP_SYMBOL(g_gemm_stamp3), sizeof host[0]) != hipSuccess) return 2;
-        if (hipMemcpyFromSymbol(host[3], HIP_SYMBOL(g_gemm_stamp2), sizeof host[0]) != hipSuccess) return 2;
-        for (int i = 0; i < 32; ++i) out24[i] = 0;
-        for (int ta = 0; ta < 4; ++ta)
-            for (int sl = 0; sl < STAMP_SLOTS; ++sl)
-                for (int i = 0; i < 8; ++i) out24[8 * ta + i] += host[ta][sl][i];
-    }
-    if (reset) {
-        void *d = nullptr;
-        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_gemm_stamp)) != hipSuccess || hipMemset(d, 0, 2 * sizeof host[0]) != hipSuccess) return 3;
-        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_gemm_stamp2)) != hipSuccess || hipMemset(d, 0, sizeof host[0]) != hipSuccess) return 3;
-        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_gemm_stamp3)) != hipSuccess || hipMemset(d, 0, sizeof host[0]) != hipSuccess) return 3;
-    }
-    return 0;
-}
-#endif
 
 // dst[m*ldd + n] (op)= src[m*lds + n] for n < N   (mode 0 copy, 1 add)
 __global__ void copy2d_kernel(long M, int N, const float *__restrict__ src, long lds_, float *__restrict__ dst, long ldd, int mode)

@@ -69,16 +69,12 @@ struct Ctx {
     }
     __device__ __forceinline__ void issue_piece(int p)   // global_load_lds writes LDS at (wave-uniform base + lane*16)
     {
-#ifndef SAHS_ABLATE_NODMA
         const int base = p * F32_THREADS + wave * WAVE;
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(nx_src + base), (lds_ptr_t)(nx_dst + base), 16, 0, 0);
-#endif
     }
     __device__ __forceinline__ void end_chunk()
     {
-#ifndef SAHS_ABLATE_NOBARRIER
         __syncthreads();   // drains the in-flight global_load_lds (vmcnt(0)) and orders buffer reuse
-#endif
         buf ^= 1;
     }
     __device__ __forceinline__ const f32x4 *cur() const { return reinterpret_cast<const f32x4 *>(lds + buf * LDS_BUF_FLOATS); }
@@ -186,9 +182,6 @@ __device__ __forceinline__ RevArg rev_arg(float x)
 // sin(2^k x + fn*pi/2) given rev_arg(x) and scale = 2^k
 __device__ __forceinline__ float sin_octave(RevArg u, float scale, int fn)
 {
-#ifdef SAHS_ABLATE_NOPE
-    return u.p * scale + (float)fn;
-#else
     const float P = u.p * scale, Lo = u.lo * scale;                 // exact
     const float f = (P - rintf(P)) + Lo;                            // fraction of a revolution, [-1/2, 1/2]
     const float qf = rintf(4.0f * f);
@@ -199,7 +192,6 @@ __device__ __forceinline__ float sin_octave(RevArg u, float scale, int fn)
     const int m = ((int)qf + fn) & 3;                               // sin(th + m pi/2)
     const float v = (m & 1) ? cp : sp;
     return (m & 2) ? -v : v;
-#endif
 }
 
 template <int D, int L, int NB, int INC = 1>   // INC: include_input (the raw coordinates come first)

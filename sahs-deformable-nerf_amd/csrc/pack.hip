@@ -119,49 +119,6 @@ __global__ void pack_stream_bf16_kernel(const float *__restrict__ flat, float *_
     }
 }
 
-#ifdef SAHS_AB_KERNELS
-// ---- bf16 stream for field_bf16q.hip (v_mfma_f32_16x16x32_bf16): same sizes and chunking as the bf16 stream, another order inside a tile:
-// fragment 2b + rt of a tile = rows 16 rt .. + 15 x k-block b; lane l holds row l & 15, element j <-> feature 32 b + 16 (j >> 2) + 4 (l >> 4) + (j & 3)
-__global__ void pack_stream_bf16q_kernel(const float *__restrict__ flat, float *__restrict__ packed)
-{
-    using namespace hb;
-    unsigned short *out = reinterpret_cast<unsigned short *>(packed + PACKH_STREAM_OFF);
-    const long total = 2 * STREAM_HW / 8;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long hw = e * 8;
-        const int level = (int)(hw / STREAM_HW);
-        const long sidx = hw - (long)level * STREAM_HW;
-        int li = 0;
-        while (li + 1 < NUM_LAYERS_H && dProgH.layer[li + 1].stream_off <= sidx) ++li;
-        const LayerH &L = dProgH.layer[li];
-        const long w = sidx - L.stream_off;
-        const int per_tile = L.KB32 * 1024;
-        const int t = (int)(w / per_tile);
-        const int rem = (int)(w - (long)t * per_tile);
-        const int b = rem >> 10, rt = (rem >> 9) & 1, lane = (rem & 511) >> 3;
-        const int i = lane & 15, g = lane >> 4;
-        const int row = 32 * t + 16 * rt + i - L.row_shift;
-        int bb = b, seg = -1;
-        for (int sg = 0; sg < L.nseg; ++sg) {
-            if (bb < L.seg[sg].blocks) { seg = sg; break; }
-            bb -= L.seg[sg].blocks;
-        }
-        unsigned short v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = 32 * bb + 16 * (j >> 2) + 4 * g + (j & 3);
-            float x = 0.0f;
-            if (seg >= 0 && c < L.seg[seg].valid && row >= 0 && row < L.src_rows)
-                x = flat[L.w_off[level] + (long)row * L.src_ld + L.seg[seg].src_col + c];
-            v[j] = f32_to_bf16_rne(x);
-        }
-        uint4 q;
-        q.x = v[0] | ((unsigned)v[1] << 16); q.y = v[2] | ((unsigned)v[3] << 16);
-        q.z = v[4] | ((unsigned)v[5] << 16); q.w = v[6] | ((unsigned)v[7] << 16);
-        *reinterpret_cast<uint4 *>(out + hw) = q;
-    }
-}
-#endif
 
 // ---- bf16x3 stream (field_bf16x3.hip): the bf16 stream with every fragment followed by the fragment of the remainders w - bf16(w) ----
 __global__ void pack_stream_bf16x3_kernel(const float *__restrict__ flat, float *__restrict__ packed)
@@ -335,15 +292,6 @@ extern "C" int SAHS_SYM(sahs_pack_weights_bf16_launch)(const float *flat, float 
     return (int)hipGetLastError();
 }
 
-#ifdef SAHS_AB_KERNELS
-extern "C" int SAHS_SYM(sahs_pack_weights_bf16q_launch)(const float *flat, float *packed, hipStream_t stream)
-{
-    pack_stream_bf16q_kernel<<<1024, 256, 0, stream>>>(flat, packed);
-    pack_grid_f32_kernel<<<1024, 256, 0, stream>>>(flat, packed);
-    pack_table_bf16_kernel<<<1, 64, 0, stream>>>(packed);
-    return (int)hipGetLastError();
-}
-#endif
 
 // [grid fp32 channel-last][hi/lo streams of both levels] for field_bf16x3.hip
 extern "C" int SAHS_SYM(sahs_pack_weights_bf16x3_launch)(const float *flat, float *packed, hipStream_t stream)

@@ -24,12 +24,6 @@ inline hipError_t per_device(Flags &flags, F &&action)
 }
 }  // namespace sahs_once
 
-// precision ids of the A/B kernels (csrc/ab/, development builds with -DSAHS_AB_KERNELS only; reserved values of include/sahs_nerf.h)
-#ifndef SAHS_BF16_2W
-#define SAHS_BF16_2W 2   /* SAHS_BF16's arithmetic and packed stream through the round-1 two-waves-per-SIMD kernel (ab/field_bf16.hip) */
-#define SAHS_BF16_Q 4    /* SAHS_BF16's arithmetic on v_mfma_f32_16x16x32_bf16 (ab/field_bf16q.hip) */
-#endif
-
 namespace SAHS_NS {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WAVE = 64;   // gfx950 wavefront

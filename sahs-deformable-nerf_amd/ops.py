@@ -15,11 +15,10 @@ import os
 import torch
 
 from . import _lib
-from ._lib import SAHS_F32, SAHS_BF16, SAHS_BF16_2W, SAHS_BF16X3, SAHS_BF16_Q, check
+from ._lib import SAHS_F32, SAHS_BF16, SAHS_BF16X3, check
 
 PRECISIONS = {"fp32": SAHS_F32, "f32": SAHS_F32, "bf16": SAHS_BF16,
               "bf16x3": SAHS_BF16X3}    # near-fp32 on the bf16 pipe: every net with hi + lo bf16 operands (3 MFMAs per product); SAHS_X3_DEFORM=f32 keeps the deformation nets on the fp32 kernel
-AB_PRECISIONS = {"bf16_2w": SAHS_BF16_2W, "bf16q": SAHS_BF16_Q}    # development A/B builds only (tools/cmp_*.py); the shipped library rejects them
 
 
 def is_mixed(arch, precision):
@@ -306,7 +305,7 @@ def render_rays_rows(packed, frame, rays, num_coarse, num_fine, rows, precision=
     mixed = is_mixed(arch, precision)      # split-operand deformation launch + low-precision radiance launch: only the split chain exists
     if mixed and not (share_deformation and num_fine > 0):
         raise _lib.SahsError("a mixed-precision model renders through the split chain (share_deformation=True, num_fine > 0)")
-    if share_deformation and num_fine > 0 and arch != "nerface_static" and precision in (SAHS_F32, SAHS_BF16, SAHS_BF16X3, SAHS_BF16_Q):      # (_Q: A/B builds)
+    if share_deformation and num_fine > 0 and arch != "nerface_static" and precision in (SAHS_F32, SAHS_BF16, SAHS_BF16X3):
         # extra workspace of the split evaluation: deformed points of every depth, the merge permutation, the new depths
         xw, z_new = buf("xw", N, Sf, 8), buf("z_new", N, num_fine)
         src = ws.get("src")

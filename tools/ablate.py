@@ -11,23 +11,14 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(REPO, "sahs-deformable-nerf_amd", "build", "variants")
-VARIANTS = {"base": [],  "nope": ["SAHS_ABLATE_NOPE"], "nobarrier": ["SAHS_ABLATE_NOBARRIER"], "noprio": ["SAHS_ABLATE_NOPRIO"], "nopack": ["SAHS_ABLATE_NOPACK"], "nopack_nodma": ["SAHS_ABLATE_NOPACK", "SAHS_ABLATE_NODMA"],
-            "nopack_nodma_nolds": ["SAHS_ABLATE_NOPACK", "SAHS_ABLATE_NODMA", "SAHS_ABLATE_NOLDSREAD"], "nodma": ["SAHS_ABLATE_NODMA"], "nomfma": ["SAHS_ABLATE_NOMFMA"], "nomfma_nodma": ["SAHS_ABLATE_NOMFMA", "SAHS_ABLATE_NODMA"],
-            "noldsread": ["SAHS_ABLATE_NOLDSREAD"], "noldsread_nodma": ["SAHS_ABLATE_NOLDSREAD", "SAHS_ABLATE_NODMA"],
-            "ntstore": ["SAHS_ABLATE_NTSTORE"], "noact": ["SAHS_ABLATE_NOACT"],
-            # round 2: hand-issued A-fragment reads N fragments ahead with counted lgkmcnt; one wave per SIMD (4 waves)
-            "apf3": ["SAHS_BF16_APF=3"], "apf4": ["SAHS_BF16_APF=4"], "apf6": ["SAHS_BF16_APF=6"], "apf8": ["SAHS_BF16_APF=8"],
-            # (wnopack: INVALID as an MFMA-only time -- without the conversions the compiler deletes 45 % of the MFMAs, DESIGN.md section 3.1b;
-            #  wall-time ablations of this kernel also move the clock the chip holds: use tools/stamp_bf16w.py, which counts cycles)
-            "wnopack": ["SAHS_ABLATE_NOPACK"], "wagpr": ["SAHS_NOTHING"], "wnodma": ["SAHS_ABLATE_NODMA"],
-            "wfp32relu": ["SAHS_BF16W_FP32_RELU"], "wpkmul": ["SAHS_BF16W_PKMUL"], "wexact": ["SAHS_BF16W_EXACT_LEAKY"],
-            "x3nodma": ["SAHS_X3_NODMA"], "x3nobar": ["SAHS_X3_NOBARRIER"], "x3noaread": ["SAHS_X3_NOAREAD"], "x3floor": ["SAHS_X3_NODMA", "SAHS_X3_NOBARRIER", "SAHS_X3_NOAREAD"],
-            # round 3: backward GEMM (gemm_dma_kernel<*, X3>) -- what the K loop waits for (tools/ab_bwd.sh runs them under rocprofv3)
-            "gnocompute": ["SAHS_GEMM_ABL_NOCOMPUTE"], "gnodma": ["SAHS_GEMM_ABL_NODMA"], "gnosplit": ["SAHS_GEMM_ABL_NOSPLIT"], "gnomfma": ["SAHS_GEMM_ABL_NOMFMA"],
-            "gnobarrier": ["SAHS_GEMM_ABL_NOBARRIER"], "gstamp": ["SAHS_GEMM_STAMP"], "gstamp_nocompute": ["SAHS_GEMM_STAMP", "SAHS_GEMM_ABL_NOCOMPUTE"], "gstamp_nodma": ["SAHS_GEMM_STAMP", "SAHS_GEMM_ABL_NODMA"], "gnodma_nobarrier": ["SAHS_GEMM_ABL_NODMA", "SAHS_GEMM_ABL_NOBARRIER"],
-            # round 4: the backward chain kernels (field_bwd_chain.hip) -- what they wait for (tools/time_bwd_parts.py under rocprofv3)
-            "cnostore": ["SAHS_DIAG", "SAHS_BWC_NOSTORE"], "cnogstore": ["SAHS_DIAG", "SAHS_BWC_NOGSTORE"], "ctilemajor": ["SAHS_DIAG", "SAHS_BWC_TILEMAJOR"], "cnomask": ["SAHS_DIAG", "SAHS_BWC_NOMASK"], "cnostore_nomask": ["SAHS_DIAG", "SAHS_BWC_NOSTORE", "SAHS_BWC_NOMASK"],
-            "w4": ["SAHS_BF16_WAVES=4"], "w4apf6": ["SAHS_BF16_WAVES=4", "SAHS_BF16_APF=6"]}
+# every timing-only switch in the sources sits behind SAHS_DIAG (sahs-deformable-nerf_amd/build.py refuses it for the shipped library)
+VARIANTS = {"base": ["SAHS_DIAG"],
+            # the split-operand forward / backward pipeline (csrc/bf16x3_pipe.hpp): without the weight DMA, the chunk barriers, the A-fragment reads
+            "x3nodma": ["SAHS_DIAG", "SAHS_X3_NODMA"], "x3nobar": ["SAHS_DIAG", "SAHS_X3_NOBARRIER"], "x3noaread": ["SAHS_DIAG", "SAHS_X3_NOAREAD"],
+            "x3floor": ["SAHS_DIAG", "SAHS_X3_NODMA", "SAHS_X3_NOBARRIER", "SAHS_X3_NOAREAD"],
+            # the backward chain kernels (csrc/field_bwd_chain.hip): what they wait for (tools/ab_chain.sh runs them under rocprofv3)
+            "cnostore": ["SAHS_DIAG", "SAHS_BWC_NOSTORE"], "cnogstore": ["SAHS_DIAG", "SAHS_BWC_NOGSTORE"], "ctilemajor": ["SAHS_DIAG", "SAHS_BWC_TILEMAJOR"],
+            "cnomask": ["SAHS_DIAG", "SAHS_BWC_NOMASK"], "cnostore_nomask": ["SAHS_DIAG", "SAHS_BWC_NOSTORE", "SAHS_BWC_NOMASK"]}
 
 
 def build():

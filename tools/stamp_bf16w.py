@@ -25,7 +25,7 @@ if sys.argv[1] == "build":
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     os.makedirs(VDIR, exist_ok=True)
-    print(mod.build(defines=["SAHS_STAMP_W"] + sys.argv[3:], out=lib_of(sys.argv[2] if len(sys.argv) > 2 else "base")))
+    print(mod.build(defines=["SAHS_DIAG", "SAHS_STAMP_W"] + sys.argv[3:], out=lib_of(sys.argv[2] if len(sys.argv) > 2 else "base")))
     sys.exit(0)
 
 import torch
