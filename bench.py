@@ -30,7 +30,8 @@ constants folded away); roofline.chain prices all field launches together agains
   torch_gpu_baseline  the same restatement in plain PyTorch-ROCm on this GPU, full frame: the denominator of the north star's
                       ">= 10x the reference single-GPU PyTorch path";
   bf16                configs[2], with the PSNR protocol of SURVEY.md section 8d on the high-dynamic-range network;
-  nerface_fp32, num_fine128, train_T2048   the secondary workloads of SURVEY.md section 8d / 8f.
+  nerface_fp32, num_fine128, train_T2048 (backward products in f32), train_T2048_bf16x3 (the default: split-bf16 backward), spade
+                      the secondary workloads of SURVEY.md section 8d / 8f.
 Only this file's cpu_baseline / torch_gpu_baseline legs import anything under oracle/ (the thing timed there, never the product path).
 """
 import argparse
@@ -332,6 +333,8 @@ def add_secondary_legs(result, pkg, dev, args):
     result["train_T2048"] = train_leg(pkg, dev, backward="fp32")
     progress("train_T2048_bf16x3 leg (the library's default: backward products as three bf16 MFMAs)")
     result["train_T2048_bf16x3"] = train_leg(pkg, dev, backward="bf16x3")
+    progress("spade leg (Stage-II generator inference, SURVEY.md section 8f-4)")
+    result["spade"] = spade_leg(pkg, dev)
 
 
 def train_leg(pkg, dev, rays=2048, steps=5, warmup=2, backward="fp32"):
@@ -410,6 +413,46 @@ def train_record(pkg, rays, dt, steps, backward, nc=64, nf=64):
                          "achieved_algorithmic": alg, "peak_algorithmic": PEAK_TFLOPS["fp32"], "frac_algorithmic": alg / PEAK_TFLOPS["fp32"],
                          "flop_rule_algorithmic": "3 x forward GEMM FLOPs per training ray (SURVEY.md section 8d) against the fp32 MFMA peak; "
                                                   "a pipe roofline only for backward_gemm_precision fp32"}}
+
+
+def spade_leg(pkg, dev, size=512, steps=10, warmup=3):
+    """SURVEY.md section 8f-4 (Stage-II refiner, _init_spade.py:284-325): `Generator` inference on a size x size pair (convolutions on MIOpen),
+    and the ONE hand-written kernel pair of that path -- instance statistics + fused normalise / modulate / activate -- on the largest SPADE
+    layer of the network (64 channels at size/2 x size/2), timed with HIP events against its algorithmic 20 B per element (HBM roof)."""
+    ops = pkg.ops
+    g = torch.Generator(device=dev).manual_seed(1)
+    torch.manual_seed(1)
+    net = pkg.spade.Generator().to(dev).eval()
+    I_src, I_raw = torch.rand(1, 3, size, size, device=dev, generator=g), torch.rand(1, 3, size, size, device=dev, generator=g)
+    with torch.no_grad():
+        for _ in range(warmup):
+            out = net(I_src, I_raw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = net(I_src, I_raw)
+        torch.cuda.synchronize()
+        gen_ms = (time.perf_counter() - t0) / steps * 1e3
+    assert tuple(out.shape) == (1, 3, size, size) and bool(torch.isfinite(out).all())
+    C, H = 64, size // 2
+    x, ga, be = (torch.randn(1, C, H, H, device=dev, generator=g) for _ in range(3))
+    for _ in range(3):
+        ops.spade_modulate(x, ga, be, slope=0.2)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 50
+    e0.record()
+    for _ in range(reps):
+        ops.spade_modulate(x, ga, be, slope=0.2)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = 20 * x.numel()
+    return {"workload": "Stage-II Generator (IdEncoder + 6 SPADE blocks) on a %dx%d source / raw pair, inference, fp32; convolutions on MIOpen" % (size, size),
+            "ms_per_image": gen_ms, "value": 1e3 / gen_ms, "unit": "images/s", "dtype": "f32",
+            "roofline": {"bound": "hbm", "kernel": "instance_stats_kernel + spade_modulate_kernel<true> on (1, %d, %d, %d)" % (C, H, H),
+                         "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0,
+                         "avg_pair_ms": ms, "bytes_per_element": 20, "elements": x.numel(),
+                         "timing": "HIP events on the launch stream around %d statistics + modulate launch pairs" % reps, "traffic": None}}
 
 
 def host_cores():

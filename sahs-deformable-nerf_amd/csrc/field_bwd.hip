@@ -809,6 +809,157 @@ __global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// The wide layers' weight gradients as 256 x 256 BLOCKS (round 4).  With 128 x 128 tiles a 256 x 256 layer is four workgroups that each
+// stream 128 columns of dY and 128 of X: every operand byte is fetched twice unless the four happen to run in step on one XCD (measured on
+// the training step: 21 GB fetched per step for 15.9 GB of operands, at 5 TB/s -- the launch is HBM-bound, so the re-reads are its time).
+// Here ONE workgroup owns the whole 256 x 256 block of a job over a sample range: per 16-sample K-step it brings in 16 x 256 of dY and
+// 16 x 256 of X once (32 KB by LDS-DMA, ring of four), splits both into bf16 hi / lo fragments once, and its eight waves (4 along M x 2
+// along N, a 64 x 128 sub-block = eight 32 x 32 accumulators each) issue 24 MFMAs per wave and K-step.  160 KB of LDS: one workgroup per
+// CU, two waves per SIMD.  The accumulators go out as atomics straight from the registers: one register of a 32 x 32 accumulator is two
+// 128-byte row segments, which the memory side takes at full rate (MI355X_MICROARCH.md, global float atomics) -- no staging pass.
+// Jobs: M, N <= 256 (columns past M / N come from the zero page); the narrower jobs stay with the 128 x 128 kernel above.
+constexpr int TW_DST = 3, TW_UNITS = 4;                                       // ring depth; 128-column operand blocks per K-step (2 of dY + 2 of X)
+constexpr int TW_STAGE_FLOATS = TW_UNITS * DTILE;                              // 8192 floats = 32 KB
+constexpr int TW_RING_FLOATS = TW_DST * TW_STAGE_FLOATS;
+constexpr int TW_FRAG_DWORDS = TW_UNITS * 2 * GT * 8;                          // [block][hi | lo][column][8 dwords = 16 bf16]: 32 KB, two of them
+constexpr int TW_LDS_BYTES = (TW_RING_FLOATS + 2 * TW_FRAG_DWORDS) * 4;
+static_assert(TW_LDS_BYTES == 163840, "one workgroup per CU: all 160 KB of it");
+
+// Software-pipelined: while the MFMAs of K-step t run from fragment buffer t & 1, the same waves split K-step t + 1 from the ring into the
+// other fragment buffer (VALU and LDS work beside the matrix pipe instead of in turns with it: in turns the kernel was instruction-bound at
+// 2 us per K-step, 3.7 TB/s), ONE barrier per K-step, two K-steps of LDS-DMA in flight behind the one being split.
+__device__ __forceinline__ void tn_block256(float *tn_lds, int M, int N, const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
+                                            float *__restrict__ C, long ldc, long k_lo, long k_hi, float *__restrict__ rowsum,
+                                            const float *__restrict__ zero)
+{
+    float *ring = tn_lds;                                                      // [TW_DST][block 0..3][16 k][128 cols]; blocks 0, 1 = dY, 2, 3 = X
+    uint32_t *frag = reinterpret_cast<uint32_t *>(tn_lds + TW_RING_FLOATS);   // [2][TW_FRAG_DWORDS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, h = lane >> 5, r32 = lane & 31, c32 = lane & 31;
+    const int T = (int)((k_hi - k_lo + GK - 1) / GK);
+    // DMA: 32 one-KB units per K-step (block b, row pair rp); wave w moves units 4 w .. 4 w + 3 = row pairs 4 (w & 1) .. of block w >> 1.
+    // K-major [16 k][128 cols], XOR-swizzled by 16 floats on odd rows as in tn_tile.
+    const float *src[4]; long step[4]; int krow[4]; bool colok[4];
+    const int blk = wave >> 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int rp = (wave & 1) * 4 + u;
+        const float *base = (blk < 2) ? A : B;
+        const long ld = (blk < 2) ? lda : ldb;
+        const int c0 = (blk & 1) * GT;
+        const int dim = (blk < 2) ? M : N;
+        const int row = 2 * rp + h;
+        const int j = c32 ^ ((row & 1) << 2);
+        src[u] = base + (k_lo + row) * ld + c0 + 4 * j;
+        step[u] = GK * ld;
+        krow[u] = row;
+        colok[u] = c0 + 4 * j < dim;
+    }
+    const int dst_off = blk * DTILE + (wave & 1) * 4 * 256;
+    auto issue = [&](int t) {
+        float *dstb = ring + (t % TW_DST) * TW_STAGE_FLOATS + dst_off;
+        const long k0 = k_lo + (long)t * GK;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float *g = (colok[u] && k0 + krow[u] < k_hi) ? src[u] + (long)t * step[u] : zero;
+            __builtin_amdgcn_global_load_lds((gbl_void_t)g, (lds_void_t)(dstb + u * 256), 16, 0, 0);
+        }
+    };
+    // split, two rounds per K-step: round r, thread -> block 2 r + (tid >> 8), samples 8 skh .. 8 skh + 7 of column scol (round 0: the dY blocks)
+    const int sb = tid >> 8, skh = (tid >> 7) & 1, scol = tid & 127;
+    const int spos0 = scol, spos1 = (((scol >> 2) ^ 4) << 2) + (scol & 3);
+    float cs = 0.0f;
+    auto split_round = [&](int t, int r) {
+        const float *col = ring + (t % TW_DST) * TW_STAGE_FLOATS + (2 * r + sb) * DTILE + 8 * skh * GT;
+        float x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = col[k * GT + ((k & 1) ? spos1 : spos0)];
+        u32x4_t hi, lo;
+        split8(x, hi, lo);
+        uint32_t *fdst = frag + (t & 1) * TW_FRAG_DWORDS + (((2 * r + sb) * 2) * GT + scol) * 8 + 4 * skh;
+        *reinterpret_cast<u32x4_t *>(fdst) = hi;
+        *reinterpret_cast<u32x4_t *>(fdst + GT * 8) = lo;
+        if (r == 0 && rowsum != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cs += x[k];
+        }
+    };
+    // MFMA: wave (wm, wn) owns rows 64 wm .. + 63 (dY block wm >> 1), columns 128 wn .. + 127 (X block wn)
+    int fa[2], fb[4];      // dword offsets inside a fragment buffer
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i] = (((wm >> 1) * 2) * GT + (64 * (wm & 1) + 32 * i + r32)) * 8 + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = (((2 + wn) * 2) * GT + (32 * j + r32)) * 8 + 4 * h;
+    f32x16_t acx[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acx[i][j][e] = 0.0f;
+
+    // vmcnt accounting as in tn_tile: this wave's loads are its 4 LDS-DMA instructions per issue(), in issue order; anything older still in
+    // flight (a previous item's atomics) can only make a counted wait stricter
+    if (T > 0) issue(0);
+    if (T > 1) issue(1);
+    if (T > 2) issue(2);
+    if (T > 0) {      // K-step 0 has landed when at most the 8 DMA instructions of steps 1, 2 are outstanding
+        if (T > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else if (T > 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        split_round(0, 0);
+        split_round(0, 1);
+    }
+    for (int t = 0; t < T; ++t) {
+        // K-step t + 1 has landed (t + 2 may be in flight); every wave has finished the MFMAs of step t - 1 and the split of step t
+        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + 3 < T) issue(t + 3);                         // into stage t % 3, which the split of step t (last iteration) was the last to read
+        const uint32_t *fr = frag + (t & 1) * TW_FRAG_DWORDS;
+        u32x4_t ah[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const u32x4_t *>(fr + fa[i]);
+            al[i] = *reinterpret_cast<const u32x4_t *>(fr + fa[i] + GT * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32x4_t bh = *reinterpret_cast<const u32x4_t *>(fr + fb[j]), bl = *reinterpret_cast<const u32x4_t *>(fr + fb[j] + GT * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acx[i][j] = mfma3(ah[i], al[i], bh, bl, acx[i][j]);
+            if (t + 1 < T && (j & 1) == 0) split_round(t + 1, j >> 1);      // beside the MFMAs: the next K-step's fragments
+        }
+    }
+    // accumulator (i, j) register e: row 64 wm + 32 i + (e & 3) + 8 (e >> 2) + 4 h, column 128 wn + 32 j + r32
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = 128 * wn + 32 * j + r32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < M && n < N) atomicAdd(C + (long)m * ldc + n, acx[i][j][e]);
+            }
+        }
+    if (rowsum != nullptr && sb * GT + scol < M) atomicAdd(rowsum + sb * GT + scol, cs);      // (two partial sums per column: samples 0..7 and 8..15 of every step)
+    __syncthreads();      // the ring and the fragment buffers are free (and this item's DMA has long drained) before the next item issues into them
+}
+
+__global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_tn_jobs256_kernel(TnBatch jobs, int njobs, long P, long range,
+                                                                                                               const float *__restrict__ zero)
+{
+    extern __shared__ __attribute__((aligned(16))) float tn_lds[];
+    const long nrange = (P + range - 1) / range;
+    const long items = nrange * njobs;                                        // item = (range r, job): the jobs of one range side by side
+    for (long it = blockIdx.x; it < items; it += gridDim.x) {
+        const long r = it / njobs;
+        const TnJob &J = jobs.j[(int)(it - r * njobs)];
+        const long k_lo = r * range, k_hi = (k_lo + range < P) ? k_lo + range : P;
+        tn_block256(tn_lds, J.M, J.N, J.A, J.lda, J.B, J.ldb, J.C, J.ldc, k_lo, k_hi, J.rowsum, zero);
+    }
+}
+
 // dst[m*ldd + n] (op)= src[m*lds + n] for n < N   (mode 0 copy, 1 add)
 __global__ void copy2d_kernel(long M, int N, const float *__restrict__ src, long lds_, float *__restrict__ dst, long ldd, int mode)
 {
@@ -1585,31 +1736,50 @@ __global__ void add_rows8_kernel(long n, const float *__restrict__ a, float *__r
     }
 }
 
-// the job table of one part -> one launch
+// the job tables of one part -> one launch each: the wide layers (M, N in (128, 256]: whole 256 x 256 blocks per workgroup) and the rest
 struct TnList {
-    TnBatch b; int n = 0, tiles = 0;
+    TnBatch b, w; int n = 0, tiles = 0, nw = 0;
     void add(const float *dY, long ldy, int M, const float *X, long ldx, int N, float *dW, long ldw, float *db = nullptr)
     {
+        static const bool no_wide = getenv("SAHS_BWD_TN_NOWIDE") != nullptr;      // (A/B aid: everything through the 128 x 128 tiles)
+        if (!no_wide && M <= 256 && N <= 256 && M >= 128 && N >= 128 && (M > 128 || N > 128)) {
+            if (nw < MAX_TN_JOBS) w.j[nw] = TnJob{dY, X, dW, db, ldy, ldx, ldw, M, N};
+            ++nw;
+            return;
+        }
         if (n < MAX_TN_JOBS) b.j[n] = TnJob{dY, X, dW, db, ldy, ldx, ldw, M, N};
         ++n;
         tiles += ((N + GT - 1) / GT) * ((M + GT - 1) / GT);
     }
     int launch(long P, const float *zero, int num_cu, hipStream_t st)
     {
-        if (n > MAX_TN_JOBS) return (int)hipErrorOutOfMemory;
-        static sahs_once::Flags attr_set;
-        const hipError_t ae = sahs_once::per_device(attr_set, [&]() {
+        if (n > MAX_TN_JOBS || nw > MAX_TN_JOBS) return (int)hipErrorOutOfMemory;
+        static sahs_once::Flags attr_set, attr_set_w;
+        hipError_t ae = sahs_once::per_device(attr_set, [&]() {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_jobs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
         });
         if (ae != hipSuccess) return (int)ae;
-        const int G = 2 * num_cu / 8 * 8;                     // two 80-KB workgroups per CU
-        // ~3 rounds of equal items: ranges of >= 1024 samples (a multiple of 16), as many as fill G workgroups three times
-        static const long rounds = getenv("SAHS_BWD_TN_ROUNDS") ? atol(getenv("SAHS_BWD_TN_ROUNDS")) : 3;      // (tuning aid)
-        long nsplit = rounds * G / (tiles > 0 ? tiles : 1);
-        if (nsplit < 1) nsplit = 1;
-        long range = ((P + nsplit - 1) / nsplit + 15) / 16 * 16;
-        if (range < 1024) range = 1024;
-        gemm_tn_jobs_kernel<<<G, TN_THREADS, TN_LDS_BYTES, st>>>(b, n, tiles, P, range, zero);
+        ae = sahs_once::per_device(attr_set_w, [&]() {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_jobs256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES);
+        });
+        if (ae != hipSuccess) return (int)ae;
+        // ranges of >= 1024 samples (a multiple of 16), `rounds` rounds of equal items per workgroup: fewer, longer items mean fewer atomic
+        // epilogues (measured on the training step: wide kernel 1.21 / 1.24 / 1.27 / 1.31 ms at 1 / 2 / 3 / 5 rounds; the narrow one is flat)
+        static const long rounds_env = getenv("SAHS_BWD_TN_ROUNDS") ? atol(getenv("SAHS_BWD_TN_ROUNDS")) : 0;      // (tuning aid)
+        auto range_for = [&](long workgroups, int units, long rounds) {
+            long nsplit = (rounds_env > 0 ? rounds_env : rounds) * workgroups / (units > 0 ? units : 1);
+            if (nsplit < 1) nsplit = 1;
+            long range = ((P + nsplit - 1) / nsplit + 15) / 16 * 16;
+            return range < 1024 ? 1024L : range;
+        };
+        if (nw > 0) {
+            gemm_tn_jobs256_kernel<<<num_cu, TN_THREADS, TW_LDS_BYTES, st>>>(w, nw, P, range_for(num_cu, nw, 1), zero);      // one 128-KB workgroup per CU
+            if (hipGetLastError() != hipSuccess) return (int)hipErrorLaunchFailure;
+        }
+        if (n > 0) {
+            const int G = 2 * num_cu / 8 * 8;                     // two 80-KB workgroups per CU
+            gemm_tn_jobs_kernel<<<G, TN_THREADS, TN_LDS_BYTES, st>>>(b, n, tiles, P, range_for(G, tiles, 2), zero);
+        }
         return (int)hipGetLastError();
     }
 };
