@@ -245,10 +245,15 @@ struct BwdEp {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(base) + (size_t)TILE * (sc.np * 128u) + (sc.prow[i] * 128u + sc.pc)) = v[i];
-#else
+#elif defined(SAHS_DIAG) && defined(SAHS_BWC_PLAINSTORE)      // A/B: default cache policy instead of non-temporal
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(base) + (sc.prow[i] * (uint32_t)(WIDTH * 4) + sc.pc + 128u * TILE)) = v[i];
+#else
+                // non-temporal: 4.4 GB of dZ per launch stream THROUGH the L2 that holds the 3 MB weight stream every workgroup re-reads
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(base) + (sc.prow[i] * (uint32_t)(WIDTH * 4) + sc.pc + 128u * TILE)));
 #endif
             }
         }

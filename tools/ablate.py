@@ -17,7 +17,7 @@ VARIANTS = {"base": ["SAHS_DIAG"],
             "x3nodma": ["SAHS_DIAG", "SAHS_X3_NODMA"], "x3nobar": ["SAHS_DIAG", "SAHS_X3_NOBARRIER"], "x3noaread": ["SAHS_DIAG", "SAHS_X3_NOAREAD"],
             "x3floor": ["SAHS_DIAG", "SAHS_X3_NODMA", "SAHS_X3_NOBARRIER", "SAHS_X3_NOAREAD"],
             # the backward chain kernels (csrc/field_bwd_chain.hip): what they wait for (tools/ab_chain.sh runs them under rocprofv3)
-            "cnostore": ["SAHS_DIAG", "SAHS_BWC_NOSTORE"], "cnogstore": ["SAHS_DIAG", "SAHS_BWC_NOGSTORE"], "ctilemajor": ["SAHS_DIAG", "SAHS_BWC_TILEMAJOR"],
+            "cnostore": ["SAHS_DIAG", "SAHS_BWC_NOSTORE"], "cnogstore": ["SAHS_DIAG", "SAHS_BWC_NOGSTORE"], "ctilemajor": ["SAHS_DIAG", "SAHS_BWC_TILEMAJOR"], "cplainstore": ["SAHS_DIAG", "SAHS_BWC_PLAINSTORE"],
             "cnomask": ["SAHS_DIAG", "SAHS_BWC_NOMASK"], "cnostore_nomask": ["SAHS_DIAG", "SAHS_BWC_NOSTORE", "SAHS_BWC_NOMASK"]}
 
 
