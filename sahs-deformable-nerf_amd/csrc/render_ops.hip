@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(RS_WAVES * 64) resample_kernel(long N, int S, 
                                                                  float *__restrict__ z_samples, float *__restrict__ z_out,
                                                                  long long *__restrict__ inds_out, int *__restrict__ src_out)
 {   // src_out (N, S+nf), optional: the merge permutation -- position `rank` of the sorted row holds element src of cat(z, samples)
-    __shared__ float s_cdf[RS_WAVES][RS_MAX], s_bins[RS_WAVES][RS_MAX], s_val[RS_WAVES][2 * RS_MAX];
+    __shared__ __attribute__((aligned(16))) float s_cdf[RS_WAVES][RS_MAX], s_bins[RS_WAVES][RS_MAX], s_val[RS_WAVES][2 * RS_MAX];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float *cdf = s_cdf[wv], *bins = s_bins[wv], *val = s_val[wv];
     const int nb = S - 1;                     // bins; pdf has nb-1 entries
@@ -263,19 +263,77 @@ __global__ void __launch_bounds__(RS_WAVES * 64) resample_kernel(long N, int S, 
         }
         __builtin_amdgcn_wave_barrier();      // LDS ops of one wave execute in order; this only pins the compiler
         // torch.sum in ATen's own summation order, torch.cumsum accumulated in double and rounded per prefix (ATen CPU's acc_type<float>):
-        // a cdf knot that moves by an ulp moves a searchsorted index (every lane redundantly; LDS broadcast reads)
-        const float sum = aten_row_sum(cdf + 1, nb - 1);
-        double c = 0.0;
-        for (int base = 1; base < nb; base += 64) {
-            const int cnt = (nb - base) < 64 ? (nb - base) : 64;
-            float keep = 0.0f;
-            for (int t = 0; t < cnt; ++t) {
-                c += (double)(cdf[base + t] / sum);
-                if (t == lane) keep = (float)c;
+        // a cdf knot that moves by an ulp moves a searchsorted index.  Round 4: the same numbers with the work spread over the lanes --
+        // (a) the eight vector-lane partial sums of ATen's row sum by eight lanes, (b) the quotients w'/sum one per lane, (c) the float64
+        // prefix sums by a lane scan WHEN THAT IS EXACT: every partial sum of <= 255 floats whose exponents span <= 2^20 fits a double's 53
+        // bits, so any order of additions gives the sequential cumsum's bits; otherwise (weights spanning more) the sequential loop.
+        const int np = nb - 1;                 // pdf entries, w' in cdf[1 .. np]
+        float sum;
+        if (np >= 8) {
+            const int vs = np >> 3, g = vs >> 2;
+            if (lane < 8) {
+                const float *x = cdf + 1;
+                float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+                for (int i = 0; i < g; ++i) {
+                    p0 += x[(4 * i) * 8 + lane]; p1 += x[(4 * i + 1) * 8 + lane]; p2 += x[(4 * i + 2) * 8 + lane]; p3 += x[(4 * i + 3) * 8 + lane];
+                }
+                for (int i = 4 * g; i < vs; ++i) p0 += x[i * 8 + lane];
+                p0 += p1; p0 += p2; p0 += p3;
+                val[S + lane] = p0;            // (val[S ..] is free until the samples are written)
             }
             __builtin_amdgcn_wave_barrier();
-            if (lane < cnt) cdf[base + lane] = keep;   // positions already consumed as w'
-            __builtin_amdgcn_wave_barrier();
+            float acc = 0.0f;
+            for (int k = vs * 8; k < np; ++k) acc += cdf[1 + k];
+            for (int l = 0; l < 8; ++l) acc += val[S + l];
+            sum = acc;
+        } else {
+            sum = aten_row_sum(cdf + 1, np);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // quotients (one IEEE division per entry, as torch's weights / sum) and their exponent span
+        int emin = 255, emax = 0;
+        for (int i = lane; i < np; i += 64) {
+            const float q = cdf[1 + i] / sum;
+            cdf[1 + i] = q;
+            const int e = (__float_as_int(q) >> 23) & 255;
+            if (q != 0.0f) { emin = e < emin ? e : emin; emax = e > emax ? e : emax; }
+            if (!(q == q) || e == 255) { emin = 0; emax = 255; }      // NaN / inf: take the sequential path
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int a_ = __shfl_xor(emin, o, WAVE), b_ = __shfl_xor(emax, o, WAVE);
+            emin = a_ < emin ? a_ : emin; emax = b_ > emax ? b_ : emax;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (emax - emin <= 20) {
+            double carry = 0.0;
+            for (int base = 0; base < np; base += 64) {
+                const int i = base + lane;
+                double c = i < np ? (double)cdf[1 + i] : 0.0;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const double up = __shfl_up(c, o, WAVE);
+                    if (lane >= o) c += up;
+                }
+                c += carry;
+                carry = __shfl(c, 63, WAVE);
+                __builtin_amdgcn_wave_barrier();
+                if (i < np) cdf[1 + i] = (float)c;
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            double c = 0.0;
+            for (int base = 1; base < nb; base += 64) {
+                const int cnt = (nb - base) < 64 ? (nb - base) : 64;
+                float keep = 0.0f;
+                for (int t = 0; t < cnt; ++t) {
+                    c += (double)cdf[base + t];
+                    if (t == lane) keep = (float)c;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < cnt) cdf[base + lane] = keep;
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         if (lane == 0) cdf[0] = 0.0f;
         __builtin_amdgcn_wave_barrier();
@@ -294,17 +352,48 @@ __global__ void __launch_bounds__(RS_WAVES * 64) resample_kernel(long N, int S, 
             if (inds_out != nullptr) inds_out[ray * nf + j] = lo;
         }
         __builtin_amdgcn_wave_barrier();
-        // rank sort of the S+nf values (ascending; equal values keep index order)
+        // rank sort of the S+nf values (ascending; equal values keep index order).  The depths z of a ray arrive sorted (stratified bins), so
+        // rank(z_a) = a + #{samples < z_a} and rank(sample_j) = #{z <= sample_j} + #{samples before it in the stable order}: half the
+        // comparisons, four values per LDS read; rows that are not sorted (the seam accepts any z) take the general count.
         const int M = from_z ? S + nf : 0;
-        for (int a = lane; a < M; a += 64) {
-            const float v = val[a];
-            int rank = 0;
-            for (int b = 0; b < M; ++b) {
-                const float o = val[b];
-                rank += (o < v || (o == v && b < a)) ? 1 : 0;
+        bool sorted = true;
+        for (int i = lane; i + 1 < S && M > 0; i += 64) sorted = sorted && (val[i] <= val[i + 1]);
+        sorted = __all(sorted);
+        if (M > 0 && sorted && (nf & 3) == 0 && (S & 3) == 0) {      // (16-byte LDS reads of the samples: S and nf multiples of 4)
+            for (int a = lane; a < M; a += 64) {
+                const float v = val[a];
+                int rank;
+                if (a < S) {
+                    rank = a;
+                    for (int b = 0; b < nf; b += 4) {
+                        const f32x4 o = *reinterpret_cast<const f32x4 *>(val + S + b);
+                        rank += (o[0] < v) + (o[1] < v) + (o[2] < v) + (o[3] < v);
+                    }
+                } else {
+                    int lo = 0, hi = S;              // #{z_b <= v}: first index with z > v
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (val[mid] <= v) lo = mid + 1; else hi = mid; }
+                    rank = lo;
+                    const int j = a - S;
+                    for (int b = 0; b < nf; b += 4) {
+                        const f32x4 o = *reinterpret_cast<const f32x4 *>(val + S + b);
+                        rank += (o[0] < v || (o[0] == v && b < j)) + (o[1] < v || (o[1] == v && b + 1 < j)) + (o[2] < v || (o[2] == v && b + 2 < j)) +
+                                (o[3] < v || (o[3] == v && b + 3 < j));
+                    }
+                }
+                z_out[ray * M + rank] = v;
+                if (src_out != nullptr) src_out[ray * M + rank] = a;
             }
-            z_out[ray * M + rank] = v;
-            if (src_out != nullptr) src_out[ray * M + rank] = a;
+        } else {
+            for (int a = lane; a < M; a += 64) {
+                const float v = val[a];
+                int rank = 0;
+                for (int b = 0; b < M; ++b) {
+                    const float o = val[b];
+                    rank += (o < v || (o == v && b < a)) ? 1 : 0;
+                }
+                z_out[ray * M + rank] = v;
+                if (src_out != nullptr) src_out[ray * M + rank] = a;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
