@@ -165,13 +165,18 @@ __global__ void __launch_bounds__(256) composite_forward_kernel(long N, int S, c
             if (last) sg += 1e-6f;
             const float alpha = 1.0f - expf(-sg * dist);
             const float f = (1.0f - alpha) + 1e-10f;
-            // exclusive cumprod in sample order
-            float myT = 1.0f;
-            const int cnt = (S - i * 64) < 64 ? (S - i * 64) : 64;
-            for (int k = 0; k < cnt; ++k) {   // k is wave-uniform: v_readlane broadcasts lane k's factor
-                if (lane == k) myT = T;
-                T = T * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), k));
-            }
+            // exclusive cumprod in sample order, the reference's association ((T f0) f1) ...: P_k = P_{k-1} * f_k with P_{-1} = T carried in from
+            // the previous 64 samples.  One in-place DPP multiply per step on ALL lanes (wave_shr:1 hands lane k the value of lane k - 1): after
+            // step s lanes <= s hold their final product and every later step recomputes the same value from a final left neighbour -- 63
+            // multiplies (+ their s_nop) instead of the 256 instructions of a broadcast (v_readlane), select and multiply per sample; same bits.
+            const float fv = valid ? f : 1.0f;                    // lanes past S multiply by one: the carry stays the product of the real samples
+            float Pk = T * fv;                                    // lane 0 is final from the start; lane k after step k
+#pragma unroll
+            for (int k = 0; k < 63; ++k)      // in place: lanes >= 1 take the left neighbour's product times their factor, lane 0 (no source lane) keeps its value
+                asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(Pk) : "v"(fv));
+            const float sh = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(T), __float_as_int(Pk), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+            const float myT = sh;                                 // T_k = P_{k-1}
+            T = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Pk), 63));
             const float w = valid ? alpha * myT : 0.0f;
             if (valid) weights[ray * S + s] = w;
             if (valid && last && w_last != nullptr) w_last[ray * sc_ld] = w;
