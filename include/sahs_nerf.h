@@ -289,8 +289,9 @@ int sahs_model_render_rays_rows(int model, const void *packed, const float *fram
  * The elementwise core of SPADELayer.forward followed by its SPADEBlock's LeakyReLU (nerf/_init_spade.py:130-139, :262-279):
  *   out = lrelu_slope( InstanceNorm2d(x; eps, biased variance, no affine) * (1 + gamma) + beta )
  * over `planes` = N*C contiguous planes of `hw` = H*W floats each (NCHW); gamma, beta, out have x's shape; slope 1 = no activation;
- * stats: 2 * planes floats of workspace (mean, 1/sqrt(var + eps) per plane).  The convolutions that produce gamma / beta stay library
+ * stats: sahs_spade_modulate_workspace_words(planes) floats of workspace (per plane: chunk sums and chunk sums of squares about the mean).  The convolutions that produce gamma / beta stay library
  * calls (MIOpen through PyTorch): sahs-deformable-nerf_amd/spade.py. */
+long sahs_spade_modulate_workspace_words(long planes);
 int sahs_spade_modulate(long planes, long hw, const float *x, const float *gamma, const float *beta, float eps, float slope, float *out,
                         float *stats, void *stream);
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     "sahs_model_field_forward_save": (_I, [_I, _P, _P, _I, _L, _I, _P, _I, _P, _P, _P, _P]),
     "sahs_model_field_backward": (_I, [_I, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
     "sahs_backward_gemm_precision": (_I, [_I]),
+    "sahs_spade_modulate_workspace_words": (_L, [_L]),
     "sahs_spade_modulate": (_I, [_L, _L, _P, _P, _P, _F, _F, _P, _P, _P]),
     "sahs_probe_arm": (_I, [_I]),
     "sahs_probe_disarm": (_I, []),

@@ -45,6 +45,7 @@ int sahs_resample_launch(long N, int S, int nf, int from_z, const float *z, cons
                          float *z_out, long long *inds, int *src, hipStream_t stream);
 int sahs_ray_uniforms_launch(unsigned long long seed, int stream_id, long ray0, long N, int S, float *out, hipStream_t stream);
 int sahs_route_xw_grad_launch(long N, int Sc, int nf, const int *src, const float *g_fine, float *g_coarse, float *g_new, hipStream_t stream);
+long sahs_spade_stats_words(long planes);
 int sahs_spade_modulate_launch(long planes, long hw, const float *x, const float *gamma, const float *beta, float eps, float slope, float *out,
                                float *stats, hipStream_t stream);
 // the NeRFaceModel builds of pack.hip / field_f32.hip (sahs_model.hpp: SAHS_MODEL=1 suffix _nf, SAHS_MODEL=2 suffix _ns)
@@ -793,6 +794,8 @@ int sahs_route_xw_grad(long N, int Sc, int nf, const int32_t *src, const float *
     int e = sahs_route_xw_grad_launch(N, Sc, nf, src, g_fine, g_coarse, g_new, (hipStream_t)stream);
     return e ? hip_fail("sahs_route_xw_grad", e) : 0;
 }
+
+long sahs_spade_modulate_workspace_words(long planes) { return planes > 0 ? sahs_spade_stats_words(planes) : 0; }
 
 int sahs_spade_modulate(long planes, long hw, const float *x, const float *gamma, const float *beta, float eps, float slope, float *out,
                         float *stats, void *stream)

@@ -325,7 +325,7 @@ def spade_modulate(x, gamma, beta, eps=1e-5, slope=1.0):
         raise _lib.SahsError("spade_modulate: x, gamma, beta must be NCHW tensors of one shape, got %s %s %s" % (tuple(x.shape), tuple(gamma.shape), tuple(beta.shape)))
     planes, hw = x.shape[0] * x.shape[1], x.shape[2] * x.shape[3]
     out = torch.empty_like(x)
-    stats = torch.empty(2 * planes, dtype=torch.float32, device=x.device)
+    stats = torch.empty(int(_lib.lib().sahs_spade_modulate_workspace_words(planes)), dtype=torch.float32, device=x.device)
     check(_lib.lib().sahs_spade_modulate(planes, hw, _p(x), _p(gamma), _p(beta), float(eps), float(slope), _p(out), _p(stats), _stream()), "sahs_spade_modulate")
     return out
 
