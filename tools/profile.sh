@@ -10,12 +10,12 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 B="python3 bench.py --no-secondary --no-cpu-baseline"
 has() { [[ " $LEGS " == *" $1 "* ]]; }
-for L in "f32|--precision fp32|2" "bf16|--precision bf16|4" "bf16x3|--precision bf16x3|2" "nfmixed|--arch nerface --precision bf16|3"; do
+for L in "f32|--precision fp32|8" "bf16|--precision bf16|100" "bf16x3|--precision bf16x3|25" "nfmixed|--arch nerface --precision bf16|80"; do
   IFS="|" read NAME ARGS STEPS <<< "$L"
   has $NAME || continue
   rm -rf $OUT/trace_$NAME
   # GPU power / clock while the leg runs ("power-limited" as a measurement): rocm-smi sampled beside the profiled program
-  ( while true; do rocm-smi --showpower --showclocks --json 2>/dev/null | tr -d '\n'; echo; sleep 0.5; done ) > $OUT/smi_$NAME.jsonl &
+  ( while true; do rocm-smi --showpower --showclocks --json 2>/dev/null | tr -d '\n'; echo; sleep 0.1; done ) > $OUT/smi_$NAME.jsonl &
   SMI=$!
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$NAME -- $B $ARGS --steps $STEPS --warmup 1 > $OUT/bench_trace_$NAME.json 2> $OUT/trace_$NAME.err
   kill $SMI 2>/dev/null; wait $SMI 2>/dev/null

@@ -65,12 +65,12 @@ def kind(kn, leg):
 
 
 stats = {}
-for leg, args, steps, what in (("f32", "--precision fp32", 2, "fp32 W512 headline; per 131,072-ray chunk: field<false,0> = coarse launch (8.39 M samples, whole network), "
+for leg, args, steps, what in (("f32", "--precision fp32", 8, "fp32 W512 headline; per 131,072-ray chunk: field<false,0> = coarse launch (8.39 M samples, whole network), "
                                 "<false,1> = deformation nets on the 8.39 M new depths, <false,2> = radiance nets on the 16.78 M fine samples"),
-                               ("bf16", "--precision bf16", 4, "bf16 W512: field_forward_bf16w_kernel<0|1|2>, same three launches per chunk"),
-                               ("bf16x3", "--precision bf16x3", 2, "bf16x3 W512: field_deform_bf16x3_kernel (deformation nets, coarse and new depths: 8.39 M samples each) + "
+                               ("bf16", "--precision bf16", 100, "bf16 W512: field_forward_bf16w_kernel<0|1|2>, same three launches per chunk"),
+                               ("bf16x3", "--precision bf16x3", 25, "bf16x3 W512: field_deform_bf16x3_kernel (deformation nets, coarse and new depths: 8.39 M samples each) + "
                                 "field_radiance_bf16x3_kernel on the 8.39 M coarse and the 16.78 M fine samples of a chunk"),
-                               ("nfmixed", "--arch nerface --precision bf16", 3, "NeRFaceModel (config/expression/person_2.yml) in mixed precision: deformation launches with split bf16 "
+                               ("nfmixed", "--arch nerface --precision bf16", 80, "NeRFaceModel (config/expression/person_2.yml) in mixed precision: deformation launches with split bf16 "
                                 "operands (sahs_nf::hx3::field_deform_bf16x3_kernel) + sahs_nf::field_forward_bf16w_kernel<2> radiance launches")):
     if not glob.glob(os.path.join(base, "trace_" + leg, "*", "*_kernel_stats.csv")):
         continue
@@ -177,7 +177,8 @@ except (IndexError, OSError) as e:
     lines.append("# training-step counters missing: %r" % (e,))
 # ---- GPU power / clock sampled by rocm-smi beside each traced leg (tools/profile.sh) ----
 def smi_summary(path):
-    pw, ck = [], []
+    """-> list of (power W, sclk MHz) samples"""
+    out = []
     for ln in open(path):
         try:
             d = json.loads(ln)
@@ -186,27 +187,32 @@ def smi_summary(path):
         for card in d.values():
             if not isinstance(card, dict):
                 continue
+            pw = ck = None
             for k, v in card.items():
                 kl = k.lower()
                 try:
                     if "power" in kl and "(w)" in kl:
-                        pw.append(float(v))
+                        pw = float(v)
                     elif kl.startswith("sclk clock speed"):
-                        ck.append(float(str(v).strip("()").lower().replace("mhz", "")))
+                        ck = float(str(v).strip("()").lower().replace("mhz", ""))
                 except ValueError:
                     pass
-    return pw, ck
+            if pw is not None and ck is not None:
+                out.append((pw, ck))
+    return out
 
 
 for leg in ("f32", "bf16", "bf16x3", "nfmixed"):
     f = os.path.join(base, "smi_%s.jsonl" % leg)
     if os.path.exists(f):
-        pw, ck = smi_summary(f)
-        if pw:
-            busy = [p for p in pw if p > 0.6 * max(pw)]
-            lines += ["", "# rocm-smi beside the %s trace leg (0.5 s samples): socket power max %.0f W, mean of the loaded samples %.0f W (%d of %d samples)%s"
-                      % (leg, max(pw), sum(busy) / len(busy), len(busy), len(pw), (", sclk max %.0f MHz / min under load %.0f MHz" % (max(ck), min(ck))) if ck else "")]
-            summary.setdefault("smi", {})[leg] = {"power_max_w": max(pw), "power_loaded_mean_w": sum(busy) / len(busy), "sclk_mhz": ck[-5:] if ck else None}
+        sm = smi_summary(f)
+        if sm:
+            top = max(p for p, _ in sm)
+            busy = [(p, c) for p, c in sm if p > 0.8 * top]
+            mp, mc = sum(p for p, _ in busy) / len(busy), sum(c for _, c in busy) / len(busy)
+            lines += ["", "# rocm-smi beside the %s trace leg: %d samples, %d of them under load (socket power > 0.8 x its maximum %.0f W): mean %.0f W at a mean sclk of %.0f MHz "
+                      "(min %.0f, max %.0f MHz under load)" % (leg, len(sm), len(busy), top, mp, mc, min(c for _, c in busy), max(c for _, c in busy))]
+            summary.setdefault("smi", {})[leg] = {"samples_under_load": len(busy), "power_max_w": top, "power_mean_w": mp, "sclk_mean_mhz": mc}
 open(os.path.join(out, tag + "_pmc_summary.csv"), "w").write("\n".join(lines) + "\n")
 json.dump(summary, open(os.path.join(out, tag + "_pmc_summary.json"), "w"), indent=1)
 print("\n".join(lines[-40:]))
