@@ -157,7 +157,7 @@ try:
     tr = collections.OrderedDict()
     for a, b in zip(fs, ws):
         n = a["Kernel_Name"]
-        nm = ("weight gradients, one launch per part: gemm_tn_jobs_kernel" if "gemm_tn_jobs_kernel" in n else "data-gradient chain field_backward_chain_*_kernel" if "field_backward_chain" in n else
+        nm = ("weight gradients over job tables: gemm_tn_jobs_kernel + gemm_tn_jobs256_kernel" if "gemm_tn_jobs" in n else "data-gradient chain field_backward_chain_*_kernel" if "field_backward_chain" in n else
               "weight-gradient GEMM gemm_tn_split_kernel" if "gemm_tn_split_kernel" in n else "weight-gradient GEMM gemm_dma_kernel<true,*>" if "gemm_dma_kernel<true" in n else "data-gradient GEMM gemm_dma_kernel<false,true>" if "gemm_dma_kernel<false" in n
               else "field_forward_f32_kernel<true,*> (activation-saving forward)" if "field_forward" in n else "gemm_f32_kernel" if "gemm_f32" in n else "other")
         d = tr.setdefault(nm, [0, 0.0, 0.0, 0.0])
