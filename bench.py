@@ -58,7 +58,7 @@ HDR = dict(seed=0, density_bias=2.0, density_gain=30.0, hdr=True)      # = VARIA
 # (WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction for 16 B/lane streaming reads).  STATIC: bench.py cannot collect PMCs itself; the
 # numbers are read from the summary that tools/profile_r2.sh wrote under profiles/.
 def _static_traffic():
-    for name in ("r3_pmc_summary.json", "r2_pmc_summary.json"):
+    for name in ("r4_pmc_summary.json", "r3_pmc_summary.json", "r2_pmc_summary.json"):
         try:
             d = json.load(open(os.path.join(REPO, "profiles", name)))
             out = {"fp32": (d["f32_radiance"]["traffic_bytes"], "profiles/%s:f32_radiance" % name),

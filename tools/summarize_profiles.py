@@ -40,7 +40,7 @@ def newest(pattern):
 
 def mode_of(kn, lead):
     for m in "012":
-        if "%s%s>" % (lead, m) in kn or "ILi%sE" % m in kn or "ELi%sE" % m in kn:
+        if "%s%s>" % (lead, m) in kn or "%s%s," % (lead, m) in kn or "ILi%sE" % m in kn or "ELi%sE" % m in kn:
             return m
     return None
 
