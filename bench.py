@@ -333,16 +333,19 @@ def add_secondary_legs(result, pkg, dev, args):
     result["train_T2048"] = train_leg(pkg, dev, backward="fp32")
     progress("train_T2048_bf16x3 leg (the library's default: backward products as three bf16 MFMAs)")
     result["train_T2048_bf16x3"] = train_leg(pkg, dev, backward="bf16x3")
+    progress("train_T2048_x3fwd leg (opt-in: the saving forward on the split-operand kernels too)")
+    result["train_T2048_x3fwd"] = train_leg(pkg, dev, backward="bf16x3", forward="bf16x3")
     progress("spade leg (Stage-II generator inference, SURVEY.md section 8f-4)")
     result["spade"] = spade_leg(pkg, dev)
 
 
-def train_leg(pkg, dev, rays=2048, steps=5, warmup=2, backward="fp32"):
+def train_leg(pkg, dev, rays=2048, steps=5, warmup=2, backward="fp32", forward="fp32"):
     """BASELINE.json configs[4]: 2048 semantically-weighted rays, train mode (noise 0.1), forward + backward through the HIP autograd
     op and the reference's loss recipe (train_stage_rays_auto.py:437-499); no optimiser step (not part of the path).
     backward: arithmetic of the backward's dense-layer products -- "fp32" = f32 MFMAs, the reference's precision (the entry named
-    train_T2048); "bf16x3" = split bf16 operands, three bf16 MFMAs per product (train_T2048_bf16x3, the library's default).  The forward is
-    the fp32 kernel in both."""
+    train_T2048); "bf16x3" = split bf16 operands, three bf16 MFMAs per product (train_T2048_bf16x3, the library's default).
+    forward: arithmetic of the saving forward launches -- "fp32" (the fp32 kernel, both entries above) or "bf16x3" (the split-operand
+    kernels also write the saved activations and sign bits: ops.training_forward_precision, the entry train_T2048_x3fwd)."""
     W, Tr = pkg.weights, pkg.training
     cfg = pkg.default_config()
     model = pkg.AudioFaceModel(cfg).to(dev).load_flat(W.flatten_state_dict(W.hash_state_dict(**HDR))).train()
@@ -372,8 +375,9 @@ def train_leg(pkg, dev, rays=2048, steps=5, warmup=2, backward="fp32"):
         loss.backward()
         return loss
 
-    before = pkg.ops.backward_gemm_precision()
+    before, before_fwd = pkg.ops.backward_gemm_precision(), pkg.ops.training_forward_precision()
     pkg.ops.backward_gemm_precision(backward)
+    pkg.ops.training_forward_precision(forward)
     try:
         for _ in range(warmup):
             step()
@@ -385,11 +389,12 @@ def train_leg(pkg, dev, rays=2048, steps=5, warmup=2, backward="fp32"):
         dt = (time.perf_counter() - t0) / steps
     finally:
         pkg.ops.backward_gemm_precision(before)
+        pkg.ops.training_forward_precision(before_fwd)
     assert bool(torch.isfinite(loss))
-    return train_record(pkg, rays, dt, steps, backward)
+    return train_record(pkg, rays, dt, steps, backward, forward=forward)
 
 
-def train_record(pkg, rays, dt, steps, backward, nc=64, nf=64):
+def train_record(pkg, rays, dt, steps, backward, nc=64, nf=64, forward="fp32"):
     """The JSON entry of a training leg.  roofline.frac = the time the step's EXECUTED matrix work needs at each pipe's peak, summed over
     the pipes, divided by the step time: forward launches (fp32 kernel: nc whole-network + nf deformation + (nc + nf) radiance evaluations
     per ray, padded tiles as issued) on the f32 MFMA pipe; backward = two products per forward MAC (data gradient, weight gradient) on the
@@ -398,14 +403,20 @@ def train_record(pkg, rays, dt, steps, backward, nc=64, nf=64):
     ex = lambda part: 2 * pkg.ops.executed_macs_per_sample("audio", pkg.ops.SAHS_F32, part)
     fwd_exec = rays * (nc * ex(0) + nf * ex(1) + (nc + nf) * ex(2))                  # FLOPs issued by the saving forward launches
     bwd_products = 2 * fwd_exec                                                        # dX and dW: one product each per forward MAC
-    f32_flops = fwd_exec + (bwd_products if backward == "fp32" else 0)
+    f32_flops = (fwd_exec if forward == "fp32" else 0) + (bwd_products if backward == "fp32" else 0)
     bf16_flops = 3 * bwd_products if backward == "bf16x3" else 0
+    if forward == "bf16x3":      # the split-operand kernels' own padded tiles (32-row tiles), as three bf16 MFMAs per product
+        ex3 = lambda part: 2 * pkg.ops.executed_macs_per_sample("audio", pkg.ops.SAHS_BF16X3, part)
+        bf16_flops += rays * ((nc + nf) * ex3(1) + (nc + nc + nf) * ex3(2))
     t_f32, t_bf16 = f32_flops / (PEAK_TFLOPS["fp32"] * 1e12), bf16_flops / (PEAK_TFLOPS["bf16"] * 1e12)
     alg = rays * (2 * nc + nf) * FLOP_PER_SAMPLE["audio"] * 3 / dt / 1e12
     dtype = {"fp32": "f32", "bf16x3": "f32 forward + split-bf16 backward GEMMs (hi + lo operands, 3 bf16 MFMAs per product, f32 accumulate)"}[backward]
+    if forward == "bf16x3":
+        dtype = "split-bf16 GEMMs in forward and backward (hi + lo operands, 3 bf16 MFMAs per product, f32 accumulate)" if backward == "bf16x3" else \
+                "split-bf16 forward GEMMs (hi + lo operands, 3 bf16 MFMAs per product, f32 accumulate) + f32 backward GEMMs"
     return {"workload": "T%d: %d semantically-weighted rays, 64+128 evaluations/ray, train mode (noise 0.1), forward + loss recipe + backward"
                         % (rays, rays), "ms_per_step": dt * 1e3, "value": rays / dt, "unit": "rays/s", "dtype": dtype,
-            "backward_gemm_precision": backward, "steps": steps,
+            "backward_gemm_precision": backward, "training_forward_precision": forward, "steps": steps,
             "roofline": {"bound": "mfma", "unit": "TFLOP/s", "frac": (t_f32 + t_bf16) / dt,
                          "what": "executed MFMA FLOPs per pipe / that pipe's peak, summed, / step time",
                          "pipes": {"f32_mfma": {"executed_tflop": f32_flops / 1e12, "peak": PEAK_TFLOPS["fp32"], "ms_at_peak": t_f32 * 1e3},

@@ -270,6 +270,12 @@ long sahs_model_bits_words_part(int model, int part);
 int sahs_model_field_forward_split_save_bits(int model, const void *packed, const float *frame, int level, int mode, long N, int S, const float *rays,
                                              int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src,
                                              float *act_out, uint32_t *bits_out, void *stream);
+/* The same buffers written by the split-operand kernels (field_bf16x3.hip; `packed` = the SAHS_BF16X3 pack of the weights): the training
+ * forward at three bf16 MFMAs per product instead of fp32 MFMAs.  Modes 1 (deformation nets) and 2 (radiance nets); the saved values are
+ * those kernels' own (within a few 1e-6 relative of the fp32 kernel's), the signs are the signs of the values saved. */
+int sahs_model_field_forward_split_save_bits_x3(int model, const void *packed, const float *frame, int level, int mode, long N, int S, const float *rays,
+                                                int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src,
+                                                float *act_out, uint32_t *bits_out, void *stream);
 long sahs_model_field_backward_fused_workspace_words(int model, int part, long P);
 int sahs_model_field_backward_fused(int model, const float *flat_params, const float *frame, int level, int part, long P, const float *act_in,
                                     const uint32_t *bits_in, const float *d_raw, const float *xw_grad_in, float *xw_grad_out, float *grad_flat,

@@ -58,6 +58,7 @@ SIGNATURES = {
     "sahs_bf16_exact_leaky": (_I, [_I]),
     "sahs_model_bits_words_part": (_L, [_I, _I]),
     "sahs_model_field_forward_split_save_bits": (_I, [_I, _P, _P, _I, _I, _L, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "sahs_model_field_forward_split_save_bits_x3": (_I, [_I, _P, _P, _I, _I, _L, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "sahs_model_field_backward_fused_workspace_words": (_L, [_I, _I, _L]),
     "sahs_model_field_backward_fused": (_I, [_I, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sahs_stage1_loss_forward": (_I, [_L, _P, _P, _P, _I, _P, _P, _P, _P]),

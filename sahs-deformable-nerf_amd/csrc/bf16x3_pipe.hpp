@@ -10,7 +10,8 @@
 // EPILOGUE POLICY (EP) handed to dense_x:
 //     ep.slope                      the factor of the "other" branch (A stage: m = v * slope, skipped when slope == 1)
 //     ep.value<TILE, U>(v, m)       the value that is converted (B stage): forward max(v, m); backward bit ? v : m
-//     ep.done4<TILE, G>(r)          called once values 4G .. 4G+3 of tile TILE are final (r[0..3]): backward stores them
+//     ep.done4<TILE, G>(r, aux)     called once values 4G .. 4G+3 of tile TILE are final (r[0..3]): the saving forward and the backward store
+//                                   them; aux = two registers of scratch that live across the calls of a tile
 //     EP::stores(tile)              constexpr: done4 of that tile is ONE vector-memory store (so that a chunk's closing wait can be a COUNTED
 //                                   vmcnt that retires the next chunk's LDS-DMA but not the younger stores: end_chunk below)
 // Derived from field_bf16w.hip (one wave per SIMD: chunked weight stream through LDS-DMA, hand-issued A reads with counted lgkmcnt, bias
@@ -80,7 +81,30 @@ struct FwdAct {
     static constexpr bool stores(int) { return false; }      // done4 issues no vector-memory instruction
     float slope;
     template <int TILE, int U> __device__ __forceinline__ float value(float v, float m) const { return slope == 1.0f ? v : fmaxf(v, m); }
-    template <int TILE, int G> __device__ __forceinline__ void done4(const float (&)[4]) const {}
+    template <int TILE, int G> __device__ __forceinline__ void done4(const float (&)[4], uint32_t (&)[2]) const {}
+};
+
+// the SAVING forward's epilogue (training with the forward on this pipe): the activation, the post-activation values stored to the layer's
+// plane of the saved-activation buffer (sahs_layout.hpp: act; 16 bytes per lane and group, non-temporal), and their signs as the bytes of
+// the lane's two sign words (sbits: this lane (sample, h) owns words q = h and q = 2 + h outright; byte TILE of word h = groups 0 | 2,
+// of word 2 + h = groups 1 | 3)
+struct SaveAct {
+    static constexpr bool stores(int) { return true; }
+    float slope;
+    float *slot;              // this lane's slot of the layer's activation plane: its sample's row + 4 h floats (a per-lane pointer: with a uniform
+                              // plane base + a 32-bit lane offset the ~25 bases of the radiance kernel end in "illegal VGPR to SGPR copy" in the backend)
+    unsigned char *sign;      // this lane's sign word q = h of the layer's plane (null: no mask behind this layer); word 2 + h is `sign2` bytes further
+    uint32_t sign2;
+    template <int TILE, int U> __device__ __forceinline__ float value(float v, float m) const { return slope == 1.0f ? v : fmaxf(v, m); }
+    template <int TILE, int G> __device__ __forceinline__ void done4(const float (&r)[4], uint32_t (&aux)[2]) const
+    {
+        __builtin_nontemporal_store(f32x4{r[0], r[1], r[2], r[3]}, reinterpret_cast<f32x4 *>(slot + (32 * TILE + 8 * G)));
+        if (sign != nullptr) {
+            const uint32_t nib = (r[0] > 0.0f ? 1u : 0u) | (r[1] > 0.0f ? 2u : 0u) | (r[2] > 0.0f ? 4u : 0u) | (r[3] > 0.0f ? 8u : 0u);
+            if constexpr (G < 2) aux[G] = nib;
+            else sign[(G & 1) * sign2 + TILE] = (unsigned char)(aux[G - 2] | (nib << 4));
+        }
+    }
 };
 
 // ---- epilogue + hi/lo conversion of a finished accumulator tile, software-pipelined (field_bf16w.hip: pack_tick) -------------------
@@ -89,7 +113,7 @@ struct FwdAct {
 //                                        C(T-2)  hi dword = cvt_pk(r_{T-3}, r_{T-2})                       when T-2 is odd
 //                                        D(T-3)  e = r - float(hi) for both values of the pair              when T-3 is odd
 //                                        E(T-4)  lo dword = cvt_pk(e0, e1)                                  when T-4 is odd
-struct PackState { f32x2 m2[2]; float r[4]; uint32_t hi[2]; float e[2][2]; };
+struct PackState { f32x2 m2[2]; float r[4]; uint32_t hi[2]; float e[2][2]; uint32_t aux[2]; };      // aux: scratch of the epilogue policy (sign nibbles)
 constexpr int NV = 16;
 constexpr int PACK_TICKS = NV + 5;
 template <int T, int TILE, class EP>
@@ -103,7 +127,7 @@ __device__ __forceinline__ void pack_tick(const f32x16 &acc, Blk &o, const EP ep
         constexpr int U = T - 1, P = U >> 1, e = U & 1;
         const float v = acc[2 * P + e];
         ps.r[U & 3] = ep.template value<TILE, U>(v, ps.m2[P & 1][e]);
-        if constexpr ((U & 3) == 3) ep.template done4<TILE, (U >> 2)>(ps.r);
+        if constexpr ((U & 3) == 3) ep.template done4<TILE, (U >> 2)>(ps.r, ps.aux);
     }
     if constexpr (T - 2 >= 1 && T - 2 < NV && ((T - 2) & 1)) {    // C(T-2): the pair (U-1, U) is complete -> hi
         constexpr int U = T - 2, P = U >> 1, s = P >> 2, jp = P & 3;

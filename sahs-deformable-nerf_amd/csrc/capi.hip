@@ -108,6 +108,12 @@ int sahs_field_deform_bf16x3_launch_nf(const float *packed, const float *frame, 
                                        const float *zvals, float *xw, int xw_row, int xw_col0, int num_cu, hipStream_t stream);
 int sahs_field_radiance_bf16x3_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                       float *raw, const float *xw, int xw_row, const int *src, int num_cu, hipStream_t stream);
+// ... that also write the saved activations and sign-bit planes of their part (training with the forward on this pipe)
+int sahs_field_deform_bf16x3_save_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
+                                         const float *zvals, float *xw, int xw_row, int xw_col0, float *actbuf, uint32_t *bits, int num_cu, hipStream_t stream);
+int sahs_field_radiance_bf16x3_save_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
+                                           float *raw, const float *xw, int xw_row, const int *src, float *actbuf, uint32_t *bits, int num_cu,
+                                           hipStream_t stream);
 // NeRFaceModel without deformation nets (person_1.yml): the whole network in bf16
 long sahs_layout_packed_words_bf16_ns(void);
 int sahs_pack_weights_bf16_launch_ns(const float *flat, float *packed, hipStream_t stream);
@@ -757,6 +763,33 @@ int sahs_model_field_forward_split_save_bits(int model, const void *packed, cons
     float *base = act_out - act_col0(model, mode) * P;
     int e = sahs_field_forward_f32_split_bits_launch((const float *)packed, frame, level, mode, P, S, rays, ray_stride, z, raw, xw, xw_row, xw_col0, src, base,
                                                      bits_out, num_cus(), (hipStream_t)stream);
+    return e ? hip_fail(who, e) : 0;
+}
+
+// the saving forward on the split-operand pipe: the buffers of sahs_model_field_forward_split_save_bits written by the SAHS_BF16X3 kernels
+// (`packed` = that precision's weights), modes 1 and 2
+int sahs_model_field_forward_split_save_bits_x3(int model, const void *packed, const float *frame, int level, int mode, long N, int S, const float *rays,
+                                                int ray_stride, const float *z, float *raw, float *xw, int xw_row, int xw_col0, const int32_t *src,
+                                                float *act_out, uint32_t *bits_out, void *stream)
+{
+    const char *who = "sahs_model_field_forward_split_save_bits_x3";
+    REQUIRE(model == SAHS_MODEL_AUDIO, "sahs_model_field_forward_split_save_bits_x3(AudioFaceModel only)");
+    if (N == 0) return 0;
+    REQUIRE(packed && frame && rays && xw && act_out && bits_out && (level == 0 || level == 1) && N >= 0 && S >= 1 && ray_stride >= 8 && (mode == 1 || mode == 2),
+            "sahs_model_field_forward_split_save_bits_x3(mode 1 = deformation nets or 2 = radiance nets)");
+    REQUIRE((mode == 1 || raw) && (mode == 2 || z) && (mode != 2 || src), "sahs_model_field_forward_split_save_bits_x3(buffers of the mode)");
+    REQUIRE(xw_col0 >= 0 && xw_row >= xw_col0 + (mode == 2 ? 0 : S) && ALIGNED16(xw) && ALIGNED16(packed) && ALIGNED16(frame) && (!raw || ALIGNED16(raw)) &&
+            ALIGNED16(act_out) && ALIGNED16(bits_out), "sahs_model_field_forward_split_save_bits_x3(xw layout / alignment)");
+    const long P = N * S;
+    REQUIRE(P <= 4000000L, "sahs_model_field_forward_split_save_bits_x3(at most 4e6 samples per call)");
+    float *base = act_out - act_col0(model, mode) * P;
+    hipStream_t st = (hipStream_t)stream;
+    int e = probed(probe_kind(model, SAHS_BF16X3, level, mode), P, st, [&] {
+        return mode == 1 ? sahs_field_deform_bf16x3_save_launch((const float *)packed, frame, level, P, S, rays, ray_stride, z, xw, xw_row, xw_col0, base, bits_out,
+                                                                num_cus(), st)
+                         : sahs_field_radiance_bf16x3_save_launch((const float *)packed, frame, level, P, S, rays, ray_stride, raw, xw, xw_row, src, base, bits_out,
+                                                                  num_cus(), st);
+    });
     return e ? hip_fail(who, e) : 0;
 }
 

@@ -49,8 +49,10 @@ __device__ __forceinline__ float sin_rev(float uh, float ul, float scale, float 
     const float t = (r + phase) + ul * scale;       // |t| < 1: fp32 rounding of a small number
     return __builtin_amdgcn_sinf(t - rintf(t));     // v_sin_f32 takes revolutions
 }
+// save (optional): this lane's slot of the sample's row of the encoding's saved-activation plane (row + 4 h floats): the fp32 values, natural
+// feature order -- what the backward's PE derivative and weight-gradient jobs read (training with the forward on this pipe)
 template <int D, int L, int NB>
-__device__ __forceinline__ void pe_blocks_x(const float *v, int h, Blk *out)
+__device__ __forceinline__ void pe_blocks_x(const float *v, int h, Blk *out, float *save = nullptr)
 {
     float uh[3], ul[3];
 #pragma unroll
@@ -82,14 +84,36 @@ __device__ __forceinline__ void pe_blocks_x(const float *v, int h, Blk *out)
                 split_pair(r[2 * jp], r[2 * jp + 1], hi, lo);
                 out[b].s[s][jp] = hi; out[b].l[s][jp] = lo;
             }
+            if (save != nullptr) {
+                *reinterpret_cast<f32x4 *>(save + 32 * b + 16 * s) = f32x4{r[0], r[1], r[2], r[3]};
+                *reinterpret_cast<f32x4 *>(save + 32 * b + 16 * s + 8) = f32x4{r[4], r[5], r[6], r[7]};
+            }
         }
+}
+
+// the epilogue policy of a layer: the plain activation, or (SAVE: training) the activation + its plane of the saved activations + its sign
+// words.  col: the layer's column of the act:: table; boff: its word offset in the part's sign planes (< 0: no mask behind this layer)
+template <bool SAVE>
+__device__ __forceinline__ auto layer_policy(float slope, float *actbuf, uint32_t *bits, long P, uint32_t pl, int h, int col, int width, int boff)
+{
+    if constexpr (SAVE) {
+        SaveAct e;
+        const int nw = width >= 256 ? 2 : 1;
+        e.slope = slope;
+        e.slot = actbuf + ((long)col * P + (long)pl * width + 4 * h);
+        e.sign = boff >= 0 ? reinterpret_cast<unsigned char *>(bits + (long)boff * P + ((long)pl * 4 + h) * nw) : nullptr;
+        e.sign2 = 2u * nw * 4u;
+        return e;
+    } else {
+        return FwdAct{slope};
+    }
 }
 
 #define CHX(id) (pick_GX(kProgH.layer[id].KB32, kProgH.layer[id].NT32) * kProgH.layer[id].KB32 * 2048)   /* halfwords in one chunk of layer id */
 
 #if SAHS_MODEL == 0      // ---- the radiance kernel (AudioFaceModel) ----
 // trilinear lookup (fp32, ATen corner order, zeros padding); this lane takes channels 16s + 8g + 4h + 0..3
-__device__ __forceinline__ void grid_block_x(const float *__restrict__ grid, float x, float y, float z, int h, Blk &out)
+__device__ __forceinline__ void grid_block_x(const float *__restrict__ grid, float x, float y, float z, int h, Blk &out, float *save = nullptr)
 {
     const float R1 = (float)(G_RES - 1);
     const float ix = ((x + 1.0f) / 2.0f) * R1, iy = ((y + 1.0f) / 2.0f) * R1, iz = ((z + 1.0f) / 2.0f) * R1;
@@ -124,14 +148,21 @@ __device__ __forceinline__ void grid_block_x(const float *__restrict__ grid, flo
             split_pair(a[2 * s + (j >> 2)][j & 3], a[2 * s + (j >> 2)][(j & 3) + 1], hi, lo);
             out.s[s][jp] = hi; out.l[s][jp] = lo;
         }
+    if (save != nullptr) {      // channels 8 k + 4 h .. + 3 of the sample's row of the GRID plane
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4 *>(save + 8 * k) = a[k];
+    }
 }
 
 
 // The radiance nets of `level` on S samples per ray whose (x', w) are xw[ray][src ? src[ray][s] : s] (field_f32.hip, FIELD_RADIANCE).
+// SAVE (training with the forward on this pipe): also the saved activations of the radiance part (actbuf: column c of the act:: table at
+// actbuf + c * P) and its sign-bit planes (bits), exactly the buffers field_forward_f32_kernel<true, 2> writes for the backward.
+template <bool SAVE>
 __global__ void __launch_bounds__(X_THREADS, 1)
 field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__restrict__ frame, int level, long P, int S,
                              const float *__restrict__ rays, int ray_stride, float *__restrict__ raw, const float *__restrict__ xw, int xw_row,
-                             const int *__restrict__ src)
+                             const int *__restrict__ src, float *__restrict__ actbuf, uint32_t *__restrict__ bits)
 {
     constexpr uint32_t RAD_OFF = (uint32_t)(2 * kProgH.layer[H_T0].stream_off);
     extern __shared__ __attribute__((aligned(16))) char lds_x[];
@@ -161,10 +192,17 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
     const long ntiles = (P + X_PTS_PER_WG - 1) / X_PTS_PER_WG;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         cx.refresh_bias_base();
+        // (SAVE: the backend moves the stream-offset chain to the VALU and then cannot feed the "s" constraint below -- "illegal VGPR to SGPR copy")
+        if constexpr (SAVE) cx.off = (uint32_t)__builtin_amdgcn_readfirstlane((int)cx.off);
         asm volatile("" : "+s"(cx.off));      // (chunk addresses are loop-invariant: keep them from being hoisted and spilled)
         St st;
         const long p_raw = tile * X_PTS_PER_WG + cx.wave * X_PTS_PER_WAVE + col;
-        const long p = p_raw < P ? p_raw : P - 1;
+        const long p = p_raw < P ? p_raw : P - 1;      // (SAVE: lanes past the end redo the last sample -- identical values to identical addresses)
+        long Pq = P;
+        if constexpr (SAVE) asm volatile("" : "+s"(Pq));      // (the ~25 plane bases c * P: keep them from being hoisted out of the tile loop and spilled)
+        const uint32_t pl = (uint32_t)p;
+#define pol(slope, c, width, boff) layer_policy<SAVE>(slope, actbuf, bits, Pq, pl, h, c, width, boff)
+#define plane(c, width) (SAVE ? actbuf + (long)(c) * Pq + p * (width) + 4 * h : nullptr)
         typedef __attribute__((address_space(3))) float *lds_float;
         const lds_float stash = (lds_float)(__attribute__((address_space(3))) char *)(lds_x + LDS_STASH_BYTE_OFF) + (cx.wave * X_PTS_PER_WAVE + col) * STASH_FLOATS;
         if (h == 0) {
@@ -172,58 +210,74 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
             const f32x4 v = *reinterpret_cast<const f32x4 *>(row);
             stash[0] = v[0]; stash[1] = v[1]; stash[2] = v[2]; stash[3] = v[3];
             stash[4] = row[4];
+            if constexpr (SAVE) { float *d = actbuf + (long)act::XW * Pq + p * 16; d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; }      // the grid backward reads x'
         }
         __builtin_amdgcn_wave_barrier();
         Blk A[8];
         f32x16 fin;
         {
             Blk B[8];
+            const auto e0 = pol(0.01f, act::T, 256, sbits::BR_T);
             {
                 Blk in_tr[3];
                 const float xp[3] = {stash[0], stash[1], stash[2]}, amb[3] = {stash[3], stash[4], 0.0f};
-                pe_blocks_x<3, 10, 2>(xp, h, in_tr);
-                pe_blocks_x<2, 4, 1>(amb, h, in_tr + 2);
-                dense_x<2, 1, 0, 8, CHX(H_T1), false>(cx, st, in_tr, in_tr + 2, nullptr, A, Ly[H_T0].bias_off, FwdAct{0.01f}, FwdAct{1.0f});
+                pe_blocks_x<3, 10, 2>(xp, h, in_tr, plane(act::PEX, 64));
+                pe_blocks_x<2, 4, 1>(amb, h, in_tr + 2, plane(act::PEW, 32));
+                dense_x<2, 1, 0, 8, CHX(H_T1), false>(cx, st, in_tr, in_tr + 2, nullptr, A, Ly[H_T0].bias_off, e0, FwdAct{1.0f});
             }
-            dense_x<8, 0, 0, 8, CHX(H_T2), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T1].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
-            dense_x<8, 0, 0, 8, CHX(H_T3), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T2].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
+            const auto e1 = pol(0.01f, act::T + 256, 256, sbits::BR_T + 8);
+            dense_x<8, 0, 0, 8, CHX(H_T2), true, 7>(cx, st, A, nullptr, nullptr, B, Ly[H_T1].bias_off, e1, e0);
+            const auto e2 = pol(0.01f, act::T + 512, 256, sbits::BR_T + 16);
+            dense_x<8, 0, 0, 8, CHX(H_T3), true, 7>(cx, st, B, nullptr, nullptr, A, Ly[H_T2].bias_off, e2, e1);
             {   // the re-injected encoding [PE(x') | PE(w)] is rebuilt at the skip layer instead of staying live
                 Blk in_tr[3];
                 const float xp[3] = {stash[0], stash[1], stash[2]}, amb[3] = {stash[3], stash[4], 0.0f};
                 pe_blocks_x<3, 10, 2>(xp, h, in_tr);
                 pe_blocks_x<2, 4, 1>(amb, h, in_tr + 2);
-                dense_x<8, 2, 1, 8, CHX(H_T4), true>(cx, st, A, in_tr, in_tr + 2, B, Ly[H_T3].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
+                dense_x<8, 2, 1, 8, CHX(H_T4), true, 7>(cx, st, A, in_tr, in_tr + 2, B, Ly[H_T3].bias_off, pol(0.01f, act::T + 768, 256, sbits::BR_T + 24), e2);
             }
 #pragma unroll 1
             for (int j = 0; j < 2; ++j) {     // T4, T5 | T6, T7 (identical shapes: one copy of the code, run twice)
-                dense_x<8, 0, 0, 8, CHX(H_T5), true>(cx, st, B, nullptr, nullptr, A, Ly[H_T4].bias_off + 512 * j, FwdAct{0.01f}, FwdAct{0.01f});
-                dense_x<8, 0, 0, 8, CHX(H_T5), true>(cx, st, A, nullptr, nullptr, B, Ly[H_T4].bias_off + 512 * j + 256, FwdAct{0.01f}, FwdAct{0.01f});
+                const auto ea = pol(0.01f, act::T + 256 * (4 + 2 * j), 256, sbits::BR_T + 8 * (4 + 2 * j));
+                dense_x<8, 0, 0, 8, CHX(H_T5), true, 7>(cx, st, B, nullptr, nullptr, A, Ly[H_T4].bias_off + 512 * j, ea,
+                                                       pol(0.01f, act::T + 256 * (3 + 2 * j), 256, sbits::BR_T + 8 * (3 + 2 * j)));
+                dense_x<8, 0, 0, 8, CHX(H_T5), true, 7>(cx, st, A, nullptr, nullptr, B, Ly[H_T4].bias_off + 512 * j + 256,
+                                                       pol(0.01f, act::T + 256 * (5 + 2 * j), 256, sbits::BR_T + 8 * (5 + 2 * j)), ea);
             }
-            dense_x<8, 0, 0, 8, CHX(H_ALPHA), true>(cx, st, B, nullptr, nullptr, A, Ly[H_FEAT].bias_off, FwdAct{1.0f}, FwdAct{0.01f});
+            dense_x<8, 0, 0, 8, CHX(H_ALPHA), true, 7>(cx, st, B, nullptr, nullptr, A, Ly[H_FEAT].bias_off, pol(1.0f, act::FEAT, 256, -1),
+                                                      pol(0.01f, act::T + 256 * 7, 256, sbits::BR_T + 8 * 7));
         }
-        dense_x_out<8, CHX(H_D0)>(cx, st, A, fin, Ly[H_ALPHA].bias_off, true, FwdAct{1.0f});
+        dense_x_out<8, CHX(H_D0), 7>(cx, st, A, fin, Ly[H_ALPHA].bias_off, true, pol(1.0f, act::FEAT, 256, -1));
         {   // colour branch
             Blk in_d[2];
             {
                 const float *rq = rays + (p / S) * ray_stride;
                 const float rdir[3] = {rq[3], rq[4], rq[5]};
-                pe_blocks_x<3, 4, 1>(rdir, h, in_d);
-                grid_block_x(grid, stash[0], stash[1], stash[2], h, in_d[1]);
+                pe_blocks_x<3, 4, 1>(rdir, h, in_d, plane(act::DIR, 32));
+                grid_block_x(grid, stash[0], stash[1], stash[2], h, in_d[1], plane(act::GRID, 32));
             }
             Blk c[4], cn[4];
-            dense_x<8, 1, 1, 4, CHX(H_D1), false>(cx, st, A, in_d, in_d + 1, c, Ly[H_D0].bias_off, FwdAct{0.01f}, FwdAct{1.0f});
-            dense_x<4, 0, 0, 4, CHX(H_D1), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D1].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
-            dense_x<4, 0, 0, 4, CHX(H_D1), true>(cx, st, cn, nullptr, nullptr, c, Ly[H_D1].bias_off + 128, FwdAct{0.01f}, FwdAct{0.01f});
-            dense_x<4, 0, 0, 4, CHX(H_RGB), true>(cx, st, c, nullptr, nullptr, cn, Ly[H_D3].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
-            dense_x_out<4, CHX(H_S0)>(cx, st, cn, fin, 0, false, FwdAct{0.01f});
+            const auto d0 = pol(0.01f, act::C, 128, sbits::BR_C);
+            dense_x<8, 1, 1, 4, CHX(H_D1), false>(cx, st, A, in_d, in_d + 1, c, Ly[H_D0].bias_off, d0, FwdAct{1.0f});
+            const auto d1 = pol(0.01f, act::C + 128, 128, sbits::BR_C + 4);
+            dense_x<4, 0, 0, 4, CHX(H_D1), true, 3>(cx, st, c, nullptr, nullptr, cn, Ly[H_D1].bias_off, d1, d0);
+            const auto d2 = pol(0.01f, act::C + 256, 128, sbits::BR_C + 8);
+            dense_x<4, 0, 0, 4, CHX(H_D1), true, 3>(cx, st, cn, nullptr, nullptr, c, Ly[H_D1].bias_off + 128, d2, d1);
+            const auto d3 = pol(0.01f, act::C + 384, 128, sbits::BR_C + 12);
+            dense_x<4, 0, 0, 4, CHX(H_RGB), true, 3>(cx, st, c, nullptr, nullptr, cn, Ly[H_D3].bias_off, d3, d2);
+            dense_x_out<4, CHX(H_S0), 3>(cx, st, cn, fin, 0, false, d3);
         }
         {   // seg branch
             Blk s[4], sn[4];
-            dense_x<8, 0, 0, 4, CHX(H_S1), false>(cx, st, A, nullptr, nullptr, s, Ly[H_S0].bias_off, FwdAct{0.01f}, FwdAct{1.0f});
-            dense_x<4, 0, 0, 4, CHX(H_S1), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S1].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
-            dense_x<4, 0, 0, 4, CHX(H_S1), true>(cx, st, sn, nullptr, nullptr, s, Ly[H_S1].bias_off + 128, FwdAct{0.01f}, FwdAct{0.01f});
-            dense_x<4, 0, 0, 4, CHX(H_SEG), true>(cx, st, s, nullptr, nullptr, sn, Ly[H_S3].bias_off, FwdAct{0.01f}, FwdAct{0.01f});
-            dense_x_out<4, CHX(H_T0)>(cx, st, sn, fin, 0, false, FwdAct{0.01f});
+            const auto s0 = pol(0.01f, act::S, 128, sbits::BR_S);
+            dense_x<8, 0, 0, 4, CHX(H_S1), false>(cx, st, A, nullptr, nullptr, s, Ly[H_S0].bias_off, s0, FwdAct{1.0f});
+            const auto s1 = pol(0.01f, act::S + 128, 128, sbits::BR_S + 4);
+            dense_x<4, 0, 0, 4, CHX(H_S1), true, 3>(cx, st, s, nullptr, nullptr, sn, Ly[H_S1].bias_off, s1, s0);
+            const auto s2 = pol(0.01f, act::S + 256, 128, sbits::BR_S + 8);
+            dense_x<4, 0, 0, 4, CHX(H_S1), true, 3>(cx, st, sn, nullptr, nullptr, s, Ly[H_S1].bias_off + 128, s2, s1);
+            const auto s3 = pol(0.01f, act::S + 384, 128, sbits::BR_S + 12);
+            dense_x<4, 0, 0, 4, CHX(H_SEG), true, 3>(cx, st, s, nullptr, nullptr, sn, Ly[H_S3].bias_off, s3, s2);
+            dense_x_out<4, CHX(H_T0), 3>(cx, st, sn, fin, 0, false, s3);
         }
         if (p_raw < P) {   // rows 4h..4h+3 and 8+4h..8+4h+3 of [rgb3 | seg12 | sigma]
             *reinterpret_cast<f32x4 *>(raw + p_raw * D_RAW + 4 * h) = f32x4{fin[0], fin[1], fin[2], fin[3]};
@@ -232,6 +286,8 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
     }
 }
 
+#undef pol
+#undef plane
 #endif      // SAHS_MODEL == 0
 
 // The deformation nets (warp field + hyper sheet, level-independent inputs) on the depths zvals: x' = x + tanh(warp(PE(x))), w = hyper(PE(x))
@@ -241,10 +297,13 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
 // from 1.7e-5 to 2.8e-5 of the fp32 frame at worst -- inside four times the fp32 tolerance for every ray, the criterion of
 // tests/test_gpu_bf16.py -- because x' = x + tanh(.) adds a SMALL correction to an exact x: the 6e-6 relative error of the nets lands on
 // |dx| << 1, not on x' itself, before sin(2^9 x') amplifies it.
+// SAVE (training with the forward on this pipe, AudioFaceModel): also the saved activations and sign-bit planes of the deformation part, the
+// buffers field_forward_f32_kernel<true, 1> writes for the backward.
+template <bool SAVE>
 __global__ void __launch_bounds__(X_THREADS, 1)
 field_deform_bf16x3_kernel(const float *__restrict__ packed, const float *__restrict__ frame, int level, long P, int S,
                            const float *__restrict__ rays, int ray_stride, const float *__restrict__ zvals, float *__restrict__ xw, int xw_row,
-                           int xw_col0)
+                           int xw_col0, float *__restrict__ actbuf, uint32_t *__restrict__ bits)
 {
     constexpr uint32_t RAD_OFF = (uint32_t)(2 * kProgH.layer[H_T0].stream_off);
     extern __shared__ __attribute__((aligned(16))) char lds_x[];
@@ -273,11 +332,17 @@ field_deform_bf16x3_kernel(const float *__restrict__ packed, const float *__rest
     const long ntiles = (P + X_PTS_PER_WG - 1) / X_PTS_PER_WG;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         cx.refresh_bias_base();
+        // (SAVE: the backend moves the stream-offset chain to the VALU and then cannot feed the "s" constraint below -- "illegal VGPR to SGPR copy")
+        if constexpr (SAVE) cx.off = (uint32_t)__builtin_amdgcn_readfirstlane((int)cx.off);
         asm volatile("" : "+s"(cx.off));      // (chunk addresses are loop-invariant: keep them from being hoisted and spilled)
         St st;
         const long p_raw = tile * X_PTS_PER_WG + cx.wave * X_PTS_PER_WAVE + col;
         const long p = p_raw < P ? p_raw : P - 1;
-        float x[3], xp[3], amb[2];
+        long Pq = P;
+        if constexpr (SAVE) asm volatile("" : "+s"(Pq));      // (plane bases c * P: not hoisted out of the tile loop)
+        const uint32_t pl = (uint32_t)p;
+#define pold(c, width, boff) layer_policy<SAVE>(0.0f, actbuf, bits, Pq, pl, h, c, width, boff)
+        float x[3], xp[3], amb[2], dx[3];
         {
             const float *rp = rays + (p / S) * ray_stride;
             const float z = zvals[p];
@@ -286,31 +351,44 @@ field_deform_bf16x3_kernel(const float *__restrict__ packed, const float *__rest
         }
         constexpr int KX32 = (KB_XYZ + 1) / 2;        // 32-feature blocks of PE(x): 2 (10 octaves) | 3 (15 octaves, NeRFaceModel)
         Blk pe_x[KX32];
-        pe_blocks_x<3, L_XYZ, KX32>(x, h, pe_x);
+        pe_blocks_x<3, L_XYZ, KX32>(x, h, pe_x, SAVE ? actbuf + (long)act::E * Pq + p * (16 * KB_XYZ) + 4 * h : nullptr);
         {   // warp field (models.py:296-305; layers alternate between two register sets)
             Blk A[4], B[4];
-            dense_x<KX32, 0, 0, 4, CHX(H_W1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_W0].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
-            dense_x<4, 0, 0, 4, CHX(H_W1), true>(cx, st, A, nullptr, nullptr, B, Ly[H_W1].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
-            dense_x<4, 0, 0, 4, CHX(H_W1), true>(cx, st, B, nullptr, nullptr, A, Ly[H_W1].bias_off + 128, FwdAct{0.0f}, FwdAct{0.0f});
-            dense_x<4, 0, 0, 4, CHX(H_W4), true>(cx, st, A, nullptr, nullptr, B, Ly[H_W3].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
-            dense_x<4, KX32, 0, 4, CHX(H_W5), true>(cx, st, B, pe_x, nullptr, A, Ly[H_W4].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
-            dense_x<4, 0, 0, 4, CHX(H_WF), true>(cx, st, A, nullptr, nullptr, B, Ly[H_W5].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
+            const auto w0 = pold(act::WH, 128, sbits::BD_WH);
+            dense_x<KX32, 0, 0, 4, CHX(H_W1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_W0].bias_off, w0, FwdAct{0.0f});
+            const auto w1 = pold(act::WH + 128, 128, sbits::BD_WH + 4);
+            dense_x<4, 0, 0, 4, CHX(H_W1), true, 3>(cx, st, A, nullptr, nullptr, B, Ly[H_W1].bias_off, w1, w0);
+            const auto w2 = pold(act::WH + 256, 128, sbits::BD_WH + 8);
+            dense_x<4, 0, 0, 4, CHX(H_W1), true, 3>(cx, st, B, nullptr, nullptr, A, Ly[H_W1].bias_off + 128, w2, w1);
+            const auto w3 = pold(act::WH + 384, 128, sbits::BD_WH + 12);
+            dense_x<4, 0, 0, 4, CHX(H_W4), true, 3>(cx, st, A, nullptr, nullptr, B, Ly[H_W3].bias_off, w3, w2);
+            const auto w4 = pold(act::WH + 512, 128, sbits::BD_WH + 16);
+            dense_x<4, KX32, 0, 4, CHX(H_W5), true, 3>(cx, st, B, pe_x, nullptr, A, Ly[H_W4].bias_off, w4, w3);
+            const auto w5 = pold(act::WH + 640, 128, sbits::BD_WH + 20);
+            dense_x<4, 0, 0, 4, CHX(H_WF), true, 3>(cx, st, A, nullptr, nullptr, B, Ly[H_W5].bias_off, w5, w4);
             f32x16 o;
-            dense_x_out<4, CHX(H_H0)>(cx, st, B, o, Ly[H_WF].bias_off, true, FwdAct{0.0f});
-            xp[0] = x[0] + tanhf(o[0]);            // models.py:305 (rows 0..2 live in lane half 0)
-            xp[1] = x[1] + tanhf(o[1]);
-            xp[2] = x[2] + tanhf(o[2]);
+            dense_x_out<4, CHX(H_H0), 3>(cx, st, B, o, Ly[H_WF].bias_off, true, w5);
+            dx[0] = tanhf(o[0]); dx[1] = tanhf(o[1]); dx[2] = tanhf(o[2]);
+            xp[0] = x[0] + dx[0];            // models.py:305 (rows 0..2 live in lane half 0)
+            xp[1] = x[1] + dx[1];
+            xp[2] = x[2] + dx[2];
         }
         {   // hyper sheet (models.py:307-314)
             Blk A[2], B[2];
-            dense_x<KX32, 0, 0, 2, CHX(H_H1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_H0].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
-            dense_x<2, 0, 0, 2, CHX(H_H1), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H1].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
-            dense_x<2, 0, 0, 2, CHX(H_H1), true>(cx, st, B, nullptr, nullptr, A, Ly[H_H1].bias_off + 64, FwdAct{0.0f}, FwdAct{0.0f});
-            dense_x<2, 0, 0, 2, CHX(H_H4), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H3].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
-            dense_x<2, KX32, 0, 2, CHX(H_H5), true>(cx, st, B, pe_x, nullptr, A, Ly[H_H4].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
-            dense_x<2, 0, 0, 2, CHX(H_HF), true>(cx, st, A, nullptr, nullptr, B, Ly[H_H5].bias_off, FwdAct{0.0f}, FwdAct{0.0f});
+            const auto g0 = pold(act::HH, 64, sbits::BD_HH);
+            dense_x<KX32, 0, 0, 2, CHX(H_H1), false>(cx, st, pe_x, nullptr, nullptr, A, Ly[H_H0].bias_off, g0, FwdAct{0.0f});
+            const auto g1 = pold(act::HH + 64, 64, sbits::BD_HH + 4);
+            dense_x<2, 0, 0, 2, CHX(H_H1), true, 1>(cx, st, A, nullptr, nullptr, B, Ly[H_H1].bias_off, g1, g0);
+            const auto g2 = pold(act::HH + 128, 64, sbits::BD_HH + 8);
+            dense_x<2, 0, 0, 2, CHX(H_H1), true, 1>(cx, st, B, nullptr, nullptr, A, Ly[H_H1].bias_off + 64, g2, g1);
+            const auto g3 = pold(act::HH + 192, 64, sbits::BD_HH + 12);
+            dense_x<2, 0, 0, 2, CHX(H_H4), true, 1>(cx, st, A, nullptr, nullptr, B, Ly[H_H3].bias_off, g3, g2);
+            const auto g4 = pold(act::HH + 256, 64, sbits::BD_HH + 16);
+            dense_x<2, KX32, 0, 2, CHX(H_H5), true, 1>(cx, st, B, pe_x, nullptr, A, Ly[H_H4].bias_off, g4, g3);
+            const auto g5 = pold(act::HH + 320, 64, sbits::BD_HH + 20);
+            dense_x<2, 0, 0, 2, CHX(H_HF), true, 1>(cx, st, A, nullptr, nullptr, B, Ly[H_H5].bias_off, g5, g4);
             f32x16 o;
-            dense_x_out<2, CHX(H_W0)>(cx, st, B, o, Ly[H_HF].bias_off, true, FwdAct{0.0f});
+            dense_x_out<2, CHX(H_W0), 1>(cx, st, B, o, Ly[H_HF].bias_off, true, g5);
             amb[0] = o[0];
             amb[1] = AMB_DIM > 1 ? o[1] : 0.0f;      // (NeRFaceModel: one ambient coordinate)
         }
@@ -318,10 +396,17 @@ field_deform_bf16x3_kernel(const float *__restrict__ packed, const float *__rest
             float *row = xw + ((p / S) * (long)xw_row + xw_col0 + (p % S)) * 8;
             *reinterpret_cast<f32x4 *>(row) = f32x4{xp[0], xp[1], xp[2], amb[0]};
             *reinterpret_cast<f32x4 *>(row + 4) = f32x4{amb[1], 0.0f, 0.0f, 0.0f};
+            if constexpr (SAVE) {      // what the backward reads of the heads: dx = tanh(.), x', w (field_f32.hip writes the same three slots)
+                float *d = actbuf + (long)act::DX * Pq + p * 16, *q = actbuf + (long)act::XW * Pq + p * 16, *w = actbuf + (long)act::AW * Pq + p * 16;
+                d[0] = dx[0]; d[1] = dx[1]; d[2] = dx[2];
+                q[0] = xp[0]; q[1] = xp[1]; q[2] = xp[2];
+                w[0] = amb[0]; w[1] = amb[1];
+            }
         }
     }
 }
 
+#undef pold
 }  // namespace hx3
 }  // namespace SAHS_NS
 
@@ -329,37 +414,67 @@ using namespace SAHS_NS;
 using namespace SAHS_NS::hx3;
 
 #if SAHS_MODEL == 0
+template <bool SAVE>
+static int launch_radiance_x3(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride, float *raw,
+                              const float *xw, int xw_row, const int *src, float *actbuf, uint32_t *bits, int num_cu, hipStream_t stream)
+{
+    if (P <= 0) return 0;
+    if (SAVE && P * (long)(4 * 256) >= (1L << 32)) return -4;      // (SaveAct: 32-bit byte offsets inside a layer's plane)
+    const long ntiles = (P + X_PTS_PER_WG - 1) / X_PTS_PER_WG;
+    const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
+    static sahs_once::Flags attr_set;
+    hipError_t ae = sahs_once::per_device(attr_set, [&]() {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_radiance_bf16x3_kernel<SAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    });
+    if (ae != hipSuccess) return (int)ae;
+    field_radiance_bf16x3_kernel<SAVE><<<grid, X_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, raw, xw, xw_row, src, actbuf, bits);
+    return (int)hipGetLastError();
+}
 // the radiance launch of the split evaluation (field_f32.hip: sahs_field_forward_f32_split_launch mode 2, same arguments)
 extern "C" int sahs_field_radiance_bf16x3_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays,
                                                  int ray_stride, float *raw, const float *xw, int xw_row, const int *src, int num_cu,
                                                  hipStream_t stream)
 {
+    return launch_radiance_x3<false>(packed, frame, level, P, S, rays, ray_stride, raw, xw, xw_row, src, nullptr, nullptr, num_cu, stream);
+}
+// ... that also saves what the backward reads (field_f32.hip: sahs_field_forward_f32_split_bits_launch mode 2 with actbuf and bits, same buffers)
+extern "C" int sahs_field_radiance_bf16x3_save_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays,
+                                                      int ray_stride, float *raw, const float *xw, int xw_row, const int *src, float *actbuf,
+                                                      uint32_t *bits, int num_cu, hipStream_t stream)
+{
+    if (actbuf == nullptr || bits == nullptr) return -2;
+    return launch_radiance_x3<true>(packed, frame, level, P, S, rays, ray_stride, raw, xw, xw_row, src, actbuf, bits, num_cu, stream);
+}
+#endif
+
+template <bool SAVE>
+static int launch_deform_x3(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride, const float *zvals,
+                            float *xw, int xw_row, int xw_col0, float *actbuf, uint32_t *bits, int num_cu, hipStream_t stream)
+{
     if (P <= 0) return 0;
+    if (SAVE && P * (long)(4 * 128) >= (1L << 32)) return -4;
     const long ntiles = (P + X_PTS_PER_WG - 1) / X_PTS_PER_WG;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     static sahs_once::Flags attr_set;
     hipError_t ae = sahs_once::per_device(attr_set, [&]() {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_radiance_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_deform_bf16x3_kernel<SAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     });
     if (ae != hipSuccess) return (int)ae;
-    field_radiance_bf16x3_kernel<<<grid, X_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, raw, xw, xw_row, src);
+    field_deform_bf16x3_kernel<SAVE><<<grid, X_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, xw, xw_row, xw_col0, actbuf, bits);
     return (int)hipGetLastError();
 }
-
-#endif
-
 // the deformation launch of the split evaluation (field_f32.hip: sahs_field_forward_f32_split_launch mode 1, same arguments)
 extern "C" int SAHS_SYM(sahs_field_deform_bf16x3_launch)(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
                                                const float *zvals, float *xw, int xw_row, int xw_col0, int num_cu, hipStream_t stream)
 {
-    if (P <= 0) return 0;
-    const long ntiles = (P + X_PTS_PER_WG - 1) / X_PTS_PER_WG;
-    const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
-    static sahs_once::Flags attr_set;
-    hipError_t ae = sahs_once::per_device(attr_set, [&]() {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_deform_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    });
-    if (ae != hipSuccess) return (int)ae;
-    field_deform_bf16x3_kernel<<<grid, X_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, xw, xw_row, xw_col0);
-    return (int)hipGetLastError();
+    return launch_deform_x3<false>(packed, frame, level, P, S, rays, ray_stride, zvals, xw, xw_row, xw_col0, nullptr, nullptr, num_cu, stream);
 }
+#if SAHS_MODEL == 0
+extern "C" int sahs_field_deform_bf16x3_save_launch(const float *packed, const float *frame, int level, long P, int S, const float *rays, int ray_stride,
+                                                    const float *zvals, float *xw, int xw_row, int xw_col0, float *actbuf, uint32_t *bits, int num_cu,
+                                                    hipStream_t stream)
+{
+    if (actbuf == nullptr || bits == nullptr) return -2;
+    return launch_deform_x3<true>(packed, frame, level, P, S, rays, ray_stride, zvals, xw, xw_row, xw_col0, actbuf, bits, num_cu, stream);
+}
+#endif

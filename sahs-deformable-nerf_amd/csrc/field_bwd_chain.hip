@@ -227,7 +227,7 @@ struct BwdEp {
             return __builtin_bit_cast(float, (t & __builtin_bit_cast(uint32_t, v)) | (~t & __builtin_bit_cast(uint32_t, m)));      // v_bfi_b32
         }
     }
-    template <int TILE, int G> __device__ __forceinline__ void done4(const float (&r)[4]) const
+    template <int TILE, int G> __device__ __forceinline__ void done4(const float (&r)[4], uint32_t (&)[2]) const
     {
 #if defined(SAHS_DIAG) && defined(SAHS_BWC_NOSTORE)      // timing-only: results wrong by construction
         asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
@@ -264,7 +264,7 @@ struct NoEp {      // (the pending-tile policy of a layer that has none)
     static constexpr bool stores(int) { return false; }
     float slope;
     template <int TILE, int U> __device__ __forceinline__ float value(float v, float) const { return v; }
-    template <int TILE, int G> __device__ __forceinline__ void done4(const float (&)[4]) const {}
+    template <int TILE, int G> __device__ __forceinline__ void done4(const float (&)[4], uint32_t (&)[2]) const {}
 };
 
 // the last tile of a chain's last layer: nothing follows that would convert it under its MFMAs

@@ -131,11 +131,11 @@ class _FieldModel(nn.Module):
         precision = self.precision if precision is None else precision
         params = list(self.parameters())
         key = (precision, params[0].device, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
-        hit = self._cache.get("packed")
+        hit = self._cache.get(("packed", precision))      # (one entry per precision: a training step on the split-operand forward holds two)
         if hit is None or hit[0] != key:
             flat = self.flat_params()
             hit = (key, ops.pack_weights(flat, precision, arch=self.arch), flat)
-            self._cache["packed"] = hit
+            self._cache["packed", precision] = hit
         return hit[1], hit[2]
 
     def frame(self, driving, pose):

@@ -393,10 +393,15 @@ def alloc_sign_bits(num_samples, mode, arch, device):
     return torch.empty(int(num_samples), words, dtype=torch.int32, device=device) if words > 0 else None
 
 
-def field_forward_split_save(packed, frame, level, mode, rays, xw, z=None, src=None, xw_col0=0, arch="audio", bits=None):
+def field_forward_split_save(packed, frame, level, mode, rays, xw, z=None, src=None, xw_col0=0, arch="audio", bits=None, precision=SAHS_F32, whole=None):
     """field_forward_split (fp32) that also keeps the activations of the layers it runs -> (raw or None, act).  act is the part's
     own buffer, (P, act_words_part(mode)) floats as dense per-layer planes; only field_backward_split of the same part reads it.
-    bits (from alloc_sign_bits, same mode): also filled -- hand it to field_backward_split with act."""
+    bits (from alloc_sign_bits, same mode): also filled -- hand it to field_backward_split with act.
+    precision SAHS_BF16X3 (AudioFaceModel, modes FIELD_DEFORM / FIELD_RADIANCE, bits required): the same buffers written by the
+    split-operand kernels; `packed` is then pack_weights(flat, SAHS_BF16X3).
+    whole=(act, bits) of a WHOLE-network save (FIELD_ALL shapes): the launch fills `mode`'s part of them instead of buffers of its own
+    (a saved array of column c starts at c * P in every save), so a FIELD_DEFORM + FIELD_RADIANCE pair leaves what one FIELD_ALL launch
+    leaves -> (raw or None, whole act)."""
     packed, frame, rays, z = _req(packed, "packed"), _req(frame, "frame"), _req(rays, "rays"), _req(z, "z")
     src, xw = _req(src, "src", torch.int32), _req(xw, "xw")
     N = rays.shape[0]
@@ -404,15 +409,31 @@ def field_forward_split_save(packed, frame, level, mode, rays, xw, z=None, src=N
     if xw.dim() != 3 or xw.shape[0] != N or xw.shape[2] != 8:
         raise _lib.SahsError("xw must be (N, row, 8)")
     raw = None if mode == FIELD_DEFORM else torch.empty(N, S, 16, dtype=torch.float32, device=rays.device)
-    act = torch.empty(N * S, _fn("act_words_part", arch)[0](int(mode)), dtype=torch.float32, device=rays.device)
+    words, bwords = _fn("act_words_part", arch)[0], _fn("bits_words_part", arch)[0]
+    if whole is not None:
+        act, bits = _req(whole[0], "whole act"), _req(whole[1], "whole bits", torch.int32)
+        if int(mode) not in (FIELD_DEFORM, FIELD_RADIANCE) or tuple(act.shape) != (N * S, int(words(FIELD_ALL))) or tuple(bits.shape) != (N * S, int(bwords(FIELD_ALL))):
+            raise _lib.SahsError("field_forward_split_save(whole): buffers of a FIELD_ALL save of the same samples, filled by a FIELD_DEFORM or FIELD_RADIANCE launch")
+        radiance = int(mode) == FIELD_RADIANCE      # the radiance arrays / planes are the tail of the whole-network tables
+        act_ptr = ctypes.c_void_p(act.data_ptr() + (4 * (int(words(FIELD_ALL)) - int(words(FIELD_RADIANCE))) * N * S if radiance else 0))
+        bits_ptr = ctypes.c_void_p(bits.data_ptr() + (4 * int(bwords(FIELD_DEFORM)) * N * S if radiance else 0))
+        f, name = _fn("field_forward_split_save_bits_x3" if int(precision) == SAHS_BF16X3 else "field_forward_split_save_bits", arch)
+        check(f(_p(packed), _p(frame), int(level), int(mode), N, int(S), _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(xw), int(xw.shape[1]), int(xw_col0),
+                _p(src), act_ptr, bits_ptr, _stream()), name)
+        return raw, act
+    act = torch.empty(N * S, words(int(mode)), dtype=torch.float32, device=rays.device)
     if bits is not None:
         bits = _req(bits, "bits", torch.int32)
-        if tuple(bits.shape) != (N * S, int(_fn("bits_words_part", arch)[0](int(mode)))):
+        if tuple(bits.shape) != (N * S, int(bwords(int(mode)))):
             raise _lib.SahsError("field_forward_split_save: bits must come from alloc_sign_bits(N * S, mode, arch, device)")
-        f, name = _fn("field_forward_split_save_bits", arch)
+        if int(precision) == SAHS_BF16X3 and arch != "audio":
+            raise _lib.SahsError("field_forward_split_save: the split-operand saving forward is built for the AudioFaceModel only")
+        f, name = _fn("field_forward_split_save_bits_x3" if int(precision) == SAHS_BF16X3 else "field_forward_split_save_bits", arch)
         check(f(_p(packed), _p(frame), int(level), int(mode), N, int(S), _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(xw), int(xw.shape[1]), int(xw_col0),
                 _p(src), _p(act), _p(bits), _stream()), name)
         return raw, act
+    if int(precision) != SAHS_F32:
+        raise _lib.SahsError("field_forward_split_save: a saving forward at a precision other than fp32 needs the sign bits (bits=alloc_sign_bits(...))")
     f, name = _fn("field_forward_split_save", arch)
     check(f(_p(packed), _p(frame), int(level), int(mode), N, int(S), _p(rays), int(rays.shape[1]), _p(z), _p(raw), _p(xw), int(xw.shape[1]), int(xw_col0),
             _p(src), _p(act), _stream()), name)
@@ -430,6 +451,34 @@ def fused_backward(enable=None):
 
 
 _FUSED_BACKWARD = os.environ.get("SAHS_BWD_FUSED", "1") != "0"
+
+
+def training_forward_precision(precision=None):
+    """Arithmetic of the SAVING forward launches of a training step (RenderRaysFn's kept path, AudioFaceModel): "fp32" (default: fp32 MFMAs,
+    the form the parity tests pin) or "bf16x3" (the split-operand kernels of the SAHS_BF16X3 frame, which then also write the saved
+    activations and sign bits; values within a few 1e-6 relative of the fp32 kernel's).  SAHS_TRAIN_FORWARD in the environment selects the
+    initial value.  None queries."""
+    global _TRAIN_FORWARD
+    if precision is not None:
+        if precision not in ("fp32", "bf16x3"):
+            raise _lib.SahsError("training_forward_precision: 'fp32' or 'bf16x3'")
+        _TRAIN_FORWARD = precision
+    return _TRAIN_FORWARD
+
+
+_TRAIN_FORWARD = os.environ.get("SAHS_TRAIN_FORWARD", "fp32")
+if _TRAIN_FORWARD not in ("fp32", "bf16x3"):
+    raise _lib.SahsError("SAHS_TRAIN_FORWARD must be 'fp32' or 'bf16x3', not %r" % (_TRAIN_FORWARD,))
+_IDENTITY_SRC = {}
+
+
+def _identity_src(N, S, device):
+    """src of a radiance launch on the samples of its own pass in order (the coarse pass through the split kernels)"""
+    key = (int(N), int(S), str(device))
+    if key not in _IDENTITY_SRC:
+        _IDENTITY_SRC.clear()
+        _IDENTITY_SRC[key] = torch.arange(S, dtype=torch.int32, device=device).repeat(N, 1).contiguous()
+    return _IDENTITY_SRC[key]
 
 
 def field_backward_split(flat, frame, level, part, act, grad_flat, grad_cond, d_raw=None, xw_grad_in=None, arch="audio", full_act=False, bits=None):
@@ -636,9 +685,11 @@ class RenderRaysFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, flat, audio, pose, rays, bg, t_rand, noise_c, u, noise_f, packed, num_coarse, num_fine, lindisp, white_background,
-                arch="audio", loss_target=None, loss_mask=None, loss_weights=None):
+                arch="audio", loss_target=None, loss_mask=None, loss_weights=None, packed_x3=None):
         """With loss_target (N,>=3), loss_mask (N,12), loss_weights (12,) the op also returns (loss, stats) of the Stage-I objective
-        (stage1_loss_forward) and its backward forms that loss's gradient inside the composite backward kernels."""
+        (stage1_loss_forward) and its backward forms that loss's gradient inside the composite backward kernels.
+        packed_x3 (pack_weights(flat, SAHS_BF16X3); AudioFaceModel, kept path): the saving forward launches run on the split-operand
+        kernels (training_forward_precision "bf16x3") -- the coarse pass as a deformation + a radiance launch into one whole-network save."""
         frame = fold_conditioning(flat.detach(), audio.detach(), pose, arch=arch)
         ctx.arch = arch
         ctx.has_loss = loss_target is not None
@@ -665,11 +716,19 @@ class RenderRaysFn(torch.autograd.Function):
             xw = torch.empty(N, num_coarse + num_fine, 8, dtype=torch.float32, device=rays.device)
             sb = lambda samples, mode: alloc_sign_bits(samples, mode, arch, rays.device)      # (None: this architecture's backward reads none)
             bits_c, bits_d, bits_r = sb(N * num_coarse, FIELD_ALL), sb(N * num_fine, FIELD_DEFORM), sb(N * (num_coarse + num_fine), FIELD_RADIANCE)
-            raw_c, act_c = field_forward_split_save(packed, frame, 0, FIELD_ALL, rays, xw, z=z_c, arch=arch, bits=bits_c)
+            x3 = packed_x3 is not None and arch == "audio" and bits_c is not None
+            pk, prec = (packed_x3, SAHS_BF16X3) if x3 else (packed, SAHS_F32)
+            if x3:
+                act_c = torch.empty(N * num_coarse, _fn("act_words_part", arch)[0](FIELD_ALL), dtype=torch.float32, device=rays.device)
+                field_forward_split_save(pk, frame, 0, FIELD_DEFORM, rays, xw, z=z_c, arch=arch, precision=prec, whole=(act_c, bits_c))
+                raw_c, _ = field_forward_split_save(pk, frame, 0, FIELD_RADIANCE, rays, xw, src=_identity_src(N, num_coarse, rays.device), arch=arch,
+                                                    precision=prec, whole=(act_c, bits_c))
+            else:
+                raw_c, act_c = field_forward_split_save(packed, frame, 0, FIELD_ALL, rays, xw, z=z_c, arch=arch, bits=bits_c)
             rgb_c, disp_c, acc_c, w_c, _ = composite_forward(raw_c, z_c, rays, noise_c, bg, white_background)
             z_f, z_new, src = resample_merge(z_c, w_c, num_fine, u=u)
-            _, act_d = field_forward_split_save(packed, frame, 1, FIELD_DEFORM, rays, xw, z=z_new, xw_col0=num_coarse, arch=arch, bits=bits_d)
-            raw_f, act_r = field_forward_split_save(packed, frame, 1, FIELD_RADIANCE, rays, xw, src=src, arch=arch, bits=bits_r)
+            _, act_d = field_forward_split_save(pk, frame, 1, FIELD_DEFORM, rays, xw, z=z_new, xw_col0=num_coarse, arch=arch, bits=bits_d, precision=prec)
+            raw_f, act_r = field_forward_split_save(pk, frame, 1, FIELD_RADIANCE, rays, xw, src=src, arch=arch, bits=bits_r, precision=prec)
             del xw
             rgb_f, disp_f, acc_f, w_f, depth_f = composite_forward(raw_f, z_f, rays, noise_f, bg, white_background)
             outs = (rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_f[:, -1].contiguous(), depth_f)
@@ -791,4 +850,4 @@ class RenderRaysFn(torch.autograd.Function):
                   "sahs_conditioning_backward")
         else:       # NeRFaceModel: the driving vector is the expression itself
             grad_audio = grad_cond[:76].clone()
-        return (grad_flat, grad_audio) + (None,) * 16
+        return (grad_flat, grad_audio) + (None,) * 17

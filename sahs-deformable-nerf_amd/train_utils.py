@@ -89,8 +89,12 @@ def predict_and_render_radiance(ray_batch, model, options, mode="train", driving
         flat = model.flat_params(differentiable=True)
         # _loss = (target (N,>=3), mask (N,12), class weights (12,)): the op also returns (loss, stats) of the Stage-I objective and
         # forms that loss's gradient inside its composite backward (ops.RenderRaysFn)
+        # ops.training_forward_precision("bf16x3"): the saving forward of a batch that keeps its activations runs on the split-operand kernels
+        packed_x3 = None
+        if ops.training_forward_precision() == "bf16x3" and arch == "audio" and nf > 0 and N <= ops.RenderRaysFn.BLOCK_RAYS:
+            packed_x3, _ = model.packed(ops.SAHS_BF16X3)
         return ops.RenderRaysFn.apply(flat, driving.to(torch.float32), pose.to(torch.float32), rays.detach(), bg, t_rand, noise_c, u, noise_f,
-                                      packed, nc, nf, bool(opt.lindisp), bool(opt.white_background), arch, *(_loss or ()))
+                                      packed, nc, nf, bool(opt.lindisp), bool(opt.white_background), arch, *(_loss or (None, None, None)), packed_x3)
     if _rows is not None:
         ops.render_rays_rows(packed, frame, rays, nc, nf, _rows, precision=model.precision, lindisp=bool(opt.lindisp),
                              white_background=bool(opt.white_background), bg=bg, t_rand=t_rand, noise_c=noise_c, u=u, noise_f=noise_f,

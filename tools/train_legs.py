@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--per-layer", action="store_true", help="keep the per-layer backward walk (ops.fused_backward(False))")
-    ap.add_argument("--only", default=None, choices=["fp32", "bf16x3"])
+    ap.add_argument("--only", default=None, choices=["fp32", "bf16x3", "x3fwd"])
     a = ap.parse_args()
     pkg = importlib.import_module("sahs-deformable-nerf_amd")
     dev = torch.device("cuda:0")
@@ -28,6 +28,8 @@ def main():
     for mode in ("fp32", "bf16x3"):
         if a.only in (None, mode):
             out["train_T2048" + ("" if mode == "fp32" else "_bf16x3")] = bench.train_leg(pkg, dev, steps=a.steps, warmup=a.warmup, backward=mode)
+    if a.only in (None, "x3fwd"):      # the saving forward on the split-operand kernels too (ops.training_forward_precision)
+        out["train_T2048_x3fwd"] = bench.train_leg(pkg, dev, steps=a.steps, warmup=a.warmup, backward="bf16x3", forward="bf16x3")
     print(json.dumps(out))
 
 
