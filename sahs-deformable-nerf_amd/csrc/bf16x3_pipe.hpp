@@ -85,24 +85,66 @@ struct FwdAct {
 };
 
 // the SAVING forward's epilogue (training with the forward on this pipe): the activation, the post-activation values stored to the layer's
-// plane of the saved-activation buffer (sahs_layout.hpp: act; 16 bytes per lane and group, non-temporal), and their signs as the bytes of
-// the lane's two sign words (sbits: this lane (sample, h) owns words q = h and q = 2 + h outright; byte TILE of word h = groups 0 | 2,
-// of word 2 + h = groups 1 | 3)
+// plane of the saved-activation buffer (sahs_layout.hpp: act), and their signs as the bytes of the lane's two sign words (sbits: this lane
+// (sample, h) owns words q = h and q = 2 + h outright; byte TILE of word h = groups 0 | 2, of word 2 + h = groups 1 | 3).
+// The values do NOT go straight to memory: in the accumulator layout every store instruction would write 32 bytes into each of 32 rows
+// (measured: the radiance launch of a training step at 3.1 ms instead of ~0.7, the vector-memory address path busy with quarter lines).
+// A per-wave 32 x 16 staging tile in LDS (what is left of the 160 KB: half the 32 x 32 of the backward chain, field_bwd_chain.hip) turns
+// them around: the lane writes its four values, after every second group the wave reads the half tile back row-major and stores it as
+// 64-byte runs -- lane l -> rows (l >> 2) + 16 i, i = 0..1, 16 bytes (l & 3).  LDS instructions of one wave execute in issue order, so the
+// read-back needs no barrier behind the writes, nor the next group's writes behind the read-back.
+typedef __attribute__((address_space(3))) f32x4 *lds_f4_t;
+constexpr int SAVE_ROW_BYTES = 80;                                       // 16 floats + 4 of padding: 16-byte aligned rows, conflict-free b128 writes
+constexpr int SAVE_WAVE_BYTES = X_PTS_PER_WAVE * SAVE_ROW_BYTES;
+constexpr int LDS_SAVE_BYTE_OFF = LDS_BYTES;
+constexpr int LDS_BYTES_SAVE = LDS_SAVE_BYTE_OFF + (X_THREADS / WAVE) * SAVE_WAVE_BYTES;
+static_assert(LDS_BYTES_SAVE <= 160 * 1024, "LDS budget of the saving kernels");
+struct SaveStage {
+    uint32_t wr, rd;          // LDS byte addresses: this lane's row (+16 h) for writing; row l >> 2, piece l & 3 for reading back
+    uint32_t pc;              // 16 (l & 3): the piece's byte offset inside a 64-byte run
+    uint32_t prow[2];         // the sample index of read-back row i (clamped to P - 1 like the lane's own sample)
+    uint32_t soff;            // byte offset of this lane's sign word q = h in a plane of ONE word per (sample, q): 4 (4 sample + h)
+};
+__device__ __forceinline__ SaveStage make_save_stage(const char *lds, int wave, int lane, long wave_sample0, long sample, long P)
+{
+    SaveStage sc;
+    const uint32_t base = lds_addr_of(lds) + LDS_SAVE_BYTE_OFF + (uint32_t)wave * SAVE_WAVE_BYTES;
+    sc.wr = base + (uint32_t)(lane & 31) * SAVE_ROW_BYTES + 16u * (uint32_t)(lane >> 5);
+    sc.rd = base + (uint32_t)(lane >> 2) * SAVE_ROW_BYTES + 16u * (uint32_t)(lane & 3);
+    sc.pc = 16u * (uint32_t)(lane & 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long r = wave_sample0 + (lane >> 2) + 16 * i;
+        sc.prow[i] = (uint32_t)(r < P ? r : P - 1);
+    }
+    sc.soff = 4u * (4u * (uint32_t)sample + (uint32_t)(lane >> 5));
+    return sc;
+}
+template <int WIDTH, bool SIGN>
 struct SaveAct {
-    static constexpr bool stores(int) { return true; }
+    static constexpr bool stores(int) { return true; }      // (the counted wait of dense_x: a suffix of a tile's groups issues at least as many stores as it has groups)
+    static constexpr int NW = WIDTH >= 256 ? WIDTH / 128 : 1;      // sign words per (sample, q)
     float slope;
-    float *slot;              // this lane's slot of the layer's activation plane: its sample's row + 4 h floats (a per-lane pointer: with a uniform
-                              // plane base + a 32-bit lane offset the ~25 bases of the radiance kernel end in "illegal VGPR to SGPR copy" in the backend)
-    unsigned char *sign;      // this lane's sign word q = h of the layer's plane (null: no mask behind this layer); word 2 + h is `sign2` bytes further
-    uint32_t sign2;
+    float *plane;             // uniform: the layer's activation plane
+    unsigned char *sign;      // uniform: the layer's sign plane (SIGN)
+    SaveStage sc;
     template <int TILE, int U> __device__ __forceinline__ float value(float v, float m) const { return slope == 1.0f ? v : fmaxf(v, m); }
     template <int TILE, int G> __device__ __forceinline__ void done4(const float (&r)[4], uint32_t (&aux)[2]) const
     {
-        __builtin_nontemporal_store(f32x4{r[0], r[1], r[2], r[3]}, reinterpret_cast<f32x4 *>(slot + (32 * TILE + 8 * G)));
-        if (sign != nullptr) {
+        *(lds_f4_t)(uintptr_t)(sc.wr + 32 * (G & 1)) = f32x4{r[0], r[1], r[2], r[3]};
+        if constexpr (G & 1) {
+            f32x4 v[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) v[i] = *(lds_f4_t)(uintptr_t)(sc.rd + i * 16 * SAVE_ROW_BYTES);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(plane) +
+                                                                          (sc.prow[i] * (uint32_t)(WIDTH * 4) + sc.pc + (uint32_t)(128 * TILE + 64 * (G >> 1)))));
+        }
+        if constexpr (SIGN) {
             const uint32_t nib = (r[0] > 0.0f ? 1u : 0u) | (r[1] > 0.0f ? 2u : 0u) | (r[2] > 0.0f ? 4u : 0u) | (r[3] > 0.0f ? 8u : 0u);
             if constexpr (G < 2) aux[G] = nib;
-            else sign[(G & 1) * sign2 + TILE] = (unsigned char)(aux[G - 2] | (nib << 4));
+            else sign[sc.soff * (uint32_t)NW + (uint32_t)((G & 1) * 8 * NW + TILE)] = (unsigned char)(aux[G - 2] | (nib << 4));
         }
     }
 };

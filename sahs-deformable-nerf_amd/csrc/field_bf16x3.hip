@@ -92,17 +92,16 @@ __device__ __forceinline__ void pe_blocks_x(const float *v, int h, Blk *out, flo
 }
 
 // the epilogue policy of a layer: the plain activation, or (SAVE: training) the activation + its plane of the saved activations + its sign
-// words.  col: the layer's column of the act:: table; boff: its word offset in the part's sign planes (< 0: no mask behind this layer)
-template <bool SAVE>
-__device__ __forceinline__ auto layer_policy(float slope, float *actbuf, uint32_t *bits, long P, uint32_t pl, int h, int col, int width, int boff)
+// words.  col: the layer's column of the act:: table; BOFF: its word offset in the part's sign planes (< 0: no mask behind this layer)
+template <bool SAVE, int WIDTH, int BOFF>
+__device__ __forceinline__ auto layer_policy(float slope, float *actbuf, uint32_t *bits, long P, const SaveStage &sc, int col, int boff)
 {
     if constexpr (SAVE) {
-        SaveAct e;
-        const int nw = width >= 256 ? 2 : 1;
+        SaveAct<WIDTH, (BOFF >= 0)> e;
         e.slope = slope;
-        e.slot = actbuf + ((long)col * P + (long)pl * width + 4 * h);
-        e.sign = boff >= 0 ? reinterpret_cast<unsigned char *>(bits + (long)boff * P + ((long)pl * 4 + h) * nw) : nullptr;
-        e.sign2 = 2u * nw * 4u;
+        e.plane = actbuf + (long)col * P;
+        e.sign = reinterpret_cast<unsigned char *>(bits + (long)boff * P);
+        e.sc = sc;
         return e;
     } else {
         return FwdAct{slope};
@@ -200,8 +199,10 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
         const long p = p_raw < P ? p_raw : P - 1;      // (SAVE: lanes past the end redo the last sample -- identical values to identical addresses)
         long Pq = P;
         if constexpr (SAVE) asm volatile("" : "+s"(Pq));      // (the ~25 plane bases c * P: keep them from being hoisted out of the tile loop and spilled)
-        const uint32_t pl = (uint32_t)p;
-#define pol(slope, c, width, boff) layer_policy<SAVE>(slope, actbuf, bits, Pq, pl, h, c, width, boff)
+        SaveStage sst;
+        if constexpr (SAVE) sst = make_save_stage(lds_x, cx.wave, cx.lane, tile * X_PTS_PER_WG + cx.wave * X_PTS_PER_WAVE, p, P);
+#define pol(slope, c, width, boff) layer_policy<SAVE, width, 0>(slope, actbuf, bits, Pq, sst, c, boff)
+#define pol_nosign(slope, c, width) layer_policy<SAVE, width, -1>(slope, actbuf, bits, Pq, sst, c, 0)
 #define plane(c, width) (SAVE ? actbuf + (long)(c) * Pq + p * (width) + 4 * h : nullptr)
         typedef __attribute__((address_space(3))) float *lds_float;
         const lds_float stash = (lds_float)(__attribute__((address_space(3))) char *)(lds_x + LDS_STASH_BYTE_OFF) + (cx.wave * X_PTS_PER_WAVE + col) * STASH_FLOATS;
@@ -244,10 +245,10 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
                 dense_x<8, 0, 0, 8, CHX(H_T5), true, 7>(cx, st, A, nullptr, nullptr, B, Ly[H_T4].bias_off + 512 * j + 256,
                                                        pol(0.01f, act::T + 256 * (5 + 2 * j), 256, sbits::BR_T + 8 * (5 + 2 * j)), ea);
             }
-            dense_x<8, 0, 0, 8, CHX(H_ALPHA), true, 7>(cx, st, B, nullptr, nullptr, A, Ly[H_FEAT].bias_off, pol(1.0f, act::FEAT, 256, -1),
+            dense_x<8, 0, 0, 8, CHX(H_ALPHA), true, 7>(cx, st, B, nullptr, nullptr, A, Ly[H_FEAT].bias_off, pol_nosign(1.0f, act::FEAT, 256),
                                                       pol(0.01f, act::T + 256 * 7, 256, sbits::BR_T + 8 * 7));
         }
-        dense_x_out<8, CHX(H_D0), 7>(cx, st, A, fin, Ly[H_ALPHA].bias_off, true, pol(1.0f, act::FEAT, 256, -1));
+        dense_x_out<8, CHX(H_D0), 7>(cx, st, A, fin, Ly[H_ALPHA].bias_off, true, pol_nosign(1.0f, act::FEAT, 256));
         {   // colour branch
             Blk in_d[2];
             {
@@ -287,6 +288,7 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
 }
 
 #undef pol
+#undef pol_nosign
 #undef plane
 #endif      // SAHS_MODEL == 0
 
@@ -340,8 +342,9 @@ field_deform_bf16x3_kernel(const float *__restrict__ packed, const float *__rest
         const long p = p_raw < P ? p_raw : P - 1;
         long Pq = P;
         if constexpr (SAVE) asm volatile("" : "+s"(Pq));      // (plane bases c * P: not hoisted out of the tile loop)
-        const uint32_t pl = (uint32_t)p;
-#define pold(c, width, boff) layer_policy<SAVE>(0.0f, actbuf, bits, Pq, pl, h, c, width, boff)
+        SaveStage sst;
+        if constexpr (SAVE) sst = make_save_stage(lds_x, cx.wave, cx.lane, tile * X_PTS_PER_WG + cx.wave * X_PTS_PER_WAVE, p, P);
+#define pold(c, width, boff) layer_policy<SAVE, width, 0>(0.0f, actbuf, bits, Pq, sst, c, boff)
         float x[3], xp[3], amb[2], dx[3];
         {
             const float *rp = rays + (p / S) * ray_stride;
@@ -424,10 +427,10 @@ static int launch_radiance_x3(const float *packed, const float *frame, int level
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     static sahs_once::Flags attr_set;
     hipError_t ae = sahs_once::per_device(attr_set, [&]() {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_radiance_bf16x3_kernel<SAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_radiance_bf16x3_kernel<SAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, SAVE ? LDS_BYTES_SAVE : LDS_BYTES);
     });
     if (ae != hipSuccess) return (int)ae;
-    field_radiance_bf16x3_kernel<SAVE><<<grid, X_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, raw, xw, xw_row, src, actbuf, bits);
+    field_radiance_bf16x3_kernel<SAVE><<<grid, X_THREADS, SAVE ? LDS_BYTES_SAVE : LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, raw, xw, xw_row, src, actbuf, bits);
     return (int)hipGetLastError();
 }
 // the radiance launch of the split evaluation (field_f32.hip: sahs_field_forward_f32_split_launch mode 2, same arguments)
@@ -457,10 +460,10 @@ static int launch_deform_x3(const float *packed, const float *frame, int level, 
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
     static sahs_once::Flags attr_set;
     hipError_t ae = sahs_once::per_device(attr_set, [&]() {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_deform_bf16x3_kernel<SAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(field_deform_bf16x3_kernel<SAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, SAVE ? LDS_BYTES_SAVE : LDS_BYTES);
     });
     if (ae != hipSuccess) return (int)ae;
-    field_deform_bf16x3_kernel<SAVE><<<grid, X_THREADS, LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, xw, xw_row, xw_col0, actbuf, bits);
+    field_deform_bf16x3_kernel<SAVE><<<grid, X_THREADS, SAVE ? LDS_BYTES_SAVE : LDS_BYTES, stream>>>(packed, frame, level, P, S, rays, ray_stride, zvals, xw, xw_row, xw_col0, actbuf, bits);
     return (int)hipGetLastError();
 }
 // the deformation launch of the split evaluation (field_f32.hip: sahs_field_forward_f32_split_launch mode 1, same arguments)

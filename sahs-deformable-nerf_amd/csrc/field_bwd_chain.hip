@@ -202,7 +202,6 @@ struct StageCtx {
 };
 constexpr int STAGE_ROW_BYTES = 144;                                      // 32 floats + 4 of padding: 16-byte aligned rows, spread over the banks
 constexpr int STAGE_WAVE_BYTES = 32 * STAGE_ROW_BYTES;
-typedef __attribute__((address_space(3))) f32x4 *lds_f4_t;
 
 template <bool MASKED, int NVALID, int WIDTH>
 struct BwdEp {
