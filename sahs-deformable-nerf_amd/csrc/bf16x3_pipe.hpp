@@ -136,10 +136,16 @@ struct SaveAct {
             f32x4 v[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) v[i] = *(lds_f4_t)(uintptr_t)(sc.rd + i * 16 * SAVE_ROW_BYTES);
+#if defined(SAHS_DIAG) && defined(SAHS_X3_SAVE_PLAIN)      // A/B: default cache policy instead of non-temporal
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(plane) + (sc.prow[i] * (uint32_t)(WIDTH * 4) + sc.pc + (uint32_t)(128 * TILE + 64 * (G >> 1)))) = v[i];
+#else
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(plane) +
                                                                           (sc.prow[i] * (uint32_t)(WIDTH * 4) + sc.pc + (uint32_t)(128 * TILE + 64 * (G >> 1)))));
+#endif
         }
         if constexpr (SIGN) {
             const uint32_t nib = (r[0] > 0.0f ? 1u : 0u) | (r[1] > 0.0f ? 2u : 0u) | (r[2] > 0.0f ? 4u : 0u) | (r[3] > 0.0f ? 8u : 0u);

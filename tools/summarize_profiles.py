@@ -79,6 +79,7 @@ for leg, args, steps, what in (("f32", "--precision fp32", 8, "fp32 W512 headlin
     shutil.copy(os.path.join(base, "bench_trace_%s.json" % leg), os.path.join(out, "%s_%s_bench_under_rocprof.json" % (tag, {"f32": "fp32"}.get(leg, leg))))
 for sub, name, arg, what in (("trace_train", "train_T2048_bf16x3", "bf16x3", "the default backward: field_backward_chain_{rad,def}_kernel = the sample-major data-gradient chains, "
                               "gemm_tn_jobs_kernel = every weight gradient of a part in one launch, both on the bf16 pipe with split operands"),
+                             ("trace_train_x3fwd", "train_T2048_x3fwd", "x3fwd", "opt-in: the saving forward on the split-operand kernels too -- field_{radiance,deform}_bf16x3_kernel<true>"),
                              ("trace_train_f32", "train_T2048", "fp32", "backward products in f32 (the reference's arithmetic): the per-layer walk, gemm_dma_kernel<*, false>")):
     if glob.glob(os.path.join(base, sub, "*", "*_kernel_stats.csv")):
         stats[sub] = kernel_stats(sub, "%s_%s_kernel_stats.csv" % (tag, name),
@@ -151,30 +152,32 @@ def last_step(rows):
     return rows[idx[-2] + 1: idx[-1] + 1]
 
 
-try:
-    fs = last_step(list(csv.DictReader(open(newest(os.path.join(base, "pmc_train_FETCH_SIZE", "*", "*counter_collection.csv"))))))
-    ws = last_step(list(csv.DictReader(open(newest(os.path.join(base, "pmc_train_WRITE_SIZE", "*", "*counter_collection.csv"))))))
+for pmc_tag, leg_arg, key in (("pmc_train", "bf16x3", "train_T2048"), ("pmc_trainx3", "x3fwd", "train_T2048_x3fwd")):
+  try:
+    fs = last_step(list(csv.DictReader(open(newest(os.path.join(base, pmc_tag + "_FETCH_SIZE", "*", "*counter_collection.csv"))))))
+    ws = last_step(list(csv.DictReader(open(newest(os.path.join(base, pmc_tag + "_WRITE_SIZE", "*", "*counter_collection.csv"))))))
     tr = collections.OrderedDict()
     for a, b in zip(fs, ws):
         n = a["Kernel_Name"]
         nm = ("weight gradients over job tables: gemm_tn_jobs_kernel + gemm_tn_jobs256_kernel" if "gemm_tn_jobs" in n else "data-gradient chain field_backward_chain_*_kernel" if "field_backward_chain" in n else
               "weight-gradient GEMM gemm_tn_split_kernel" if "gemm_tn_split_kernel" in n else "weight-gradient GEMM gemm_dma_kernel<true,*>" if "gemm_dma_kernel<true" in n else "data-gradient GEMM gemm_dma_kernel<false,true>" if "gemm_dma_kernel<false" in n
-              else "field_forward_f32_kernel<true,*> (activation-saving forward)" if "field_forward" in n else "gemm_f32_kernel" if "gemm_f32" in n else "other")
+              else "field_forward_f32_kernel<true,*> (activation-saving forward)" if "field_forward" in n
+              else "field_{radiance,deform}_bf16x3_kernel<true> (activation-saving forward, split operands)" if "bf16x3_kernel" in n else "gemm_f32_kernel" if "gemm_f32" in n else "other")
         d = tr.setdefault(nm, [0, 0.0, 0.0, 0.0])
         d[0] += 1
         d[1] += float(a["Counter_Value"]) * 2048
         d[2] += float(b["Counter_Value"]) * 1024
         d[3] += (int(a["End_Timestamp"]) - int(a["Start_Timestamp"])) * 1e-9
-    lines += ["", "# training step T2048 (tools/train_legs.py --only bf16x3), one step: HBM-side bytes per kernel group (2 x FETCH_SIZE + WRITE_SIZE) and the rate over the kernels' time",
+    lines += ["", "# training step T2048 (tools/train_legs.py --only %s), one step: HBM-side bytes per kernel group (2 x FETCH_SIZE + WRITE_SIZE) and the rate over the kernels' time" % leg_arg,
               "train_kernel_group,launches,fetch_GB_x2,write_GB,time_ms,TB_per_s"]
     tot = [0.0, 0.0, 0.0]
     for nm, d in tr.items():
         lines.append("%s,%d,%.3f,%.3f,%.3f,%.2f" % (nm, d[0], d[1] / 1e9, d[2] / 1e9, d[3] * 1e3, (d[1] + d[2]) / d[3] / 1e12))
         tot = [tot[0] + d[1], tot[1] + d[2], tot[2] + d[3]]
     lines.append("total,,%.3f,%.3f,%.3f,%.2f" % (tot[0] / 1e9, tot[1] / 1e9, tot[2] * 1e3, (tot[0] + tot[1]) / tot[2] / 1e12))
-    summary["train_T2048"] = {"fetch_bytes_corrected": tot[0], "write_bytes": tot[1], "kernel_time_ms": tot[2] * 1e3}
-except (IndexError, OSError) as e:
-    lines.append("# training-step counters missing: %r" % (e,))
+    summary[key] = {"fetch_bytes_corrected": tot[0], "write_bytes": tot[1], "kernel_time_ms": tot[2] * 1e3}
+  except (IndexError, OSError) as e:
+    lines.append("# training-step counters missing (%s): %r" % (key, e))
 # ---- GPU power / clock sampled by rocm-smi beside each traced leg (tools/profile.sh) ----
 def smi_summary(path):
     """-> list of (power W, sclk MHz) samples"""
