@@ -89,32 +89,34 @@ struct FwdAct {
 // (sample, h) owns words q = h and q = 2 + h outright; byte TILE of word h = groups 0 | 2, of word 2 + h = groups 1 | 3).
 // The values do NOT go straight to memory: in the accumulator layout every store instruction would write 32 bytes into each of 32 rows
 // (measured: the radiance launch of a training step at 3.1 ms instead of ~0.7, the vector-memory address path busy with quarter lines).
-// A per-wave 32 x 16 staging tile in LDS (what is left of the 160 KB: half the 32 x 32 of the backward chain, field_bwd_chain.hip) turns
-// them around: the lane writes its four values, after every second group the wave reads the half tile back row-major and stores it as
-// 64-byte runs -- lane l -> rows (l >> 2) + 16 i, i = 0..1, 16 bytes (l & 3).  LDS instructions of one wave execute in issue order, so the
-// read-back needs no barrier behind the writes, nor the next group's writes behind the read-back.
+// A per-wave 32 x 32 staging tile in LDS (as in the backward chain, field_bwd_chain.hip) turns them around: the lane writes its four
+// values, after the tile's fourth group the wave reads it back row-major and stores WHOLE 128-byte lines, non-temporal -- lane l -> rows
+// (l >> 3) + 8 i, i = 0..3, 16 bytes (l & 7).  (Half tiles stored as 64-byte runs, the first version: 20 % more bytes at the memory --
+// WRITE_SIZE 4.59 against 3.94 GB for the fine radiance launch -- and default-policy stores, which merge in L2, evict the weight stream:
+// 1.31 against 1.04 ms.)  LDS instructions of one wave execute in issue order: no barrier between the writes and the read-back.
+// Where the four tiles (18 KB) live is the kernel's business (field_bf16x3.hip: the saving kernels give up the biases of the nets they do
+// not run, the radiance kernel also its x', w stash).
 typedef __attribute__((address_space(3))) f32x4 *lds_f4_t;
-constexpr int SAVE_ROW_BYTES = 80;                                       // 16 floats + 4 of padding: 16-byte aligned rows, conflict-free b128 writes
-constexpr int SAVE_WAVE_BYTES = X_PTS_PER_WAVE * SAVE_ROW_BYTES;
-constexpr int LDS_SAVE_BYTE_OFF = LDS_BYTES;
-constexpr int LDS_BYTES_SAVE = LDS_SAVE_BYTE_OFF + (X_THREADS / WAVE) * SAVE_WAVE_BYTES;
-static_assert(LDS_BYTES_SAVE <= 160 * 1024, "LDS budget of the saving kernels");
+constexpr int SAVE_ROW_BYTES = 144;                                      // 32 floats + 4 of padding: 16-byte aligned rows, spread over the banks
+constexpr int SAVE_WAVE_BYTES = X_PTS_PER_WAVE * SAVE_ROW_BYTES;         // 4608
+constexpr int LDS_BYTES_SAVE = 160 * 1024;
 struct SaveStage {
-    uint32_t wr, rd;          // LDS byte addresses: this lane's row (+16 h) for writing; row l >> 2, piece l & 3 for reading back
-    uint32_t pc;              // 16 (l & 3): the piece's byte offset inside a 64-byte run
-    uint32_t prow[2];         // the sample index of read-back row i (clamped to P - 1 like the lane's own sample)
+    uint32_t wr, rd;          // LDS byte addresses: this lane's row (+16 h) for writing; row l >> 3, piece l & 7 for reading back
+    uint32_t pc;              // 16 (l & 7): the piece's byte offset inside a 128-byte line
+    uint32_t prow[4];         // the sample index of read-back row i (clamped to P - 1 like the lane's own sample)
     uint32_t soff;            // byte offset of this lane's sign word q = h in a plane of ONE word per (sample, q): 4 (4 sample + h)
 };
-__device__ __forceinline__ SaveStage make_save_stage(const char *lds, int wave, int lane, long wave_sample0, long sample, long P)
+// tile_byte_off: where this wave's staging tile starts in the workgroup's LDS
+__device__ __forceinline__ SaveStage make_save_stage(const char *lds, uint32_t tile_byte_off, int lane, long wave_sample0, long sample, long P)
 {
     SaveStage sc;
-    const uint32_t base = lds_addr_of(lds) + LDS_SAVE_BYTE_OFF + (uint32_t)wave * SAVE_WAVE_BYTES;
+    const uint32_t base = lds_addr_of(lds) + tile_byte_off;
     sc.wr = base + (uint32_t)(lane & 31) * SAVE_ROW_BYTES + 16u * (uint32_t)(lane >> 5);
-    sc.rd = base + (uint32_t)(lane >> 2) * SAVE_ROW_BYTES + 16u * (uint32_t)(lane & 3);
-    sc.pc = 16u * (uint32_t)(lane & 3);
+    sc.rd = base + (uint32_t)(lane >> 3) * SAVE_ROW_BYTES + 16u * (uint32_t)(lane & 7);
+    sc.pc = 16u * (uint32_t)(lane & 7);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const long r = wave_sample0 + (lane >> 2) + 16 * i;
+    for (int i = 0; i < 4; ++i) {
+        const long r = wave_sample0 + (lane >> 3) + 8 * i;
         sc.prow[i] = (uint32_t)(r < P ? r : P - 1);
     }
     sc.soff = 4u * (4u * (uint32_t)sample + (uint32_t)(lane >> 5));
@@ -122,7 +124,7 @@ __device__ __forceinline__ SaveStage make_save_stage(const char *lds, int wave, 
 }
 template <int WIDTH, bool SIGN>
 struct SaveAct {
-    static constexpr bool stores(int) { return true; }      // (the counted wait of dense_x: a suffix of a tile's groups issues at least as many stores as it has groups)
+    static constexpr bool stores(int) { return true; }      // (the counted wait of dense_x: a suffix of a tile's groups issues at least as many stores as it has groups: 4 + sign bytes at the fourth)
     static constexpr int NW = WIDTH >= 256 ? WIDTH / 128 : 1;      // sign words per (sample, q)
     float slope;
     float *plane;             // uniform: the layer's activation plane
@@ -131,20 +133,19 @@ struct SaveAct {
     template <int TILE, int U> __device__ __forceinline__ float value(float v, float m) const { return slope == 1.0f ? v : fmaxf(v, m); }
     template <int TILE, int G> __device__ __forceinline__ void done4(const float (&r)[4], uint32_t (&aux)[2]) const
     {
-        *(lds_f4_t)(uintptr_t)(sc.wr + 32 * (G & 1)) = f32x4{r[0], r[1], r[2], r[3]};
-        if constexpr (G & 1) {
-            f32x4 v[2];
+        *(lds_f4_t)(uintptr_t)(sc.wr + 32 * G) = f32x4{r[0], r[1], r[2], r[3]};
+        if constexpr (G == 3) {
+            f32x4 v[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) v[i] = *(lds_f4_t)(uintptr_t)(sc.rd + i * 16 * SAVE_ROW_BYTES);
+            for (int i = 0; i < 4; ++i) v[i] = *(lds_f4_t)(uintptr_t)(sc.rd + i * 8 * SAVE_ROW_BYTES);
 #if defined(SAHS_DIAG) && defined(SAHS_X3_SAVE_PLAIN)      // A/B: default cache policy instead of non-temporal
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(plane) + (sc.prow[i] * (uint32_t)(WIDTH * 4) + sc.pc + (uint32_t)(128 * TILE + 64 * (G >> 1)))) = v[i];
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(plane) + (sc.prow[i] * (uint32_t)(WIDTH * 4) + sc.pc + (uint32_t)(128 * TILE))) = v[i];
 #else
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(plane) +
-                                                                          (sc.prow[i] * (uint32_t)(WIDTH * 4) + sc.pc + (uint32_t)(128 * TILE + 64 * (G >> 1)))));
+            for (int i = 0; i < 4; ++i)
+                __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(plane) + (sc.prow[i] * (uint32_t)(WIDTH * 4) + sc.pc + (uint32_t)(128 * TILE))));
 #endif
         }
         if constexpr (SIGN) {

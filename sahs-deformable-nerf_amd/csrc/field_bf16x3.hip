@@ -164,6 +164,10 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
                              const int *__restrict__ src, float *__restrict__ actbuf, uint32_t *__restrict__ bits)
 {
     constexpr uint32_t RAD_OFF = (uint32_t)(2 * kProgH.layer[H_T0].stream_off);
+    // SAVE: the four staging tiles of the epilogue (bf16x3_pipe.hpp: SaveAct) -- wave 0's where the deformation nets' biases would be, the
+    // others' from the x', w stash on (those five values stay in registers instead) to the end of the 160 KB
+    constexpr int RAD_BIAS0 = kProgH.layer[H_T0].bias_off;
+    static_assert(!SAVE || (RAD_BIAS0 * 4 >= SAVE_WAVE_BYTES && LDS_STASH_BYTE_OFF + (X_THREADS / WAVE - 1) * SAVE_WAVE_BYTES <= LDS_BYTES_SAVE), "staging tiles of the saving radiance kernel");
     extern __shared__ __attribute__((aligned(16))) char lds_x[];
     Ctx cx;
     cx.stream = reinterpret_cast<const unsigned short *>(packed + PACKX_STREAM_OFF) + (long)level * STREAM_HWX;
@@ -177,7 +181,8 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
     {
         const float *bsrc = frame + FRAME_BIAS_OFF + level * BIAS_FLOATS;
         float *bl = reinterpret_cast<float *>(lds_x + LDS_BIAS_BYTE_OFF);
-        for (int i = threadIdx.x; i < BIAS_FLOATS; i += X_THREADS) bl[i] = bsrc[i];
+        // (SAVE: the biases of the deformation nets, which this kernel does not run, make room for a staging tile: RAD_BIAS0 floats)
+        for (int i = threadIdx.x + (SAVE ? RAD_BIAS0 : 0); i < BIAS_FLOATS; i += X_THREADS) bl[i] = bsrc[i];
         cx.wrap_at = (uint32_t)STREAM_HWX;
         cx.wrap_to = RAD_OFF;
         cx.off = RAD_OFF;
@@ -200,18 +205,27 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
         long Pq = P;
         if constexpr (SAVE) asm volatile("" : "+s"(Pq));      // (the ~25 plane bases c * P: keep them from being hoisted out of the tile loop and spilled)
         SaveStage sst;
-        if constexpr (SAVE) sst = make_save_stage(lds_x, cx.wave, cx.lane, tile * X_PTS_PER_WG + cx.wave * X_PTS_PER_WAVE, p, P);
+        if constexpr (SAVE)
+            sst = make_save_stage(lds_x, cx.wave == 0 ? (uint32_t)LDS_BIAS_BYTE_OFF : (uint32_t)(LDS_STASH_BYTE_OFF + (cx.wave - 1) * SAVE_WAVE_BYTES), cx.lane,
+                                  tile * X_PTS_PER_WG + cx.wave * X_PTS_PER_WAVE, p, P);
 #define pol(slope, c, width, boff) layer_policy<SAVE, width, 0>(slope, actbuf, bits, Pq, sst, c, boff)
 #define pol_nosign(slope, c, width) layer_policy<SAVE, width, -1>(slope, actbuf, bits, Pq, sst, c, 0)
 #define plane(c, width) (SAVE ? actbuf + (long)(c) * Pq + p * (width) + 4 * h : nullptr)
         typedef __attribute__((address_space(3))) float *lds_float;
         const lds_float stash = (lds_float)(__attribute__((address_space(3))) char *)(lds_x + LDS_STASH_BYTE_OFF) + (cx.wave * X_PTS_PER_WAVE + col) * STASH_FLOATS;
-        if (h == 0) {
+        float sxw[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#define xwv(i) (SAVE ? sxw[i] : stash[i])      /* x'[3], w[2] of this lane's sample: SAVE in registers (both lanes of the sample load them), else parked in LDS */
+        if (SAVE || h == 0) {
             const float *row = xw + ((p / S) * (long)xw_row + (src != nullptr ? src[p] : (int)(p % S))) * 8;
             const f32x4 v = *reinterpret_cast<const f32x4 *>(row);
-            stash[0] = v[0]; stash[1] = v[1]; stash[2] = v[2]; stash[3] = v[3];
-            stash[4] = row[4];
-            if constexpr (SAVE) { float *d = actbuf + (long)act::XW * Pq + p * 16; d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; }      // the grid backward reads x'
+            if constexpr (SAVE) {
+                sxw[0] = v[0]; sxw[1] = v[1]; sxw[2] = v[2]; sxw[3] = v[3];
+                sxw[4] = row[4];
+                if (h == 0) { float *d = actbuf + (long)act::XW * Pq + p * 16; d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; }      // the grid backward reads x'
+            } else {
+                stash[0] = v[0]; stash[1] = v[1]; stash[2] = v[2]; stash[3] = v[3];
+                stash[4] = row[4];
+            }
         }
         __builtin_amdgcn_wave_barrier();
         Blk A[8];
@@ -221,7 +235,7 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
             const auto e0 = pol(0.01f, act::T, 256, sbits::BR_T);
             {
                 Blk in_tr[3];
-                const float xp[3] = {stash[0], stash[1], stash[2]}, amb[3] = {stash[3], stash[4], 0.0f};
+                const float xp[3] = {xwv(0), xwv(1), xwv(2)}, amb[3] = {xwv(3), xwv(4), 0.0f};
                 pe_blocks_x<3, 10, 2>(xp, h, in_tr, plane(act::PEX, 64));
                 pe_blocks_x<2, 4, 1>(amb, h, in_tr + 2, plane(act::PEW, 32));
                 dense_x<2, 1, 0, 8, CHX(H_T1), false>(cx, st, in_tr, in_tr + 2, nullptr, A, Ly[H_T0].bias_off, e0, FwdAct{1.0f});
@@ -232,7 +246,7 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
             dense_x<8, 0, 0, 8, CHX(H_T3), true, 7>(cx, st, B, nullptr, nullptr, A, Ly[H_T2].bias_off, e2, e1);
             {   // the re-injected encoding [PE(x') | PE(w)] is rebuilt at the skip layer instead of staying live
                 Blk in_tr[3];
-                const float xp[3] = {stash[0], stash[1], stash[2]}, amb[3] = {stash[3], stash[4], 0.0f};
+                const float xp[3] = {xwv(0), xwv(1), xwv(2)}, amb[3] = {xwv(3), xwv(4), 0.0f};
                 pe_blocks_x<3, 10, 2>(xp, h, in_tr);
                 pe_blocks_x<2, 4, 1>(amb, h, in_tr + 2);
                 dense_x<8, 2, 1, 8, CHX(H_T4), true, 7>(cx, st, A, in_tr, in_tr + 2, B, Ly[H_T3].bias_off, pol(0.01f, act::T + 768, 256, sbits::BR_T + 24), e2);
@@ -255,7 +269,7 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
                 const float *rq = rays + (p / S) * ray_stride;
                 const float rdir[3] = {rq[3], rq[4], rq[5]};
                 pe_blocks_x<3, 4, 1>(rdir, h, in_d, plane(act::DIR, 32));
-                grid_block_x(grid, stash[0], stash[1], stash[2], h, in_d[1], plane(act::GRID, 32));
+                grid_block_x(grid, xwv(0), xwv(1), xwv(2), h, in_d[1], plane(act::GRID, 32));
             }
             Blk c[4], cn[4];
             const auto d0 = pol(0.01f, act::C, 128, sbits::BR_C);
@@ -288,6 +302,7 @@ field_radiance_bf16x3_kernel(const float *__restrict__ packed, const float *__re
 }
 
 #undef pol
+#undef xwv
 #undef pol_nosign
 #undef plane
 #endif      // SAHS_MODEL == 0
@@ -308,6 +323,8 @@ field_deform_bf16x3_kernel(const float *__restrict__ packed, const float *__rest
                            int xw_col0, float *__restrict__ actbuf, uint32_t *__restrict__ bits)
 {
     constexpr uint32_t RAD_OFF = (uint32_t)(2 * kProgH.layer[H_T0].stream_off);
+    constexpr int DEF_BIAS1 = kProgH.layer[H_T0].bias_off;      // the deformation nets' biases are the first of the level's array
+    static_assert(!SAVE || LDS_BIAS_BYTE_OFF + DEF_BIAS1 * 4 + (X_THREADS / WAVE) * SAVE_WAVE_BYTES <= LDS_BYTES_SAVE, "staging tiles of the saving deformation kernel");
     extern __shared__ __attribute__((aligned(16))) char lds_x[];
     Ctx cx;
     cx.stream = reinterpret_cast<const unsigned short *>(packed + PACKX_STREAM_OFF) + (long)level * STREAM_HWX;
@@ -320,7 +337,8 @@ field_deform_bf16x3_kernel(const float *__restrict__ packed, const float *__rest
     {
         const float *bsrc = frame + FRAME_BIAS_OFF + level * BIAS_FLOATS;
         float *bl = reinterpret_cast<float *>(lds_x + LDS_BIAS_BYTE_OFF);
-        for (int i = threadIdx.x; i < BIAS_FLOATS; i += X_THREADS) bl[i] = bsrc[i];
+        // (SAVE: only the deformation nets' biases; the staging tiles of the epilogue take the place of the others': SaveAct)
+        for (int i = threadIdx.x; i < (SAVE ? DEF_BIAS1 : BIAS_FLOATS); i += X_THREADS) bl[i] = bsrc[i];
         cx.wrap_at = RAD_OFF;          // the deformation nets are the stream's first layers: [0, RAD_OFF)
         cx.wrap_to = 0u;
         cx.off = 0u;
@@ -343,7 +361,8 @@ field_deform_bf16x3_kernel(const float *__restrict__ packed, const float *__rest
         long Pq = P;
         if constexpr (SAVE) asm volatile("" : "+s"(Pq));      // (plane bases c * P: not hoisted out of the tile loop)
         SaveStage sst;
-        if constexpr (SAVE) sst = make_save_stage(lds_x, cx.wave, cx.lane, tile * X_PTS_PER_WG + cx.wave * X_PTS_PER_WAVE, p, P);
+        if constexpr (SAVE)
+            sst = make_save_stage(lds_x, (uint32_t)(LDS_BIAS_BYTE_OFF + DEF_BIAS1 * 4 + cx.wave * SAVE_WAVE_BYTES), cx.lane, tile * X_PTS_PER_WG + cx.wave * X_PTS_PER_WAVE, p, P);
 #define pold(c, width, boff) layer_policy<SAVE, width, 0>(0.0f, actbuf, bits, Pq, sst, c, boff)
         float x[3], xp[3], amb[2], dx[3];
         {
