@@ -624,6 +624,12 @@ static_assert(TN_LDS_BYTES == 81920, "two workgroups per CU: 2 x 80 KB = the 160
 
 // One 128 x 128 tile of C += A^T B over the samples [k_lo, k_hi): the body shared by the per-layer kernel (one tile-slab per workgroup)
 // and the job-table kernel (a workgroup walks many).  Ends on an LDS barrier: the ring and the fragment buffer are free on return.
+// position (dwords) of column `col`'s 4 dwords (8 bf16: samples 8 h .. 8 h + 7 of a K-step) inside one [hi] or [lo] fragment block of GT
+// columns: [32-column group][h][column of the group][4 dwords] -- the MFMA phase's lane (r32, h) and the split phase's thread (column, h) both
+// touch 16 bytes at 16 x lane: conflict-free ds_read_b128 / ds_write_b128.  (Round 4, first form: [column][h][4 dwords] = a 32-byte lane
+// stride, two lanes per bank group -- SQ_LDS_BANK_CONFLICT 1.5-1.7 x SQ_ACTIVE_INST_LDS in both weight-gradient kernels.)
+__device__ __forceinline__ constexpr int frag_pos(int col, int h) { return ((col >> 5) * 64 + h * 32 + (col & 31)) * 4; }
+
 __device__ __forceinline__ void tn_tile(float *tn_lds, int M, int N, const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
                                         float *__restrict__ C, long ldc, long k_lo, long k_hi, float *__restrict__ rowsum, int bx, int by,
                                         const float *__restrict__ zero, unsigned char *__restrict__ bits)
@@ -666,12 +672,12 @@ __device__ __forceinline__ void tn_tile(float *tn_lds, int M, int N, const float
     // split phase: this thread's column of its operand tile, at its two swizzle positions (even / odd sample rows)
     const int sop = tid >> 8, skh = (tid >> 7) & 1, scol = tid & 127;        // samples 8 skh .. 8 skh + 7 of the column
     const int spos0 = scol, spos1 = (((scol >> 2) ^ 4) << 2) + (scol & 3);
-    uint32_t *fdst = frag + ((sop * 2) * GT + scol) * 8 + 4 * skh;           // hi row of this column; the lo row is GT * 8 dwords further
+    uint32_t *fdst = frag + (sop * 2) * GT * 8 + frag_pos(scol, skh);        // hi block of this column; the lo block is GT * 8 dwords further
     // MFMA phase: fragment rows of this wave's 2 + 2 column blocks
     const uint32_t *fa[2], *fb;                                              // wave (wm, wn): rows 64 wm + 32 i, columns 32 wn
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fa[i] = frag + ((0 * 2) * GT + 64 * wm + 32 * i + r32) * 8 + 4 * h;
-    fb = frag + ((1 * 2) * GT + 32 * wn + r32) * 8 + 4 * h;
+    for (int i = 0; i < 2; ++i) fa[i] = frag + (0 * 2) * GT * 8 + frag_pos(64 * wm + 32 * i + r32, h);
+    fb = frag + (1 * 2) * GT * 8 + frag_pos(32 * wn + r32, h);
     f32x16_t acx[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -822,7 +828,7 @@ __global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu
 constexpr int TW_DST = 3, TW_UNITS = 4;                                       // ring depth; 128-column operand blocks per K-step (2 of dY + 2 of X)
 constexpr int TW_STAGE_FLOATS = TW_UNITS * DTILE;                              // 8192 floats = 32 KB
 constexpr int TW_RING_FLOATS = TW_DST * TW_STAGE_FLOATS;
-constexpr int TW_FRAG_DWORDS = TW_UNITS * 2 * GT * 8;                          // [block][hi | lo][column][8 dwords = 16 bf16]: 32 KB, two of them
+constexpr int TW_FRAG_DWORDS = TW_UNITS * 2 * GT * 8;                          // [block][hi | lo][frag_pos(column, h)]: 32 KB, two of them
 constexpr int TW_LDS_BYTES = (TW_RING_FLOATS + 2 * TW_FRAG_DWORDS) * 4;
 static_assert(TW_LDS_BYTES == 163840, "one workgroup per CU: all 160 KB of it");
 
@@ -876,7 +882,7 @@ __device__ __forceinline__ void tn_block256(float *tn_lds, int M, int N, const f
         for (int k = 0; k < 8; ++k) x[k] = col[k * GT + ((k & 1) ? spos1 : spos0)];
         u32x4_t hi, lo;
         split8(x, hi, lo);
-        uint32_t *fdst = frag + (t & 1) * TW_FRAG_DWORDS + (((2 * r + sb) * 2) * GT + scol) * 8 + 4 * skh;
+        uint32_t *fdst = frag + (t & 1) * TW_FRAG_DWORDS + ((2 * r + sb) * 2) * GT * 8 + frag_pos(scol, skh);
         *reinterpret_cast<u32x4_t *>(fdst) = hi;
         *reinterpret_cast<u32x4_t *>(fdst + GT * 8) = lo;
         if (r == 0 && rowsum != nullptr) {
@@ -887,9 +893,9 @@ __device__ __forceinline__ void tn_block256(float *tn_lds, int M, int N, const f
     // MFMA: wave (wm, wn) owns rows 64 wm .. + 63 (dY block wm >> 1), columns 128 wn .. + 127 (X block wn)
     int fa[2], fb[4];      // dword offsets inside a fragment buffer
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fa[i] = (((wm >> 1) * 2) * GT + (64 * (wm & 1) + 32 * i + r32)) * 8 + 4 * h;
+    for (int i = 0; i < 2; ++i) fa[i] = ((wm >> 1) * 2) * GT * 8 + frag_pos(64 * (wm & 1) + 32 * i + r32, h);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fb[j] = (((2 + wn) * 2) * GT + (32 * j + r32)) * 8 + 4 * h;
+    for (int j = 0; j < 4; ++j) fb[j] = ((2 + wn) * 2) * GT * 8 + frag_pos(32 * j + r32, h);
     f32x16_t acx[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
