@@ -138,6 +138,10 @@ struct SaveAct {
             f32x4 v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = *(lds_f4_t)(uintptr_t)(sc.rd + i * 8 * SAVE_ROW_BYTES);
+#if defined(SAHS_DIAG) && defined(SAHS_X3_NOREADBACK)      // timing-only (results wrong by construction): the stores without waiting for the read-back
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = f32x4{r[0], r[1], r[2], r[3]};
+#endif
 #if defined(SAHS_DIAG) && defined(SAHS_X3_SAVE_PLAIN)      // A/B: default cache policy instead of non-temporal
 #pragma unroll
             for (int i = 0; i < 4; ++i)

@@ -666,7 +666,11 @@ __device__ __forceinline__ void tn_tile(float *tn_lds, int M, int N, const float
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const float *g = (colok[u] && k0 + krow[u] < k_hi) ? src[u] + (long)t * step[u] : zero;
+#if defined(SAHS_DIAG) && defined(SAHS_TN_NODMA)      // timing-only (results wrong by construction): the K loop without its operand fetch
+            asm volatile("" :: "v"(g), "v"(dstb));
+#else
             __builtin_amdgcn_global_load_lds((gbl_void_t)g, (lds_void_t)(dstb + u * 256), 16, 0, 0);
+#endif
         }
     };
     // split phase: this thread's column of its operand tile, at its two swizzle positions (even / odd sample rows)
@@ -868,7 +872,11 @@ __device__ __forceinline__ void tn_block256(float *tn_lds, int M, int N, const f
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float *g = (colok[u] && k0 + krow[u] < k_hi) ? src[u] + (long)t * step[u] : zero;
+#if defined(SAHS_DIAG) && defined(SAHS_TN_NODMA)      // timing-only (results wrong by construction): the K loop without its operand fetch
+            asm volatile("" :: "v"(g), "v"(dstb));
+#else
             __builtin_amdgcn_global_load_lds((gbl_void_t)g, (lds_void_t)(dstb + u * 256), 16, 0, 0);
+#endif
         }
     };
     // split, two rounds per K-step: round r, thread -> block 2 r + (tid >> 8), samples 8 skh .. 8 skh + 7 of column scol (round 0: the dY blocks)

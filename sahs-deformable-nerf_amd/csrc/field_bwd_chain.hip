@@ -237,6 +237,10 @@ struct BwdEp {
                 f32x4 v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = *(lds_f4_t)(uintptr_t)(sc.rd + i * 8 * STAGE_ROW_BYTES);
+#if defined(SAHS_DIAG) && defined(SAHS_X3_NOREADBACK)      // timing-only (results wrong by construction): the stores without waiting for the read-back
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = f32x4{r[0], r[1], r[2], r[3]};
+#endif
 #if defined(SAHS_DIAG) && defined(SAHS_BWC_NOGSTORE)      // timing-only: the staging round trip without the global stores
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(v[i]));
