@@ -936,11 +936,19 @@ __device__ __forceinline__ void tn_block256(float *tn_lds, int M, int N, const f
             ah[i] = *reinterpret_cast<const u32x4_t *>(fr + fa[i]);
             al[i] = *reinterpret_cast<const u32x4_t *>(fr + fa[i] + GT * 8);
         }
+        // every fragment of the K-step is requested before the first MFMA (the compiler otherwise reads a column block's pair right in front of
+        // its six MFMAs and waits: four exposed LDS round trips per K-step with two waves per SIMD to cover them)
+        u32x4_t bh[4], bl[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const u32x4_t bh = *reinterpret_cast<const u32x4_t *>(fr + fb[j]), bl = *reinterpret_cast<const u32x4_t *>(fr + fb[j] + GT * 8);
+            bh[j] = *reinterpret_cast<const u32x4_t *>(fr + fb[j]);
+            bl[j] = *reinterpret_cast<const u32x4_t *>(fr + fb[j] + GT * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acx[i][j] = mfma3(ah[i], al[i], bh, bl, acx[i][j]);
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acx[i][j] = mfma3(ah[i], al[i], bh[j], bl[j], acx[i][j]);
             if (t + 1 < T && (j & 1) == 0) split_round(t + 1, j >> 1);      // beside the MFMAs: the next K-step's fragments
         }
     }
