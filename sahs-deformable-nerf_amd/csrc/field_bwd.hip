@@ -1024,37 +1024,82 @@ __device__ __forceinline__ void pe_grad(const float *enc, const float *denc, flo
 constexpr int DIN_LD = 16 * (KB_XYZ + KB_AMB);   // row of the gradient wrt [PE(x') blocks | PE(w) blocks]: 96 | 128 | 64
 constexpr int DIN_AMB = 16 * KB_XYZ;             // where the PE(w) part starts
 
+// one coordinate's gradient through its encoding (pe_grad, one axis)
+template <int D, int L, int INC>
+__device__ __forceinline__ float pe_grad_axis(const float *enc, const float *denc, int a)
+{
+    constexpr int D0 = INC ? D : 0;
+    float g = INC ? denc[a] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const int si = D0 + 2 * D * k + a, ci = si + D;
+        g += (float)(1 << k) * (denc[si] * enc[ci] - denc[ci] * enc[si]);
+    }
+    return g;
+}
+
 // Per sample: d_in [P x DIN_LD] = gradient wrt [PE(x') blocks | PE(w) blocks] (d_in2, optional: a second contribution, added).  d_xw [P x 4] +=
 // dL/dx' through PE63 (the trilinear part was written by grid_backward_kernel), d_w [P x 4] = dL/dw; seam8 (optional): the same as (P,8) rows
 // [dx'0 dx'1 dx'2 0 | dw0 dw1 0 0], the form in which the seam gradient leaves the radiance part of a split walk.
+// A workgroup takes 64 samples at a time: their gradient rows and saved encodings (contiguous blocks of the planes) come in as coalesced
+// 16-byte loads and are parked in LDS; then four threads per sample -- one per coordinate of x', one for w -- walk the octaves.  (Round 4,
+// first form: one thread per sample reading its own 384-byte rows, a line per lane and load: 1.5 TB/s of useful bytes, 270 us per step.)
+constexpr int EB_SAMPLES = 64, EB_ROW = DIN_LD + 1;      // LDS row stride (floats): odd, the four threads of a sample and the samples spread over the banks
 __global__ void __launch_bounds__(256) encode_backward_kernel(long P, const float *__restrict__ actbuf, const float *__restrict__ d_in,
                                                               const float *__restrict__ d_in2, float *__restrict__ d_xw, float *__restrict__ d_w,
                                                               float *__restrict__ seam8)
 {
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
-        float gx[3], gw[2];
-        float din[DIN_LD];
-#pragma unroll
-        for (int i = 0; i < DIN_LD / 4; ++i) {
-            f32x4 v = *reinterpret_cast<const f32x4 *>(d_in + p * DIN_LD + 4 * i);
+    __shared__ float s_din[EB_SAMPLES * EB_ROW], s_enc[EB_SAMPLES * EB_ROW];
+    const int tid = threadIdx.x, sl = tid >> 2, r = tid & 3;
+    const long nblk = (P + EB_SAMPLES - 1) / EB_SAMPLES;
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const long p0 = blk * EB_SAMPLES;
+        const int nv = (int)((P - p0 < EB_SAMPLES) ? P - p0 : EB_SAMPLES);
+        __syncthreads();      // (the previous block's readers are done)
+        for (int i = tid; i < nv * (DIN_LD / 4); i += 256) {
+            const int row = i / (DIN_LD / 4), c4 = i - row * (DIN_LD / 4);
+            f32x4 v = *reinterpret_cast<const f32x4 *>(d_in + p0 * DIN_LD + 4 * (long)i);
             if (d_in2 != nullptr) {
-                const f32x4 u = *reinterpret_cast<const f32x4 *>(d_in2 + p * DIN_LD + 4 * i);
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(d_in2 + p0 * DIN_LD + 4 * (long)i);
                 v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
             }
-            din[4 * i] = v[0]; din[4 * i + 1] = v[1]; din[4 * i + 2] = v[2]; din[4 * i + 3] = v[3];
+            float *d = s_din + row * EB_ROW + 4 * c4;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
-        pe_grad<3, L_XYZ, 1>(actbuf + (long)act::PEX * P + p * (16 * KB_XYZ), din, gx);
-        gw[0] = 0.0f; gw[1] = 0.0f;
+        for (int i = tid; i < nv * (4 * KB_XYZ); i += 256) {
+            const int row = i / (4 * KB_XYZ), c4 = i - row * (4 * KB_XYZ);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(actbuf + (long)act::PEX * P + p0 * (16 * KB_XYZ) + 4 * (long)i);
+            float *d = s_enc + row * EB_ROW + 4 * c4;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
 #if SAHS_MODEL != 2
-        pe_grad<AMB_DIM, L_AMB, AMB_INC>(actbuf + (long)act::PEW * P + p * (16 * KB_AMB), din + DIN_AMB, gw);
+        for (int i = tid; i < nv * (4 * KB_AMB); i += 256) {
+            const int row = i / (4 * KB_AMB), c4 = i - row * (4 * KB_AMB);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(actbuf + (long)act::PEW * P + p0 * (16 * KB_AMB) + 4 * (long)i);
+            float *d = s_enc + row * EB_ROW + DIN_AMB + 4 * c4;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
 #endif
-        f32x4 t = *reinterpret_cast<const f32x4 *>(d_xw + p * 4);
-        t[0] += gx[0]; t[1] += gx[1]; t[2] += gx[2];
-        *reinterpret_cast<f32x4 *>(d_xw + p * 4) = t;
-        *reinterpret_cast<f32x4 *>(d_w + p * 4) = f32x4{gw[0], gw[1], 0.0f, 0.0f};
-        if (seam8 != nullptr) {
-            *reinterpret_cast<f32x4 *>(seam8 + p * 8) = f32x4{t[0], t[1], t[2], t[3]};
-            *reinterpret_cast<f32x4 *>(seam8 + p * 8 + 4) = f32x4{gw[0], gw[1], 0.0f, 0.0f};
+        __syncthreads();
+        if (sl < nv) {
+            const long p = p0 + sl;
+            const float *enc = s_enc + sl * EB_ROW, *din = s_din + sl * EB_ROW;
+            if (r < 3) {
+                const float t = d_xw[p * 4 + r] + pe_grad_axis<3, L_XYZ, 1>(enc, din, r);
+                d_xw[p * 4 + r] = t;
+                if (seam8 != nullptr) seam8[p * 8 + r] = t;
+            } else {
+                float gw[2] = {0.0f, 0.0f};
+#if SAHS_MODEL != 2
+#pragma unroll
+                for (int a = 0; a < AMB_DIM; ++a) gw[a] = pe_grad_axis<AMB_DIM, L_AMB, AMB_INC>(enc + DIN_AMB, din + DIN_AMB, a);
+#endif
+                *reinterpret_cast<f32x4 *>(d_w + p * 4) = f32x4{gw[0], gw[1], 0.0f, 0.0f};
+                if (seam8 != nullptr) {
+                    seam8[p * 8 + 3] = d_xw[p * 4 + 3];
+                    *reinterpret_cast<f32x4 *>(seam8 + p * 8 + 4) = f32x4{gw[0], gw[1], 0.0f, 0.0f};
+                }
+            }
         }
     }
 }
