@@ -20,7 +20,7 @@ for f in sorted(glob.glob("gpurun_out/pmc_train_sq/p*/**/*counter_collection.csv
     for r in [r for r in rows if cond[-2] < int(r["Dispatch_Id"]) <= cond[-1]]:
         n=r["Kernel_Name"]
         k=("tn_jobs256" if "jobs256" in n else "tn_jobs" if "tn_jobs" in n else "chain_rad" if "chain_rad" in n else "chain_def" if "chain_def" in n else
-           "fwd_radiance" if "radiance_bf16x3" in n else "fwd_deform" if "deform_bf16x3" in n else "fwd_f32" if "field_forward_f32" in n else None)
+           "grid_bwd" if "grid_backward" in n else "encode_bwd" if "encode_backward" in n else "fwd_radiance" if "radiance_bf16x3" in n else "fwd_deform" if "deform_bf16x3" in n else "fwd_f32" if "field_forward_f32" in n else None)
         if k is None: continue
         d=agg.setdefault(k, collections.OrderedDict())
         d[r["Counter_Name"]]=d.get(r["Counter_Name"],0.0)+float(r["Counter_Value"])
