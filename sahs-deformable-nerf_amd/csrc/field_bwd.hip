@@ -1044,12 +1044,12 @@ __device__ __forceinline__ float pe_grad_axis(const float *enc, const float *den
 // A workgroup takes 64 samples at a time: their gradient rows and saved encodings (contiguous blocks of the planes) come in as coalesced
 // 16-byte loads and are parked in LDS; then four threads per sample -- one per coordinate of x', one for w -- walk the octaves.  (Round 4,
 // first form: one thread per sample reading its own 384-byte rows, a line per lane and load: 1.5 TB/s of useful bytes, 270 us per step.)
-constexpr int EB_SAMPLES = 64, EB_ROW = DIN_LD + 1;      // LDS row stride (floats): odd, the four threads of a sample and the samples spread over the banks
+constexpr int EB_SAMPLES = 64, EB_ROW = DIN_LD + 4;      // LDS row stride (floats): 16-byte aligned rows, the four threads of a sample on four banks of their own
 __global__ void __launch_bounds__(256) encode_backward_kernel(long P, const float *__restrict__ actbuf, const float *__restrict__ d_in,
                                                               const float *__restrict__ d_in2, float *__restrict__ d_xw, float *__restrict__ d_w,
                                                               float *__restrict__ seam8)
 {
-    __shared__ float s_din[EB_SAMPLES * EB_ROW], s_enc[EB_SAMPLES * EB_ROW];
+    __shared__ __attribute__((aligned(16))) float s_din[EB_SAMPLES * EB_ROW], s_enc[EB_SAMPLES * EB_ROW];
     const int tid = threadIdx.x, sl = tid >> 2, r = tid & 3;
     const long nblk = (P + EB_SAMPLES - 1) / EB_SAMPLES;
     for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -1063,21 +1063,18 @@ __global__ void __launch_bounds__(256) encode_backward_kernel(long P, const floa
                 const f32x4 u = *reinterpret_cast<const f32x4 *>(d_in2 + p0 * DIN_LD + 4 * (long)i);
                 v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
             }
-            float *d = s_din + row * EB_ROW + 4 * c4;
-            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            *reinterpret_cast<f32x4 *>(s_din + row * EB_ROW + 4 * c4) = v;
         }
         for (int i = tid; i < nv * (4 * KB_XYZ); i += 256) {
             const int row = i / (4 * KB_XYZ), c4 = i - row * (4 * KB_XYZ);
             const f32x4 v = *reinterpret_cast<const f32x4 *>(actbuf + (long)act::PEX * P + p0 * (16 * KB_XYZ) + 4 * (long)i);
-            float *d = s_enc + row * EB_ROW + 4 * c4;
-            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            *reinterpret_cast<f32x4 *>(s_enc + row * EB_ROW + 4 * c4) = v;
         }
 #if SAHS_MODEL != 2
         for (int i = tid; i < nv * (4 * KB_AMB); i += 256) {
             const int row = i / (4 * KB_AMB), c4 = i - row * (4 * KB_AMB);
             const f32x4 v = *reinterpret_cast<const f32x4 *>(actbuf + (long)act::PEW * P + p0 * (16 * KB_AMB) + 4 * (long)i);
-            float *d = s_enc + row * EB_ROW + DIN_AMB + 4 * c4;
-            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            *reinterpret_cast<f32x4 *>(s_enc + row * EB_ROW + DIN_AMB + 4 * c4) = v;
         }
 #endif
         __syncthreads();
