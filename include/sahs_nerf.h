@@ -257,10 +257,10 @@ int sahs_route_xw_grad(long N, int Sc, int nf, const int32_t *src, const float *
  * Process-wide; enable < 0 queries; SAHS_BF16_EXACT_LEAKY=1 in the environment selects it at first use.  Returns the state in force. */
 int sahs_bf16_exact_leaky(int enable);
 
-/* The fused backward walk (round 4; SAHS_MODEL_AUDIO, split-operand arithmetic = sahs_backward_gemm_precision SAHS_BF16X3).  Replaces the
- * ~38 GEMM launches sahs_model_field_backward_split makes per part -- autograd of modules.py:254-295 (NeRFMLP), :371-390 (WarpFieldMLP),
- * :444-462 (HyperSheetMLP) as driven by train_stage_rays_auto.py:437-499 -- by two: one sample-major data-gradient chain and one
- * weight-gradient launch over a job table.  The (leaky-)ReLU masks come from SIGN BITS the saving forward writes beside the activations:
+/* The fused backward walk (round 4; SAHS_MODEL_AUDIO; in the arithmetic sahs_backward_gemm_precision names: split-bf16 operands,
+ * SAHS_BF16X3, or exact fp32 products, SAHS_F32 -- the reference's).  Replaces the ~38 GEMM launches sahs_model_field_backward_split makes
+ * per part -- autograd of modules.py:254-295 (NeRFMLP), :371-390 (WarpFieldMLP), :444-462 (HyperSheetMLP) as driven by
+ * train_stage_rays_auto.py:437-499 -- by two or three: one sample-major data-gradient chain and the weight gradients over job tables.  The (leaky-)ReLU masks come from SIGN BITS the saving forward writes beside the activations:
  * sahs_model_field_forward_split_save_bits = sahs_model_field_forward_split_save that also fills bits_out, N*S*sahs_model_bits_words_part(
  * model, mode) 32-bit words (mode 0: [deformation planes | radiance planes]).  sahs_model_field_backward_fused takes the same arguments as
  * sahs_model_field_backward_split plus bits_in (the planes of `part`; part 3: both, as written by a mode-0 save); workspace:

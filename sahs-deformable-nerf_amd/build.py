@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsahs_nerf.so")
-SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "spade_ops.hip", "field_f32.hip", "field_bf16w.hip", "field_bf16x3.hip", "field_bwd.hip", "field_bwd_chain.hip", "train_bwd.hip"]
+SOURCES = ["capi.hip", "pack.hip", "render_ops.hip", "spade_ops.hip", "field_f32.hip", "field_bf16w.hip", "field_bf16x3.hip", "field_bwd.hip", "field_bwd_chain.hip", "field_bwd_chain_f32.hip", "train_bwd.hip"]
 # sources built again for the NeRFaceModel architectures (csrc/sahs_model.hpp: -DSAHS_MODEL=1 / 2, symbols suffixed _nf / _ns)
 MODEL_SOURCES = ["pack.hip", "field_f32.hip", "field_bwd.hip"]
 NERFACE_DEFORM_SOURCES = ["field_bf16x3.hip"]      # NeRFaceModel WITH deformation nets (SAHS_MODEL=1): their split-operand kernel (mixed precision)
@@ -26,7 +26,9 @@ FIELD_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
 # weight prefetch); its activation-saving and NeRFace builds do spill a little (build/<library>.resource_usage.txt).
 NO_SCRATCH = {"gemm_dma_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb0E": 0, "field_forward_bf16w_kernel": 0,
               "field_radiance_bf16x3_kernel": 0, "field_deform_bf16x3_kernel": 0, "gemm_tn_split_kernel": 0, "gemm_tn_jobs_kernel": 0,
-              "field_backward_chain_rad_kernel": 0, "field_backward_chain_def_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb1E": 0}
+              "field_backward_chain_rad_kernel": 0, "field_backward_chain_def_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb1E": 0,
+              "gemm_tn_jobs_f32_kernel": 0, "gemm_tn_jobs256_f32_kernel": 0,
+              "field_backward_chain_rad_f32_kernel": 0, "field_backward_chain_def_f32_kernel": 0}
 # Kernels with hand-issued `asm volatile ds_read_b128` + counted waits (csrc/bf16_pipe.hpp): (source, SAHS_MODEL, kernel name pattern).
 # Every build compiles these to ISA as well and runs tools/check_lds_inflight.py on it: an object in which anything touches a read's
 # destination before the wait that retires it is never linked.

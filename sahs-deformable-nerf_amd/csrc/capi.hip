@@ -811,7 +811,6 @@ int sahs_model_field_backward_fused(int model, const float *flat_params, const f
             "sahs_model_field_backward_fused(d_raw for the radiance part, xw_grad_in for the deformation part alone, xw_grad_out for the radiance part alone)");
     REQUIRE(ALIGNED16(act_in) && ALIGNED16(bits_in) && ALIGNED16(workspace) && (!d_raw || ALIGNED16(d_raw)) && (!xw_grad_in || ALIGNED16(xw_grad_in)) &&
             (!xw_grad_out || ALIGNED16(xw_grad_out)), "sahs_model_field_backward_fused(alignment)");
-    REQUIRE(sahs_bwd_gemm_precision_state(-1) != 0, "sahs_model_field_backward_fused(split-operand arithmetic only: sahs_backward_gemm_precision is SAHS_F32)");
     if (P == 0) return 0;
     const float *base = act_in - act_col0(model, part) * P;
     int e = sahs_field_backward_fused_launch(flat_params, frame, level, part, P, base, bits_in, d_raw, xw_grad_in, xw_grad_out, grad_flat, grad_cond,

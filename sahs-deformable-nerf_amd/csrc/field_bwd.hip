@@ -982,6 +982,234 @@ __global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same two job-table launches in exact fp32 products (ops.backward_gemm_precision("fp32"): the reference's arithmetic), on
+// v_mfma_f32_16x16x4_f32.  Same operand tiles ([16 k][128 cols] K-major, XOR-swizzled on odd rows) brought in by the same LDS-DMA ring; no
+// split phase: the MFMA lanes read their operands straight from the ring (lane (q, c16): sample 4 s4 + q, column 16 i + c16 -- ds_read_b32,
+// conflict-free under the swizzle), four samples per MFMA.  Bound: the f32 matrix pipe -- a 256 x 256 block is 128 MFMAs per wave and K-step
+// (4096 cycles) against 32 KB of operands -- not HBM.  Ring of four K-steps.
+constexpr int TF_DST = 4;
+constexpr int TF_LDS_BYTES = TF_DST * 2 * DTILE * 4;                           // 64 KB: two workgroups per CU
+constexpr int TFW_LDS_BYTES = TF_DST * TW_STAGE_FLOATS * 4;                    // 128 KB: one workgroup per CU
+__device__ __forceinline__ int swz_col(int col, int odd) { return (((col >> 2) ^ (odd << 2)) << 2) + (col & 3); }
+
+// One 128 x 128 tile of C += A^T B over the samples [k_lo, k_hi): wave (wm, wn) of eight owns rows 64 wm .., columns 32 wn ...
+__device__ __forceinline__ void tn_tile_f32(float *ring, int M, int N, const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
+                                            float *__restrict__ C, long ldc, long k_lo, long k_hi, float *__restrict__ rowsum, int bx, int by,
+                                            const float *__restrict__ zero)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3, h = lane >> 5, c32 = lane & 31, q = lane >> 4, c16 = lane & 15;
+    const long m0 = (long)by * GT;
+    const int n0 = bx * GT;
+    const int T = (int)((k_hi - k_lo + GK - 1) / GK);
+    const bool do_sum = rowsum != nullptr && bx == 0;
+    // DMA as in tn_tile: waves 0..3 move the dY tile, waves 4..7 the X tile, two instructions per wave and K-step
+    const float *src[2]; long step[2]; int krow[2]; bool colok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int rp = (wave & 3) * 2 + u;
+        const float *base = (wave < 4) ? A : B;
+        const long ld = (wave < 4) ? lda : ldb;
+        const long c0 = (wave < 4) ? m0 : n0;
+        const int dim = (wave < 4) ? M : N;
+        const int row = 2 * rp + h;
+        const int j = c32 ^ ((row & 1) << 2);
+        src[u] = base + (k_lo + row) * ld + c0 + 4 * j;
+        step[u] = GK * ld;
+        krow[u] = row;
+        colok[u] = c0 + 4 * j < dim;
+    }
+    const int dst_off = ((wave < 4) ? 0 : DTILE) + (wave & 3) * 2 * 256;
+    auto issue = [&](int t) {
+        float *dstb = ring + (t % TF_DST) * 2 * DTILE + dst_off;
+        const long k0 = k_lo + (long)t * GK;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float *g = (colok[u] && k0 + krow[u] < k_hi) ? src[u] + (long)t * step[u] : zero;
+            __builtin_amdgcn_global_load_lds((gbl_void_t)g, (lds_void_t)(dstb + u * 256), 16, 0, 0);
+        }
+    };
+    int colA[4], colB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) colA[i] = swz_col(64 * wm + 16 * i + c16, q & 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) colB[j] = DTILE + swz_col(32 * wn + 16 * j + c16, q & 1);
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float cs = 0.0f;
+    // vmcnt accounting as in tn_tile: the wave's only loads are its 2 LDS-DMA instructions per issue(), completing in issue order
+    if (T > 0) issue(0);
+    if (T > 1) issue(1);
+    if (T > 2) issue(2);
+    for (int t = 0; t < T; ++t) {
+        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + TF_DST - 1 < T) issue(t + TF_DST - 1);        // into the stage every wave finished reading before the barrier above
+        const float *stage = ring + (t % TF_DST) * 2 * DTILE;
+#pragma unroll
+        for (int s4 = 0; s4 < GK / 4; ++s4) {
+            float a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = stage[(4 * s4 + q) * GT + colA[i]];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = stage[(4 * s4 + q) * GT + colB[j]];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (do_sum && tid < GT) {
+#pragma unroll
+            for (int k = 0; k < GK; ++k) cs += stage[k * GT + swz_col(tid, k & 1)];
+        }
+    }
+    // accumulator (i, j) register r: row 64 wm + 16 i + 4 q + r, column 32 wn + 16 j + c16
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 32 * wn + 16 * j + c16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long m = m0 + 64 * wm + 16 * i + 4 * q + r;
+                if (m < M && n < N && ldc > 0) atomicAdd(C + m * ldc + n, acc[i][j][r]);
+            }
+        }
+    if (do_sum && tid < GT && m0 + tid < M) atomicAdd(rowsum + m0 + tid, cs);
+    __syncthreads();      // the ring is free (this item's DMA has drained) before the next item issues into it
+}
+
+__global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) gemm_tn_jobs_f32_kernel(TnBatch jobs, int njobs, int tiles_total, long P, long range,
+                                                                                                                 const float *__restrict__ zero)
+{
+    extern __shared__ __attribute__((aligned(16))) float tn_lds[];
+    const int G = gridDim.x;                                                  // a multiple of 8
+    const int vid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);          // consecutive virtual ids = consecutive slots of one XCD
+    const long nrange = (P + range - 1) / range;
+    const long items = nrange * tiles_total;
+    for (long it = vid; it < items; it += G) {
+        const long r = it / tiles_total;
+        int tg = (int)(it - r * tiles_total), j = 0;
+        for (; j < njobs - 1; ++j) {
+            const int tj = ((jobs.j[j].N + GT - 1) / GT) * ((jobs.j[j].M + GT - 1) / GT);
+            if (tg < tj) break;
+            tg -= tj;
+        }
+        const TnJob &J = jobs.j[j];
+        const int nx = (J.N + GT - 1) / GT;
+        const long k_lo = r * range, k_hi = (k_lo + range < P) ? k_lo + range : P;
+        tn_tile_f32(tn_lds, J.M, J.N, J.A, J.lda, J.B, J.ldb, J.C, J.ldc, k_lo, k_hi, J.rowsum, tg % nx, tg / nx, zero);
+    }
+}
+
+// One whole 256 x 256 block: wave (wm, wn) of eight owns rows 64 wm .. (dY block wm >> 1), columns 128 wn .. (X block wn): 4 x 8 accumulators
+__device__ __forceinline__ void tn_block256_f32(float *ring, int M, int N, const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
+                                                float *__restrict__ C, long ldc, long k_lo, long k_hi, float *__restrict__ rowsum,
+                                                const float *__restrict__ zero)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, h = lane >> 5, c32 = lane & 31, q = lane >> 4, c16 = lane & 15;
+    const int T = (int)((k_hi - k_lo + GK - 1) / GK);
+    // DMA as in tn_block256: 32 one-KB units per K-step (block b, row pair rp); wave w moves row pairs 4 (w & 1) .. of block w >> 1
+    const float *src[4]; long step[4]; int krow[4]; bool colok[4];
+    const int blk = wave >> 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int rp = (wave & 1) * 4 + u;
+        const float *base = (blk < 2) ? A : B;
+        const long ld = (blk < 2) ? lda : ldb;
+        const int c0 = (blk & 1) * GT;
+        const int dim = (blk < 2) ? M : N;
+        const int row = 2 * rp + h;
+        const int j = c32 ^ ((row & 1) << 2);
+        src[u] = base + (k_lo + row) * ld + c0 + 4 * j;
+        step[u] = GK * ld;
+        krow[u] = row;
+        colok[u] = c0 + 4 * j < dim;
+    }
+    const int dst_off = blk * DTILE + (wave & 1) * 4 * 256;
+    auto issue = [&](int t) {
+        float *dstb = ring + (t % TF_DST) * TW_STAGE_FLOATS + dst_off;
+        const long k0 = k_lo + (long)t * GK;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float *g = (colok[u] && k0 + krow[u] < k_hi) ? src[u] + (long)t * step[u] : zero;
+            __builtin_amdgcn_global_load_lds((gbl_void_t)g, (lds_void_t)(dstb + u * 256), 16, 0, 0);
+        }
+    };
+    int colA[4], colB[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) colA[i] = (wm >> 1) * DTILE + swz_col(64 * (wm & 1) + 16 * i + c16, q & 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) colB[j] = (2 + wn) * DTILE + swz_col(16 * j + c16, q & 1);
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float cs = 0.0f;
+    const int scol = (tid >> 7) * DTILE, sc = tid & 127;      // bias gradient: thread tid < 256 sums column tid of dY
+    // vmcnt accounting: this wave's loads are its 4 LDS-DMA instructions per issue(), in issue order; anything older still in flight (a
+    // previous item's atomics) can only make a counted wait stricter
+    if (T > 0) issue(0);
+    if (T > 1) issue(1);
+    if (T > 2) issue(2);
+    for (int t = 0; t < T; ++t) {
+        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + TF_DST - 1 < T) issue(t + TF_DST - 1);
+        const float *stage = ring + (t % TF_DST) * TW_STAGE_FLOATS;
+#pragma unroll
+        for (int s4 = 0; s4 < GK / 4; ++s4) {
+            float a[4], b[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = stage[(4 * s4 + q) * GT + colA[i]];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = stage[(4 * s4 + q) * GT + colB[j]];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (rowsum != nullptr && tid < 2 * GT) {
+#pragma unroll
+            for (int k = 0; k < GK; ++k) cs += stage[scol + k * GT + swz_col(sc, k & 1)];
+        }
+    }
+    // accumulator (i, j) register r: row 64 wm + 16 i + 4 q + r, column 128 wn + 16 j + c16
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = 128 * wn + 16 * j + c16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 64 * wm + 16 * i + 4 * q + r;
+                if (m < M && n < N) atomicAdd(C + (long)m * ldc + n, acc[i][j][r]);
+            }
+        }
+    if (rowsum != nullptr && tid < 2 * GT && tid < M) atomicAdd(rowsum + tid, cs);
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_tn_jobs256_f32_kernel(TnBatch jobs, int njobs, long P, long range,
+                                                                                                                   const float *__restrict__ zero)
+{
+    extern __shared__ __attribute__((aligned(16))) float tn_lds[];
+    const long nrange = (P + range - 1) / range;
+    const long items = nrange * njobs;                                        // item = (range r, job): the jobs of one range side by side
+    for (long it = blockIdx.x; it < items; it += gridDim.x) {
+        const long r = it / njobs;
+        const TnJob &J = jobs.j[(int)(it - r * njobs)];
+        const long k_lo = r * range, k_hi = (k_lo + range < P) ? k_lo + range : P;
+        tn_block256_f32(tn_lds, J.M, J.N, J.A, J.lda, J.B, J.ldb, J.C, J.ldc, k_lo, k_hi, J.rowsum, zero);
+    }
+}
+
 // dst[m*ldd + n] (op)= src[m*lds + n] for n < N   (mode 0 copy, 1 add)
 __global__ void copy2d_kernel(long M, int N, const float *__restrict__ src, long lds_, float *__restrict__ dst, long ldd, int mode)
 {
@@ -1781,13 +2009,22 @@ int sahs_bwd_chain_rad_launch(const void *bstream, long P, const float *d_raw, c
                               float *din_b, int num_cu, hipStream_t stream);
 int sahs_bwd_chain_def_launch(const void *bstream, long P, const float *xwg, const float *actbuf, const uint32_t *bits, float *dact, float *g3,
                               float *dw4, int num_cu, hipStream_t stream);
+// field_bwd_chain_f32.hip: the same chains in exact fp32 products
+long sahs_bwd_chain_f32_stream_floats(int part);
+int sahs_bwd_chain_f32_pack_launch(const float *flat, float *stream_out, int level, int part, hipStream_t stream);
+int sahs_bwd_chain_f32_rad_launch(const float *bstream, long P, const float *d_raw, const uint32_t *bits, float *dact, float *dgridf, float *din_a,
+                                  float *din_b, int num_cu, hipStream_t stream);
+int sahs_bwd_chain_f32_def_launch(const float *bstream, long P, const float *xwg, const float *actbuf, const uint32_t *bits, float *dact, float *g3,
+                                  float *dw4, int num_cu, hipStream_t stream);
 }
 
 namespace {
 constexpr long RAD_PLANES = act::STRIDE - act::XW, DEF_PLANES = act::XW;        // floats per sample of the dZ planes of a part
 struct FusedWs {      // workspace of one part, in floats
-    static long rad(long P) { return P * (RAD_PLANES + 32 + 2 * DIN_LD + 8) + DB_SCRATCH + 2 * GRID_FLOATS + sahs_bwd_chain_stream_hw(2) / 2 + HEAD_FLOATS; }
-    static long def(long P) { return P * (DEF_PLANES + 8) + DB_SCRATCH + sahs_bwd_chain_stream_hw(1) / 2; }
+    // the part's transposed weight stream: split bf16 (hi + lo halfwords) or fp32, whichever the walk's arithmetic is
+    static long stream(int part) { const long a = sahs_bwd_chain_stream_hw(part) / 2, b = sahs_bwd_chain_f32_stream_floats(part); return a > b ? a : b; }
+    static long rad(long P) { return P * (RAD_PLANES + 32 + 2 * DIN_LD + 8) + DB_SCRATCH + 2 * GRID_FLOATS + stream(2) + HEAD_FLOATS; }
+    static long def(long P) { return P * (DEF_PLANES + 8) + DB_SCRATCH + stream(1); }
 };
 
 __global__ void add_rows8_kernel(long n, const float *__restrict__ a, float *__restrict__ y)      // y[i] += a[i] over (P,8) rows, as float4s
@@ -1815,9 +2052,10 @@ struct TnList {
         ++n;
         tiles += ((N + GT - 1) / GT) * ((M + GT - 1) / GT);
     }
-    int launch(long P, const float *zero, int num_cu, hipStream_t st)
+    int launch(long P, const float *zero, int num_cu, hipStream_t st, bool f32)
     {
         if (n > MAX_TN_JOBS || nw > MAX_TN_JOBS) return (int)hipErrorOutOfMemory;
+        if (f32) return launch_f32(P, zero, num_cu, st);
         static sahs_once::Flags attr_set, attr_set_w;
         hipError_t ae = sahs_once::per_device(attr_set, [&]() {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_jobs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
@@ -1846,6 +2084,34 @@ struct TnList {
         }
         return (int)hipGetLastError();
     }
+    static long range_for(long P, long workgroups, int units, long rounds)      // (as above: equal items, `rounds` per workgroup, >= 1024 samples)
+    {
+        long nsplit = rounds * workgroups / (units > 0 ? units : 1);
+        if (nsplit < 1) nsplit = 1;
+        const long range = ((P + nsplit - 1) / nsplit + 15) / 16 * 16;
+        return range < 1024 ? 1024L : range;
+    }
+    int launch_f32(long P, const float *zero, int num_cu, hipStream_t st)
+    {
+        static sahs_once::Flags attr_set, attr_set_w;
+        hipError_t ae = sahs_once::per_device(attr_set, [&]() {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_jobs_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TF_LDS_BYTES);
+        });
+        if (ae != hipSuccess) return (int)ae;
+        ae = sahs_once::per_device(attr_set_w, [&]() {
+            return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_jobs256_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TFW_LDS_BYTES);
+        });
+        if (ae != hipSuccess) return (int)ae;
+        if (nw > 0) {
+            gemm_tn_jobs256_f32_kernel<<<num_cu, TN_THREADS, TFW_LDS_BYTES, st>>>(w, nw, P, range_for(P, num_cu, nw, 1), zero);      // one 128-KB workgroup per CU
+            if (hipGetLastError() != hipSuccess) return (int)hipErrorLaunchFailure;
+        }
+        if (n > 0) {
+            const int G = 2 * num_cu / 8 * 8;                     // two 64-KB workgroups per CU
+            gemm_tn_jobs_f32_kernel<<<G, TN_THREADS, TF_LDS_BYTES, st>>>(b, n, tiles, P, range_for(P, G, tiles, 2), zero);
+        }
+        return (int)hipGetLastError();
+    }
 };
 }  // namespace
 
@@ -1862,15 +2128,17 @@ static int fused_rad(const float *flat, const float *frame, int level, long P, c
     const FlatOffsets::Lvl &Lv = F.lvl[level];
     float *dact_mem = ws, *dgridf = dact_mem + P * RAD_PLANES, *din_a = dgridf + P * 32, *din_b = din_a + P * DIN_LD, *dxw = din_b + P * DIN_LD,
           *dw = dxw + P * 4, *db = dw + P * 4, *grid_cl = db + DB_SCRATCH, *dgrid_cl = grid_cl + GRID_FLOATS, *bstream = dgrid_cl + GRID_FLOATS,
-          *heads = bstream + sahs_bwd_chain_stream_hw(2) / 2;
+          *heads = bstream + FusedWs::stream(2);
     float *dact = dact_mem - (long)act::XW * P;              // plane of act:: column c at dact + c * P (columns >= XW are backed)
     b.zero = db + DB_SCRATCH - 64;
     if (hipMemsetAsync(db, 0, sizeof(float) * DB_SCRATCH, stream) != hipSuccess) return (int)hipGetLastError();
     if (hipMemsetAsync(dgrid_cl, 0, sizeof(float) * GRID_FLOATS, stream) != hipSuccess) return (int)hipGetLastError();
     if (hipMemsetAsync(heads, 0, sizeof(float) * HEAD_FLOATS, stream) != hipSuccess) return (int)hipGetLastError();
-    int e = sahs_bwd_chain_pack_launch(flat, bstream, level, 2, stream);
+    const bool f32 = !Bwd::x3();      // exact fp32 products (ops.backward_gemm_precision("fp32")): the fp32 chain and job kernels
+    int e = f32 ? sahs_bwd_chain_f32_pack_launch(flat, bstream, level, 2, stream) : sahs_bwd_chain_pack_launch(flat, bstream, level, 2, stream);
     if (e) return e;
-    e = sahs_bwd_chain_rad_launch(bstream, P, d_raw, bits, dact, dgridf, din_a, din_b, num_cu, stream);
+    e = f32 ? sahs_bwd_chain_f32_rad_launch(bstream, P, d_raw, bits, dact, dgridf, din_a, din_b, num_cu, stream)
+            : sahs_bwd_chain_rad_launch(bstream, P, d_raw, bits, dact, dgridf, din_a, din_b, num_cu, stream);
     if (e) return e;
     // ---- encodings + feature grid -> the seam gradient (what the deformation part waits for) ----
     {
@@ -1937,7 +2205,7 @@ static int fused_rad(const float *flat, const float *frame, int level, long P, c
         defer_consts(Lv.xyz_w[0], D_TR_IN, TR_H, D_XYZ + D_AMB, D_TR_CONST, dl, trc, d_trc);
     }
     if (b.err) return b.err;
-    e = L.launch(P, b.zero, num_cu, stream);
+    e = L.launch(P, b.zero, num_cu, stream, f32);
     if (e) return e;
     b.flush_deferred();
     return b.err;
@@ -1951,9 +2219,11 @@ static int fused_def(const float *flat, const float *frame, long P, const float 
     float *dact = ws, *g3 = dact + P * DEF_PLANES, *dw4 = g3 + P * 4, *db = dw4 + P * 4, *bstream = db + DB_SCRATCH;
     b.zero = db + DB_SCRATCH - 64;
     if (hipMemsetAsync(db, 0, sizeof(float) * DB_SCRATCH, stream) != hipSuccess) return (int)hipGetLastError();
-    int e = sahs_bwd_chain_pack_launch(flat, bstream, 0, 1, stream);
+    const bool f32 = !Bwd::x3();
+    int e = f32 ? sahs_bwd_chain_f32_pack_launch(flat, bstream, 0, 1, stream) : sahs_bwd_chain_pack_launch(flat, bstream, 0, 1, stream);
     if (e) return e;
-    e = sahs_bwd_chain_def_launch(bstream, P, xwg, actbuf, bits, dact, g3, dw4, num_cu, stream);
+    e = f32 ? sahs_bwd_chain_f32_def_launch(bstream, P, xwg, actbuf, bits, dact, g3, dw4, num_cu, stream)
+            : sahs_bwd_chain_def_launch(bstream, P, xwg, actbuf, bits, dact, g3, dw4, num_cu, stream);
     if (e) return e;
     auto AC = [&](int c) { return actbuf + (long)c * P; };
     auto DA = [&](int c) { return dact + (long)c * P; };
@@ -1992,7 +2262,7 @@ static int fused_def(const float *flat, const float *frame, long P, const float 
     net(dw4, AMB_DIM, F.hyp_fw, F.hyp_fb, F.hyp_w, F.hyp_b, HYP_H, act::HH);
     net(g3, 3, F.warp_fw, F.warp_fb, F.warp_w, F.warp_b, WARP_H, act::WH);
     if (b.err) return b.err;
-    e = L.launch(P, b.zero, num_cu, stream);
+    e = L.launch(P, b.zero, num_cu, stream, f32);
     if (e) return e;
     b.flush_deferred();
     return b.err;

@@ -441,9 +441,10 @@ def field_forward_split_save(packed, frame, level, mode, rays, xw, z=None, src=N
 
 
 def fused_backward(enable=None):
-    """The fused backward walk (one data-gradient chain launch + one weight-gradient launch per part: include/sahs_nerf.h,
-    sahs_model_field_backward_fused) is taken whenever a backward is given sign bits, the architecture has it and the backward arithmetic is
-    "bf16x3"; fused_backward(False) keeps the per-layer walk (the A/B reference).  None queries."""
+    """The fused backward walk (one data-gradient chain launch + one or two weight-gradient launches per part: include/sahs_nerf.h,
+    sahs_model_field_backward_fused) is taken whenever a backward is given sign bits and the architecture has it (AudioFaceModel), in the
+    arithmetic backward_gemm_precision() names -- split-bf16 operands or exact fp32 products; fused_backward(False) keeps the per-layer walk
+    (the A/B reference).  None queries."""
     global _FUSED_BACKWARD
     if enable is not None:
         _FUSED_BACKWARD = bool(enable)
@@ -501,7 +502,7 @@ def field_backward_split(flat, frame, level, part, act, grad_flat, grad_cond, d_
     if xw_grad_in is not None and xw_grad_in.numel() != P * 8:
         raise _lib.SahsError("field_backward_split: xw_grad_in must hold (P,8)")
     out = torch.empty(P, 8, dtype=torch.float32, device=act.device) if part == FIELD_RADIANCE else None
-    if bits is not None and _FUSED_BACKWARD and arch == "audio" and backward_gemm_precision() == "bf16x3":
+    if bits is not None and _FUSED_BACKWARD and arch == "audio":
         bits = _req(bits, "bits", torch.int32)
         bw = lambda m: int(_fn("bits_words_part", arch)[0](int(m)))
         saved_mode = 0 if (full_act or int(part) == 3) else int(part)
@@ -778,8 +779,8 @@ class RenderRaysFn(torch.autograd.Function):
         both_levels = loss_ops is not None or (any(g is not None for g in (g_rgb_f, g_disp_f, g_acc_f, g_depth_f, g_wbg)) and
                                                any(g is not None for g in (g_rgb_c, g_disp_c, g_acc_c)))
         # the fused walk is two full-chip persistent launches per part: run side by side they starve each other (measured: 14.0 ms per step on two
-        # streams, 13.3 on one), so the pairwise two-stream issue below is for the per-layer walks only (fp32 backward products, NeRFaceModels)
-        fused_walk = bits_c is not None and _FUSED_BACKWARD and ctx.arch == "audio" and backward_gemm_precision() == "bf16x3"
+        # streams, 13.3 on one), so the pairwise two-stream issue below is for the per-layer walks only (NeRFaceModels, fused_backward(False))
+        fused_walk = bits_c is not None and _FUSED_BACKWARD and ctx.arch == "audio"
         if (ctx.shared and nf > 0 and kept is not None and N <= RenderRaysFn.BLOCK_RAYS and both_levels and not fused_walk
                 and not os.environ.get("SAHS_BWD_ONE_STREAM")):
             # The two levels' radiance walks are independent of each other, and so are the two deformation walks that follow them (coarse
