@@ -993,18 +993,30 @@ constexpr int TF_LDS_BYTES = TF_DST * 2 * DTILE * 4;                           /
 constexpr int TFW_LDS_BYTES = TF_DST * TW_STAGE_FLOATS * 4;                    // 128 KB: one workgroup per CU
 __device__ __forceinline__ int swz_col(int col, int odd) { return (((col >> 2) ^ (odd << 2)) << 2) + (col & 3); }
 
-// One 128 x 128 tile of C += A^T B over the samples [k_lo, k_hi): wave (wm, wn) of eight owns rows 64 wm .., columns 32 wn ...
+// One (up to) 128 x 128 tile of C += A^T B over the samples [k_lo, k_hi).  The tile's valid part is TR x TC 16 x 16 accumulators (a head's
+// dW is 1 x 8, a 64-wide layer against PE(x) 4 x 4, a trunk layer against PE(w) 8 x 2): the eight waves are laid over it as RW x CW with
+// CW = 4, 2, 1 for TC > 4, > 2, <= 2, a wave owning up to 4 x 2 accumulators -- only the valid ones are multiplied (wave-uniform bounds),
+// and the work stays spread evenly over the four SIMDs (wave & 3).
 __device__ __forceinline__ void tn_tile_f32(float *ring, int M, int N, const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
                                             float *__restrict__ C, long ldc, long k_lo, long k_hi, float *__restrict__ rowsum, int bx, int by,
                                             const float *__restrict__ zero)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3, h = lane >> 5, c32 = lane & 31, q = lane >> 4, c16 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c32 = lane & 31, q = lane >> 4, c16 = lane & 15;
     const long m0 = (long)by * GT;
     const int n0 = bx * GT;
     const int T = (int)((k_hi - k_lo + GK - 1) / GK);
     const bool do_sum = rowsum != nullptr && bx == 0;
+    const int mt = (int)(M - m0 < GT ? M - m0 : GT), nt = N - n0 < GT ? N - n0 : GT;
+    const int TR = (mt + 15) >> 4, TC = (nt + 15) >> 4;
+    const int CW = TC > 4 ? 4 : (TC > 2 ? 2 : 1), RW = 8 / CW, RPW = (TR + RW - 1) / RW;      // RPW <= 4
+    const int wm = wave / CW, wn = wave % CW;
+    const int rt0 = wm * RPW, ct0 = 2 * wn;
+    const int ni = __builtin_amdgcn_readfirstlane(TR - rt0 < 0 ? 0 : (TR - rt0 < RPW ? TR - rt0 : RPW));
+    const int nj = __builtin_amdgcn_readfirstlane(TC - ct0 < 0 ? 0 : (TC - ct0 < 2 ? TC - ct0 : 2));
     // DMA as in tn_tile: waves 0..3 move the dY tile, waves 4..7 the X tile, two instructions per wave and K-step
-    const float *src[2]; long step[2]; int krow[2]; bool colok[2];
+    // (K-steps are issued in order: the lane's source pointers simply advance; columns past the operand's width read the zero page and stay
+    // there; rows past k_hi exist in the last K-step of a ragged range only -- a uniform test)
+    const float *cur[2]; long step[2]; int krow[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int rp = (wave & 3) * 2 + u;
@@ -1014,26 +1026,32 @@ __device__ __forceinline__ void tn_tile_f32(float *ring, int M, int N, const flo
         const int dim = (wave < 4) ? M : N;
         const int row = 2 * rp + h;
         const int j = c32 ^ ((row & 1) << 2);
-        src[u] = base + (k_lo + row) * ld + c0 + 4 * j;
-        step[u] = GK * ld;
+        const bool colok = c0 + 4 * j < dim;
+        cur[u] = colok ? base + (k_lo + row) * ld + c0 + 4 * j : zero;
+        step[u] = colok ? GK * ld : 0;
         krow[u] = row;
-        colok[u] = c0 + 4 * j < dim;
     }
     const int dst_off = ((wave < 4) ? 0 : DTILE) + (wave & 3) * 2 * 256;
     auto issue = [&](int t) {
         float *dstb = ring + (t % TF_DST) * 2 * DTILE + dst_off;
         const long k0 = k_lo + (long)t * GK;
+        const bool tail = k0 + GK > k_hi;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const float *g = (colok[u] && k0 + krow[u] < k_hi) ? src[u] + (long)t * step[u] : zero;
+            const float *g = (tail && k0 + krow[u] >= k_hi) ? zero : cur[u];
+#if defined(SAHS_DIAG) && defined(SAHS_TNF_NODMA)      // timing-only (results wrong by construction): the K loop without its operand fetch
+            asm volatile("" :: "v"(g), "v"(dstb));
+#else
             __builtin_amdgcn_global_load_lds((gbl_void_t)g, (lds_void_t)(dstb + u * 256), 16, 0, 0);
+#endif
+            cur[u] += step[u];
         }
     };
     int colA[4], colB[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) colA[i] = swz_col(64 * wm + 16 * i + c16, q & 1);
+    for (int i = 0; i < 4; ++i) colA[i] = swz_col((16 * (rt0 + i) + c16) & (GT - 1), q & 1);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) colB[j] = DTILE + swz_col(32 * wn + 16 * j + c16, q & 1);
+    for (int j = 0; j < 2; ++j) colB[j] = DTILE + swz_col((16 * (ct0 + j) + c16) & (GT - 1), q & 1);
     f32x4 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1048,61 +1066,73 @@ __device__ __forceinline__ void tn_tile_f32(float *ring, int M, int N, const flo
         if (t + 2 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t + TF_DST - 1 < T) issue(t + TF_DST - 1);        // into the stage every wave finished reading before the barrier above
         const float *stage = ring + (t % TF_DST) * 2 * DTILE;
+        // K-step t + 3 goes into the stage every wave finished reading before the barrier above -- requested behind the first quarter of
+        // this step's MFMAs, not in front of them: its address arithmetic then runs beside the matrix pipe instead of holding it up
+        if (!(ni > 0 && nj > 0) && t + TF_DST - 1 < T) issue(t + TF_DST - 1);
+        if (ni > 0 && nj > 0) {
 #pragma unroll
-        for (int s4 = 0; s4 < GK / 4; ++s4) {
-            float a[4], b[2];
+            for (int s4 = 0; s4 < GK / 4; ++s4) {
+                if (s4 == 1 && t + TF_DST - 1 < T) issue(t + TF_DST - 1);
+                float a[4], b[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = stage[(4 * s4 + q) * GT + colA[i]];
+                for (int i = 0; i < 4; ++i)
+                    if (i < ni) a[i] = stage[(4 * s4 + q) * GT + colA[i]];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = stage[(4 * s4 + q) * GT + colB[j]];
+                for (int j = 0; j < 2; ++j)
+                    if (j < nj) b[j] = stage[(4 * s4 + q) * GT + colB[j]];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j)
+                        if (i < ni && j < nj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
         if (do_sum && tid < GT) {
 #pragma unroll
             for (int k = 0; k < GK; ++k) cs += stage[k * GT + swz_col(tid, k & 1)];
         }
     }
-    // accumulator (i, j) register r: row 64 wm + 16 i + 4 q + r, column 32 wn + 16 j + c16
+    // accumulator (i, j) register r: row 16 (rt0 + i) + 4 q + r, column 16 (ct0 + j) + c16
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int n = n0 + 32 * wn + 16 * j + c16;
+            if (i < ni && j < nj) {
+                const int n = n0 + 16 * (ct0 + j) + c16;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long m = m0 + 64 * wm + 16 * i + 4 * q + r;
-                if (m < M && n < N && ldc > 0) atomicAdd(C + m * ldc + n, acc[i][j][r]);
+                for (int r = 0; r < 4; ++r) {
+                    const long m = m0 + 16 * (rt0 + i) + 4 * q + r;
+                    if (m < M && n < N && ldc > 0) atomicAdd(C + m * ldc + n, acc[i][j][r]);
+                }
             }
         }
     if (do_sum && tid < GT && m0 + tid < M) atomicAdd(rowsum + m0 + tid, cs);
     __syncthreads();      // the ring is free (this item's DMA has drained) before the next item issues into it
 }
 
-__global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) gemm_tn_jobs_f32_kernel(TnBatch jobs, int njobs, int tiles_total, long P, long range,
-                                                                                                                 const float *__restrict__ zero)
+// The item table of an fp32 job launch.  Unit = one output tile (narrow kernel) or one 256 x 256 job (wide kernel); a unit's samples are
+// cut into n ranges in proportion to what a K-step of it costs (a 16 x 128 head tile is 1/8 of the MFMAs of a 128 x 128 tile, a 128 x 256
+// layer half of a 256 x 256 one), so that items cost the same and every workgroup gets the same number of them: with equal ranges the
+// launch lasts as long as its dearest unit (measured: wide kernel 2.83 ms per 262,144 samples for 2.24 ms of matrix work in its longest item).
+struct TnUnit { unsigned short start, n; unsigned char job, bx, by, pad; };
+constexpr int MAX_TN_UNITS = 64;
+struct TnPlan { TnUnit u[MAX_TN_UNITS]; int nunits, items; };
+static_assert(sizeof(TnBatch) + sizeof(TnPlan) <= 3800, "kernel-argument budget");
+
+__global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) gemm_tn_jobs_f32_kernel(TnBatch jobs, TnPlan plan, long P, const float *__restrict__ zero)
 {
     extern __shared__ __attribute__((aligned(16))) float tn_lds[];
-    const int G = gridDim.x;                                                  // a multiple of 8
-    const int vid = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);          // consecutive virtual ids = consecutive slots of one XCD
-    const long nrange = (P + range - 1) / range;
-    const long items = nrange * tiles_total;
-    for (long it = vid; it < items; it += G) {
-        const long r = it / tiles_total;
-        int tg = (int)(it - r * tiles_total), j = 0;
-        for (; j < njobs - 1; ++j) {
-            const int tj = ((jobs.j[j].N + GT - 1) / GT) * ((jobs.j[j].M + GT - 1) / GT);
-            if (tg < tj) break;
-            tg -= tj;
-        }
-        const TnJob &J = jobs.j[j];
-        const int nx = (J.N + GT - 1) / GT;
-        const long k_lo = r * range, k_hi = (k_lo + range < P) ? k_lo + range : P;
-        tn_tile_f32(tn_lds, J.M, J.N, J.A, J.lda, J.B, J.ldb, J.C, J.ldc, k_lo, k_hi, J.rowsum, tg % nx, tg / nx, zero);
+    const int G = gridDim.x;
+    for (int it = blockIdx.x; it < plan.items; it += G) {
+        int u = 0;
+        while (u + 1 < plan.nunits && (int)plan.u[u + 1].start <= it) ++u;
+        const TnUnit U = plan.u[u];
+        const long range = ((P + U.n - 1) / U.n + 15) / 16 * 16;
+        const long k_lo = (long)(it - U.start) * range, k_hi = (k_lo + range < P) ? k_lo + range : P;
+        if (k_lo >= P) continue;
+        const TnJob &J = jobs.j[U.job];
+        tn_tile_f32(tn_lds, J.M, J.N, J.A, J.lda, J.B, J.ldb, J.C, J.ldc, k_lo, k_hi, J.rowsum, U.bx, U.by, zero);
     }
 }
 
@@ -1111,10 +1141,11 @@ __device__ __forceinline__ void tn_block256_f32(float *ring, int M, int N, const
                                                 float *__restrict__ C, long ldc, long k_lo, long k_hi, float *__restrict__ rowsum,
                                                 const float *__restrict__ zero)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, h = lane >> 5, c32 = lane & 31, q = lane >> 4, c16 = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1, h = lane >> 5, c32 = lane & 31, q = lane >> 4, c16 = lane & 15;
     const int T = (int)((k_hi - k_lo + GK - 1) / GK);
     // DMA as in tn_block256: 32 one-KB units per K-step (block b, row pair rp); wave w moves row pairs 4 (w & 1) .. of block w >> 1
-    const float *src[4]; long step[4]; int krow[4]; bool colok[4];
+    // (pointers advance per K-step as in tn_tile_f32)
+    const float *cur[4]; long step[4]; int krow[4];
     const int blk = wave >> 1;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1125,19 +1156,25 @@ __device__ __forceinline__ void tn_block256_f32(float *ring, int M, int N, const
         const int dim = (blk < 2) ? M : N;
         const int row = 2 * rp + h;
         const int j = c32 ^ ((row & 1) << 2);
-        src[u] = base + (k_lo + row) * ld + c0 + 4 * j;
-        step[u] = GK * ld;
+        const bool colok = c0 + 4 * j < dim;
+        cur[u] = colok ? base + (k_lo + row) * ld + c0 + 4 * j : zero;
+        step[u] = colok ? GK * ld : 0;
         krow[u] = row;
-        colok[u] = c0 + 4 * j < dim;
     }
     const int dst_off = blk * DTILE + (wave & 1) * 4 * 256;
     auto issue = [&](int t) {
         float *dstb = ring + (t % TF_DST) * TW_STAGE_FLOATS + dst_off;
         const long k0 = k_lo + (long)t * GK;
+        const bool tail = k0 + GK > k_hi;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float *g = (colok[u] && k0 + krow[u] < k_hi) ? src[u] + (long)t * step[u] : zero;
+            const float *g = (tail && k0 + krow[u] >= k_hi) ? zero : cur[u];
+#if defined(SAHS_DIAG) && defined(SAHS_TNF_NODMA)      // timing-only (results wrong by construction): the K loop without its operand fetch
+            asm volatile("" :: "v"(g), "v"(dstb));
+#else
             __builtin_amdgcn_global_load_lds((gbl_void_t)g, (lds_void_t)(dstb + u * 256), 16, 0, 0);
+#endif
+            cur[u] += step[u];
         }
     };
     int colA[4], colB[8];
@@ -1161,19 +1198,41 @@ __device__ __forceinline__ void tn_block256_f32(float *ring, int M, int N, const
         if (t + 2 < T) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
         else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t + TF_DST - 1 < T) issue(t + TF_DST - 1);
         const float *stage = ring + (t % TF_DST) * TW_STAGE_FLOATS;
+        const bool rows_valid = 64 * wm < M;      // (a 128 x 256 layer: waves 4..7 -- the second wave of every SIMD -- own rows of the zero page)
+        if (!rows_valid && t + TF_DST - 1 < T) issue(t + TF_DST - 1);
+        if (rows_valid) {
+            // operands of sample group s4 + 1 are requested before the 32 MFMAs of group s4 (two register sets).  Measured MFMA busy 0.71 at
+            // 2.35 GHz -- and the same launch time with the compiler's own read placement, with all four groups read up front and every
+            // accumulator taking its four MFMAs in a row (the forward's pattern), with the DMA issue in front of the MFMAs, and without the
+            // operand fetch (-7 %): LAB_NOTES R4.6
+            float a[2][4], b[2][8];
 #pragma unroll
-        for (int s4 = 0; s4 < GK / 4; ++s4) {
-            float a[4], b[8];
+            for (int i = 0; i < 4; ++i) a[0][i] = stage[q * GT + colA[i]];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = stage[(4 * s4 + q) * GT + colA[i]];
+            for (int j = 0; j < 8; ++j) b[0][j] = stage[q * GT + colB[j]];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) b[j] = stage[(4 * s4 + q) * GT + colB[j]];
+            for (int s4 = 0; s4 < GK / 4; ++s4) {
+                if (s4 + 1 < GK / 4) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i) a[(s4 + 1) & 1][i] = stage[(4 * (s4 + 1) + q) * GT + colA[i]];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 8; ++j) b[(s4 + 1) & 1][j] = stage[(4 * (s4 + 1) + q) * GT + colB[j]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s4 == 1 && t + TF_DST - 1 < T) issue(t + TF_DST - 1);      // (behind the first quarter of the step's MFMAs: see tn_tile_f32)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+#if defined(SAHS_DIAG) && defined(SAHS_TNF_NOMFMA)      // timing-only (results wrong by construction): the K loop without its matrix work
+                        acc[i][j][0] += a[s4 & 1][i] * b[s4 & 1][j];
+#else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s4 & 1][i], b[s4 & 1][j], acc[i][j], 0, 0, 0);
+#endif
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (rowsum != nullptr && tid < 2 * GT) {
 #pragma unroll
@@ -1189,23 +1248,24 @@ __device__ __forceinline__ void tn_block256_f32(float *ring, int M, int N, const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = 64 * wm + 16 * i + 4 * q + r;
-                if (m < M && n < N) atomicAdd(C + (long)m * ldc + n, acc[i][j][r]);
+                if (64 * wm < M && m < M && n < N) atomicAdd(C + (long)m * ldc + n, acc[i][j][r]);
             }
         }
     if (rowsum != nullptr && tid < 2 * GT && tid < M) atomicAdd(rowsum + tid, cs);
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_tn_jobs256_f32_kernel(TnBatch jobs, int njobs, long P, long range,
-                                                                                                                   const float *__restrict__ zero)
+__global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_tn_jobs256_f32_kernel(TnBatch jobs, TnPlan plan, long P, const float *__restrict__ zero)
 {
     extern __shared__ __attribute__((aligned(16))) float tn_lds[];
-    const long nrange = (P + range - 1) / range;
-    const long items = nrange * njobs;                                        // item = (range r, job): the jobs of one range side by side
-    for (long it = blockIdx.x; it < items; it += gridDim.x) {
-        const long r = it / njobs;
-        const TnJob &J = jobs.j[(int)(it - r * njobs)];
-        const long k_lo = r * range, k_hi = (k_lo + range < P) ? k_lo + range : P;
+    for (int it = blockIdx.x; it < plan.items; it += gridDim.x) {
+        int u = 0;
+        while (u + 1 < plan.nunits && (int)plan.u[u + 1].start <= it) ++u;
+        const TnUnit U = plan.u[u];
+        const long range = ((P + U.n - 1) / U.n + 15) / 16 * 16;
+        const long k_lo = (long)(it - U.start) * range, k_hi = (k_lo + range < P) ? k_lo + range : P;
+        if (k_lo >= P) continue;
+        const TnJob &J = jobs.j[U.job];
         tn_block256_f32(tn_lds, J.M, J.N, J.A, J.lda, J.B, J.ldb, J.C, J.ldc, k_lo, k_hi, J.rowsum, zero);
     }
 }
@@ -2084,12 +2144,25 @@ struct TnList {
         }
         return (int)hipGetLastError();
     }
-    static long range_for(long P, long workgroups, int units, long rounds)      // (as above: equal items, `rounds` per workgroup, >= 1024 samples)
+    // units with relative K-step costs -> ranges per unit so that `slots` items of equal cost come out (ranges of >= 1024 samples)
+    static bool make_plan(TnPlan &pl, const float *cost, int nunits, long slots, long P)
     {
-        long nsplit = rounds * workgroups / (units > 0 ? units : 1);
-        if (nsplit < 1) nsplit = 1;
-        const long range = ((P + nsplit - 1) / nsplit + 15) / 16 * 16;
-        return range < 1024 ? 1024L : range;
+        if (nunits > MAX_TN_UNITS) return false;
+        double total = 0.0;
+        for (int i = 0; i < nunits; ++i) total += cost[i];
+        const long nmax = P / 1024 > 0 ? P / 1024 : 1;
+        int start = 0;
+        for (int i = 0; i < nunits; ++i) {
+            long n = (long)(cost[i] / total * (double)slots + 0.5);
+            n = n < 1 ? 1 : (n > nmax ? nmax : n);
+            if (start + n > 65535) return false;
+            pl.u[i].start = (unsigned short)start;
+            pl.u[i].n = (unsigned short)n;
+            start += (int)n;
+        }
+        pl.nunits = nunits;
+        pl.items = start;
+        return true;
     }
     int launch_f32(long P, const float *zero, int num_cu, hipStream_t st)
     {
@@ -2102,13 +2175,34 @@ struct TnList {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_jobs256_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TFW_LDS_BYTES);
         });
         if (ae != hipSuccess) return (int)ae;
-        if (nw > 0) {
-            gemm_tn_jobs256_f32_kernel<<<num_cu, TN_THREADS, TFW_LDS_BYTES, st>>>(w, nw, P, range_for(P, num_cu, nw, 1), zero);      // one 128-KB workgroup per CU
+        if (nw > 0) {      // one 128-KB workgroup per CU, one item each
+            TnPlan pl;
+            float cost[MAX_TN_UNITS];
+            for (int i = 0; i < nw && i < MAX_TN_UNITS; ++i) {
+                cost[i] = w.j[i].M > 128 ? 2.0f : 1.0f;          // (rows past M are the zero page: the waves that own them skip their MFMAs)
+                pl.u[i].job = (unsigned char)i; pl.u[i].bx = pl.u[i].by = pl.u[i].pad = 0;
+            }
+            if (!make_plan(pl, cost, nw, num_cu, P)) return (int)hipErrorOutOfMemory;
+            gemm_tn_jobs256_f32_kernel<<<num_cu, TN_THREADS, TFW_LDS_BYTES, st>>>(w, pl, P, zero);
             if (hipGetLastError() != hipSuccess) return (int)hipErrorLaunchFailure;
         }
-        if (n > 0) {
-            const int G = 2 * num_cu / 8 * 8;                     // two 64-KB workgroups per CU
-            gemm_tn_jobs_f32_kernel<<<G, TN_THREADS, TF_LDS_BYTES, st>>>(b, n, tiles, P, range_for(P, G, tiles, 2), zero);
+        if (n > 0) {       // two 64-KB workgroups per CU, two items each
+            const int G = 2 * num_cu;
+            TnPlan pl;
+            float cost[MAX_TN_UNITS];
+            int nu = 0;
+            for (int i = 0; i < n; ++i) {
+                const int nx = (b.j[i].N + GT - 1) / GT, ny = (b.j[i].M + GT - 1) / GT;
+                for (int by = 0; by < ny; ++by)
+                    for (int bx = 0; bx < nx; ++bx, ++nu) {
+                        if (nu >= MAX_TN_UNITS) return (int)hipErrorOutOfMemory;
+                        const int mt = b.j[i].M - by * GT < GT ? b.j[i].M - by * GT : GT, nt = b.j[i].N - bx * GT < GT ? b.j[i].N - bx * GT : GT;
+                        cost[nu] = 0.2f + (float)(((mt + 15) / 16) * ((nt + 15) / 16)) / 64.0f;      // a K-step: its fixed part + the tile's valid accumulators
+                        pl.u[nu].job = (unsigned char)i; pl.u[nu].bx = (unsigned char)bx; pl.u[nu].by = (unsigned char)by; pl.u[nu].pad = 0;
+                    }
+            }
+            if (!make_plan(pl, cost, nu, 2L * G, P)) return (int)hipErrorOutOfMemory;
+            gemm_tn_jobs_f32_kernel<<<G, TN_THREADS, TF_LDS_BYTES, st>>>(b, pl, P, zero);
         }
         return (int)hipGetLastError();
     }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ / L2 counters of the training step's kernels (separate passes; kernel trace only beside them):  tools/pmc_train_sq.sh [x3fwd|bf16x3]
+# SQ / L2 counters of the training step's kernels (separate passes; kernel trace only beside them):  tools/pmc_train_sq.sh [x3fwd|bf16x3|fp32]
 LEG=${1:-x3fwd}
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_train_sq; rm -rf $OUT; mkdir -p $OUT
@@ -28,8 +28,8 @@ for f in sorted(glob.glob("gpurun_out/pmc_train_sq/p*/**/*counter_collection.csv
 for k,d in agg.items():
     g=lambda c: d.get(c,0.0)
     ns=g("_ns_SQ_BUSY_CYCLES") or 1
-    print("%-12s time %.3f ms | mfma_busy/busy %.3f | wait_any/wave_cycles %.3f | active_any/wave_cycles %.3f | lds active/valu active %.2f | bank conflict cycles/lds active %.3f | L2 hit %.3f | EA rd %.3g wr %.3g"
-          % (k, ns/1e6, g("SQ_VALU_MFMA_BUSY_CYCLES")/(g("SQ_BUSY_CYCLES") or 1), g("SQ_WAIT_INST_ANY")/(g("SQ_WAVE_CYCLES") or 1), g("SQ_ACTIVE_INST_ANY")/(g("SQ_WAVE_CYCLES") or 1),
+    print("%-12s time %.3f ms | clock %.2f GHz | mfma_busy/busy %.3f | wait_any/wave_cycles %.3f | active_any/wave_cycles %.3f | lds active/valu active %.2f | bank conflict cycles/lds active %.3f | L2 hit %.3f | EA rd %.3g wr %.3g"
+          % (k, ns/1e6, g("GRBM_GUI_ACTIVE")/8.0/ns, g("SQ_VALU_MFMA_BUSY_CYCLES")/(g("SQ_BUSY_CYCLES") or 1), g("SQ_WAIT_INST_ANY")/(g("SQ_WAVE_CYCLES") or 1), g("SQ_ACTIVE_INST_ANY")/(g("SQ_WAVE_CYCLES") or 1),
              g("SQ_ACTIVE_INST_LDS")/(g("SQ_ACTIVE_INST_VALU") or 1), g("SQ_LDS_BANK_CONFLICT")/(g("SQ_ACTIVE_INST_LDS") or 1), g("TCC_HIT_sum")/((g("TCC_HIT_sum")+g("TCC_MISS_sum")) or 1), g("TCC_EA_RDREQ_sum"), g("TCC_EA_WRREQ_sum")))
     print("             raw:", {c: v for c, v in d.items() if not c.startswith("_ns_")})
 PY
