@@ -417,6 +417,7 @@ def train_record(pkg, rays, dt, steps, backward, nc=64, nf=64, forward="fp32"):
     return {"workload": "T%d: %d semantically-weighted rays, 64+128 evaluations/ray, train mode (noise 0.1), forward + loss recipe + backward"
                         % (rays, rays), "ms_per_step": dt * 1e3, "value": rays / dt, "unit": "rays/s", "dtype": dtype,
             "backward_gemm_precision": backward, "training_forward_precision": forward, "steps": steps,
+            "backward_walk": "fused (one data-gradient chain + job-table weight-gradient launches per part)" if pkg.ops.fused_backward() else "per-layer GEMM launches",
             "roofline": {"bound": "mfma", "unit": "TFLOP/s", "frac": (t_f32 + t_bf16) / dt,
                          "what": "executed MFMA FLOPs per pipe / that pipe's peak, summed, / step time",
                          "pipes": {"f32_mfma": {"executed_tflop": f32_flops / 1e12, "peak": PEAK_TFLOPS["fp32"], "ms_at_peak": t_f32 * 1e3},

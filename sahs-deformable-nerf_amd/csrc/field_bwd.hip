@@ -2151,14 +2151,25 @@ struct TnList {
         double total = 0.0;
         for (int i = 0; i < nunits; ++i) total += cost[i];
         const long nmax = P / 1024 > 0 ? P / 1024 : 1;
+        long n[MAX_TN_UNITS], sum = 0;
+        for (int i = 0; i < nunits; ++i) {
+            n[i] = (long)(cost[i] / total * (double)slots + 0.5);
+            n[i] = n[i] < 1 ? 1 : (n[i] > nmax ? nmax : n[i]);
+            sum += n[i];
+        }
+        while (sum > slots) {      // never one item more than the slots: it would be a whole extra round of the launch (measured: 1.9 -> 3.5 ms)
+            int big = 0;
+            for (int i = 1; i < nunits; ++i)
+                if (n[i] > n[big]) big = i;
+            if (n[big] <= 1) break;
+            --n[big]; --sum;
+        }
         int start = 0;
         for (int i = 0; i < nunits; ++i) {
-            long n = (long)(cost[i] / total * (double)slots + 0.5);
-            n = n < 1 ? 1 : (n > nmax ? nmax : n);
-            if (start + n > 65535) return false;
+            if (start + n[i] > 65535) return false;
             pl.u[i].start = (unsigned short)start;
-            pl.u[i].n = (unsigned short)n;
-            start += (int)n;
+            pl.u[i].n = (unsigned short)n[i];
+            start += (int)n[i];
         }
         pl.nunits = nunits;
         pl.items = start;
@@ -2175,18 +2186,21 @@ struct TnList {
             return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_jobs256_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TFW_LDS_BYTES);
         });
         if (ae != hipSuccess) return (int)ae;
+        static const float c0w = getenv("SAHS_TNF_C0W") ? (float)atof(getenv("SAHS_TNF_C0W")) : 0.27f;      // (tuning aids: a K-step's fixed part in the two
+        static const float c0n = getenv("SAHS_TNF_C0N") ? (float)atof(getenv("SAHS_TNF_C0N")) : 1.3f;      //  cost models, items per workgroup of the narrow launch)
+        static const long rounds_n = getenv("SAHS_TNF_ROUNDS") ? atol(getenv("SAHS_TNF_ROUNDS")) : 3;
         if (nw > 0) {      // one 128-KB workgroup per CU, one item each
             TnPlan pl;
             float cost[MAX_TN_UNITS];
             for (int i = 0; i < nw && i < MAX_TN_UNITS; ++i) {
-                cost[i] = w.j[i].M > 128 ? 2.0f : 1.0f;          // (rows past M are the zero page: the waves that own them skip their MFMAs)
+                cost[i] = c0w + (w.j[i].M > 128 ? 2.0f : 1.0f);      // (rows past M are the zero page: the waves that own them skip their MFMAs; 0.27: a K-step's fixed part)
                 pl.u[i].job = (unsigned char)i; pl.u[i].bx = pl.u[i].by = pl.u[i].pad = 0;
             }
             if (!make_plan(pl, cost, nw, num_cu, P)) return (int)hipErrorOutOfMemory;
             gemm_tn_jobs256_f32_kernel<<<num_cu, TN_THREADS, TFW_LDS_BYTES, st>>>(w, pl, P, zero);
             if (hipGetLastError() != hipSuccess) return (int)hipErrorLaunchFailure;
         }
-        if (n > 0) {       // two 64-KB workgroups per CU, two items each
+        if (n > 0) {       // two 64-KB workgroups per CU, three items each (measured on the training step: 0.91 / 0.69 / 0.64 / 0.64 ms per launch at 1 / 2 / 3 / 4)
             const int G = 2 * num_cu;
             TnPlan pl;
             float cost[MAX_TN_UNITS];
@@ -2197,11 +2211,13 @@ struct TnList {
                     for (int bx = 0; bx < nx; ++bx, ++nu) {
                         if (nu >= MAX_TN_UNITS) return (int)hipErrorOutOfMemory;
                         const int mt = b.j[i].M - by * GT < GT ? b.j[i].M - by * GT : GT, nt = b.j[i].N - bx * GT < GT ? b.j[i].N - bx * GT : GT;
-                        cost[nu] = 0.2f + (float)(((mt + 15) / 16) * ((nt + 15) / 16)) / 64.0f;      // a K-step: its fixed part + the tile's valid accumulators
+                        // a K-step: its fixed part (barrier, DMA issue, first LDS round trip; fitted on the training step, tools/sweep_tnf.sh: 0.72 / 0.69 /
+                        // 0.64 / 0.70 ms per launch at 0.55 / 0.9 / 1.3 / 2.0) + the tile's valid accumulators
+                        cost[nu] = c0n + (float)(((mt + 15) / 16) * ((nt + 15) / 16)) / 64.0f;
                         pl.u[nu].job = (unsigned char)i; pl.u[nu].bx = (unsigned char)bx; pl.u[nu].by = (unsigned char)by; pl.u[nu].pad = 0;
                     }
             }
-            if (!make_plan(pl, cost, nu, 2L * G, P)) return (int)hipErrorOutOfMemory;
+            if (!make_plan(pl, cost, nu, rounds_n * G, P)) return (int)hipErrorOutOfMemory;
             gemm_tn_jobs_f32_kernel<<<G, TN_THREADS, TF_LDS_BYTES, st>>>(b, pl, P, zero);
         }
         return (int)hipGetLastError();
