@@ -164,7 +164,7 @@ struct BwdEpF {
         }
         asm volatile("" : "+v"(o));     // pin: keep the finished tile from being sunk into the next layer
         out[t] = o;
-        if (save != nullptr) *reinterpret_cast<f32x4 *>(save + 16 * t) = o;
+        if (save != nullptr) *reinterpret_cast<f32x4 *>(save + 16 * t) = o;      // (non-temporal: measured no gain here, 2.31 vs 2.30 ms per launch)
     }
 };
 
