@@ -29,7 +29,8 @@ if has train; then
   rm -rf $OUT/trace_train_x3fwd
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train_x3fwd -- python3 tools/train_legs.py --only x3fwd --steps 5 --warmup 2 > $OUT/bench_trace_train_x3fwd.json 2> $OUT/trace_train_x3fwd.err
   for C in FETCH_SIZE WRITE_SIZE; do
-    rm -rf $OUT/pmc_train_$C $OUT/pmc_trainx3_$C
+    rm -rf $OUT/pmc_train_$C $OUT/pmc_trainx3_$C $OUT/pmc_trainf32_$C
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_trainf32_$C -- python3 tools/train_legs.py --only fp32 --steps 2 --warmup 1 > $OUT/pmc_trainf32_$C.json 2> $OUT/pmc_trainf32_$C.err
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_train_$C -- python3 tools/train_legs.py --only bf16x3 --steps 2 --warmup 1 > $OUT/pmc_train_$C.json 2> $OUT/pmc_train_$C.err
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_trainx3_$C -- python3 tools/train_legs.py --only x3fwd --steps 2 --warmup 1 > $OUT/pmc_trainx3_$C.json 2> $OUT/pmc_trainx3_$C.err
   done

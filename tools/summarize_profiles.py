@@ -80,7 +80,8 @@ for leg, args, steps, what in (("f32", "--precision fp32", 8, "fp32 W512 headlin
 for sub, name, arg, what in (("trace_train", "train_T2048_bf16x3", "bf16x3", "the default backward: field_backward_chain_{rad,def}_kernel = the sample-major data-gradient chains, "
                               "gemm_tn_jobs_kernel = every weight gradient of a part in one launch, both on the bf16 pipe with split operands"),
                              ("trace_train_x3fwd", "train_T2048_x3fwd", "x3fwd", "opt-in: the saving forward on the split-operand kernels too -- field_{radiance,deform}_bf16x3_kernel<true>"),
-                             ("trace_train_f32", "train_T2048", "fp32", "backward products in f32 (the reference's arithmetic): the per-layer walk, gemm_dma_kernel<*, false>")):
+                             ("trace_train_f32", "train_T2048", "fp32", "backward products in f32 (the reference's arithmetic): the fused walk in f32 -- field_backward_chain_{rad,def}_f32_kernel, "
+                              "gemm_tn_jobs_f32_kernel / gemm_tn_jobs256_f32_kernel")):
     if glob.glob(os.path.join(base, sub, "*", "*_kernel_stats.csv")):
         stats[sub] = kernel_stats(sub, "%s_%s_kernel_stats.csv" % (tag, name),
                                   "rocprofv3 --kernel-trace --stats -- python3 tools/train_legs.py --only %s --steps 5 --warmup 2   (T2048: 2048-ray forward + backward, 7 steps; %s)" % (arg, what))
@@ -152,14 +153,15 @@ def last_step(rows):
     return rows[idx[-2] + 1: idx[-1] + 1]
 
 
-for pmc_tag, leg_arg, key in (("pmc_train", "bf16x3", "train_T2048"), ("pmc_trainx3", "x3fwd", "train_T2048_x3fwd")):
+for pmc_tag, leg_arg, key in (("pmc_train", "bf16x3", "train_T2048"), ("pmc_trainx3", "x3fwd", "train_T2048_x3fwd"), ("pmc_trainf32", "fp32", "train_T2048_f32")):
   try:
     fs = last_step(list(csv.DictReader(open(newest(os.path.join(base, pmc_tag + "_FETCH_SIZE", "*", "*counter_collection.csv"))))))
     ws = last_step(list(csv.DictReader(open(newest(os.path.join(base, pmc_tag + "_WRITE_SIZE", "*", "*counter_collection.csv"))))))
     tr = collections.OrderedDict()
     for a, b in zip(fs, ws):
         n = a["Kernel_Name"]
-        nm = ("weight gradients over job tables: gemm_tn_jobs_kernel + gemm_tn_jobs256_kernel" if "gemm_tn_jobs" in n else "data-gradient chain field_backward_chain_*_kernel" if "field_backward_chain" in n else
+        nm = ("weight gradients over job tables, f32: gemm_tn_jobs_f32_kernel + gemm_tn_jobs256_f32_kernel" if "gemm_tn_jobs" in n and "_f32_kernel" in n else
+              "weight gradients over job tables: gemm_tn_jobs_kernel + gemm_tn_jobs256_kernel" if "gemm_tn_jobs" in n else "data-gradient chain field_backward_chain_*_kernel" if "field_backward_chain" in n else
               "weight-gradient GEMM gemm_tn_split_kernel" if "gemm_tn_split_kernel" in n else "weight-gradient GEMM gemm_dma_kernel<true,*>" if "gemm_dma_kernel<true" in n else "data-gradient GEMM gemm_dma_kernel<false,true>" if "gemm_dma_kernel<false" in n
               else "field_forward_f32_kernel<true,*> (activation-saving forward)" if "field_forward" in n
               else "field_{radiance,deform}_bf16x3_kernel<true> (activation-saving forward, split operands)" if "bf16x3_kernel" in n else "gemm_f32_kernel" if "gemm_f32" in n else "other")
