@@ -1248,7 +1248,11 @@ __device__ __forceinline__ void tn_block256_f32(float *ring, int M, int N, const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = 64 * wm + 16 * i + 4 * q + r;
+#if defined(SAHS_DIAG) && defined(SAHS_TNF_NOATOMIC)      // timing-only (results wrong by construction): the launch without its atomic epilogue
+                if (64 * wm < M && m < M && n < N && acc[i][j][r] == 123.456f) C[(long)m * ldc + n] = 0.0f;
+#else
                 if (64 * wm < M && m < M && n < N) atomicAdd(C + (long)m * ldc + n, acc[i][j][r]);
+#endif
             }
         }
     if (rowsum != nullptr && tid < 2 * GT && tid < M) atomicAdd(rowsum + tid, cs);

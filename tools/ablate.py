@@ -17,7 +17,7 @@ VARIANTS = {"base": ["SAHS_DIAG"],
             "x3nodma": ["SAHS_DIAG", "SAHS_X3_NODMA"], "x3nobar": ["SAHS_DIAG", "SAHS_X3_NOBARRIER"], "x3noaread": ["SAHS_DIAG", "SAHS_X3_NOAREAD"],
             "x3saveplain": ["SAHS_DIAG", "SAHS_X3_SAVE_PLAIN"],      # the saving forward's activation stores with the default cache policy
             "tnnodma": ["SAHS_DIAG", "SAHS_TN_NODMA"],      # the weight-gradient job kernels without their operand fetch (what the K loop costs by itself)
-            "tnfnodma": ["SAHS_DIAG", "SAHS_TNF_NODMA"], "tnfnomfma": ["SAHS_DIAG", "SAHS_TNF_NOMFMA"],      # the fp32 weight-gradient job kernels: without the operand fetch / without the wide kernel's MFMAs
+            "tnfnodma": ["SAHS_DIAG", "SAHS_TNF_NODMA"], "tnfnomfma": ["SAHS_DIAG", "SAHS_TNF_NOMFMA"], "tnfnoatomic": ["SAHS_DIAG", "SAHS_TNF_NOATOMIC"],      # the fp32 weight-gradient job kernels: without the operand fetch / without the wide kernel's MFMAs
             "x3noreadback": ["SAHS_DIAG", "SAHS_X3_NOREADBACK"],      # saving forward + backward chains: the line stores without the LDS read-back they wait for
             "x3floor": ["SAHS_DIAG", "SAHS_X3_NODMA", "SAHS_X3_NOBARRIER", "SAHS_X3_NOAREAD"],
             # the backward chain kernels (csrc/field_bwd_chain.hip): what they wait for (tools/ab_chain.sh runs them under rocprofv3)
