@@ -82,10 +82,12 @@ def test_train_step_2048_rays_vs_eager_autograd(weights_mod):
     print(json.dumps(res))
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_train_step_vs_reference_fixture(flat_weights, fused):
+@pytest.mark.parametrize("fused,prec", [(False, "bf16x3"), (True, "bf16x3"), (True, "fp32")])
+def test_train_step_vs_reference_fixture(flat_weights, fused, prec):
     """fused: the objective evaluated by sahs_stage1_loss_forward and its gradient formed inside composite_backward_kernel
     (run_one_iter_of_nerf(..., _loss=...)); otherwise the torch statement of the loss modules + autograd.  Same bounds.
+    prec: the arithmetic of the backward walk -- the default split-bf16 operands, or exact fp32 products (the reference's own; the fused
+    walk's f32 kernels: field_bwd_chain_f32.hip, gemm_tn_jobs*_f32_kernel).
     f-2 pinned: one training step (train_stage_rays_auto.py:437-468) on the high-dynamic-range network -- train-mode render
     with the reference's captured draws, the loss recipe, the sample_prob feedback and backward through the HIP kernels --
     against what the REFERENCE computed on the same 32 rays (tests/golden/train_step_hdr.npz: its own MaskMSELoss /
@@ -132,7 +134,13 @@ def test_train_step_vs_reference_fixture(flat_weights, fused):
     p64, p32 = g["sample_prob_f64"], g["sample_prob"].astype(np.float64)
     e_hip, e_ref = np.abs(prob.detach().cpu().numpy() - p64).max(), np.abs(p32 - p64).max()
     assert e_hip <= 3.0 * e_ref + 1e-6, (e_hip, e_ref)
-    loss.backward()
+    ops = pkg("ops")
+    ops.backward_gemm_precision(prec)
+    try:
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.backward_gemm_precision("bf16x3")
     params = dict(model.named_parameters())
     names = [str(n) for n in g["grad_names"]]
     n32, n64 = g["grad_norms"], g["grad_norms_f64"]
