@@ -23,10 +23,12 @@ FIELD_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee"]
 # about, and a spilled in-flight destination would be stored before its data has landed.  The build reads the compiler's own resource
 # remarks and FAILS if one of them has a non-zero scratch size (substring of the mangled name -> max bytes).  The headline fp32 forward
 # kernel (audio model, no activation saving) is held to zero scratch as a performance guard (a reload's wait also drains its in-flight
-# weight prefetch); its activation-saving and NeRFace builds do spill a little (build/<library>.resource_usage.txt).
+# weight prefetch); its activation-saving and NeRFace builds do spill a little (build/<library>.resource_usage.txt): with the tile stores
+# unconditional (f32_pipe.hpp: kStores) the saving audio kernels keep two plane pointers in scratch, reloaded twice per 128-sample tile --
+# extra vector-memory operations can only make a counted wait stricter, never weaker.
 NO_SCRATCH = {"gemm_dma_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb0E": 0, "field_forward_bf16w_kernel": 0,
               "field_radiance_bf16x3_kernel": 0, "field_deform_bf16x3_kernel": 0, "gemm_tn_split_kernel": 0, "gemm_tn_jobs_kernel": 0,
-              "field_backward_chain_rad_kernel": 0, "field_backward_chain_def_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb1E": 0,
+              "field_backward_chain_rad_kernel": 0, "field_backward_chain_def_kernel": 0, "_ZN4sahs24field_forward_f32_kernelILb1E": 96,
               "gemm_tn_jobs_f32_kernel": 0, "gemm_tn_jobs256_f32_kernel": 0,
               "field_backward_chain_rad_f32_kernel": 0, "field_backward_chain_def_f32_kernel": 0}
 # Kernels with hand-issued `asm volatile ds_read_b128` + counted waits (csrc/bf16_pipe.hpp): (source, SAHS_MODEL, kernel name pattern).

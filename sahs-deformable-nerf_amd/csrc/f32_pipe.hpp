@@ -55,9 +55,17 @@ struct Ctx {
         const int base = p * F32_THREADS + wave * WAVE;
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(nx_src + base), (lds_ptr_t)(nx_dst + base), 16, 0, 0);
     }
+    // N: the wave's vector-memory operations that may still be in flight behind the chunk's closing barrier -- the stores of its last
+    // finished tiles, all younger than the chunk's LDS-DMA pieces (vmcnt retires in issue order: "all but the N youngest done" covers every
+    // piece).  N = 0: everything drains (the forward without saved activations: __syncthreads, as before).
+    template <int N = 0>
     __device__ __forceinline__ void end_chunk()
     {
-        __syncthreads();   // drains the in-flight global_load_lds (vmcnt(0)) and orders buffer reuse
+        if constexpr (N == 0) {
+            __syncthreads();   // drains the in-flight global_load_lds (vmcnt(0)) and orders buffer reuse
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+        }
         buf ^= 1;
     }
     __device__ __forceinline__ const f32x4 *cur() const { return reinterpret_cast<const f32x4 *>(lds + buf * LDS_BUF_FLOATS); }
@@ -80,11 +88,27 @@ __device__ __forceinline__ f32x4 act4(f32x4 v, float slope)   // slope in [0,1]:
     return o;
 }
 
+// Vector-memory operations a wave is GUARANTEED to have issued after the last LDS-DMA piece of a chunk: per_tile stores for every tile that
+// finishes at or behind that piece's step (a finished tile's store follows the piece of the same step in program order; a scheduling barrier
+// behind the last piece keeps it there).  0 when pieces are still issued behind the step loop (short chunks).  A saving forward waited for
+// vmcnt(0) at every chunk end -- i.e. for the acknowledgement of stores it had issued a few hundred cycles earlier, ~100 times per sample tile.
+constexpr int stores_behind_last_piece(int STEPS, int PAIR, int KB, int next_floats, int per_tile)
+{
+    const int npieces = (next_floats + PIECE_FLOATS - 1) / PIECE_FLOATS;
+    const int pstep = (STEPS / 2 >= npieces) ? (STEPS / 2) / npieces : 1;
+    if (per_tile == 0 || npieces > (STEPS + pstep - 1) / pstep) return 0;
+    int n = 0;
+    for (int s = (npieces - 1) * pstep; s < STEPS; ++s)
+        if ((s % (PAIR * KB)) / PAIR == KB - 1) n += per_tile;
+    return n > 48 ? 48 : n;
+}
+
 // One dense layer.  in0[KB0] ++ in1[KB1] are the input k-blocks (16 features each); out[NT] the 16-row output tiles.
 // NEXT = floats in the chunk that follows this layer's last chunk.
 // A chunk is a flat run of G*KB steps; step = one A fragment (ds_read_b128) feeding 4 MFMAs.  Tiles are taken in pairs so
 // two independent accumulation chains alternate (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle dependent latency).
-// EP: first(cx, out, t) = the accumulator a tile starts from; done<NT>(acc, out, t) = what becomes of the finished tile.
+// EP: first(cx, out, t) = the accumulator a tile starts from; done<NT>(acc, out, t) = what becomes of the finished tile; EP::kStores = the
+// vector-memory stores done() issues UNCONDITIONALLY per tile (the chunk's closing wait leaves them in flight).
 template <int KB0, int KB1, int NT, int NEXT, class EP>
 __device__ __forceinline__ void dense_ep(Ctx &cx, const f32x4 *in0, const f32x4 *in1, f32x4 *out, EP &ep)
 {
@@ -93,6 +117,7 @@ __device__ __forceinline__ void dense_ep(Ctx &cx, const f32x4 *in0, const f32x4 
     constexpr int NCH = NT / G;
     constexpr int PAIR = (G >= 2) ? 2 : 1;             // tiles interleaved
     constexpr int STEPS = G * KB;                      // A fragments per chunk
+    constexpr int N_MID = stores_behind_last_piece(STEPS, PAIR, KB, G * KB * 256, EP::kStores), N_LAST = stores_behind_last_piece(STEPS, PAIR, KB, NEXT, EP::kStores);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int nfl = (c + 1 < NCH) ? G * KB * 256 : NEXT;
@@ -112,7 +137,10 @@ __device__ __forceinline__ void dense_ep(Ctx &cx, const f32x4 *in0, const f32x4 
             const int pp = s / (PAIR * KB), r = s % (PAIR * KB), m = r % PAIR, b = r / PAIR;
             const int t = c * G + pp * PAIR + m;
             if (b == 0) acc[m] = ep.first(cx, out, t);
-            if (s % pstep == 0 && s / pstep < npieces) cx.issue_piece(s / pstep);
+            if (s % pstep == 0 && s / pstep < npieces) {
+                cx.issue_piece(s / pstep);
+                if (EP::kStores > 0 && s / pstep == npieces - 1) __builtin_amdgcn_sched_barrier(0);      // (the counted wait below: no store moves in front of the last piece)
+            }
             const f32x4 x = (b < KB0) ? in0[b] : in1[b - KB0];
             const f32x4 w = a[s % A_AHEAD];
 #pragma unroll
@@ -123,14 +151,17 @@ __device__ __forceinline__ void dense_ep(Ctx &cx, const f32x4 *in0, const f32x4 
 #pragma unroll
         for (int pc = (STEPS + pstep - 1) / pstep; pc < MAX_PIECES; ++pc)
             if (pc < npieces) cx.issue_piece(pc);
-        cx.end_chunk();
+        if (c + 1 < NCH) cx.template end_chunk<N_MID>();
+        else cx.template end_chunk<N_LAST>();
     }
 }
 
 // The forward epilogue.  slope: 1 = no activation, 0 = relu, 0.01 = leaky relu.  accum: start from out[] instead of the bias.
+template <bool HAS_SAVE>
 struct FwdEp {
+    static constexpr int kStores = HAS_SAVE ? 1 : 0;
     int bias_off; bool accum; float slope;
-    float *save;              // this lane's slot of the layer's saved-activation block, or null
+    float *save;              // HAS_SAVE: this lane's slot of the layer's saved-activation block (never null: lanes past the end redo the last sample)
     uint32_t *bsave;          // this lane's word(s) of the layer's sign-bit plane (sahs_layout.hpp: sbits), or null
     uint32_t sgn;             // sign nibble of the even tile of a pair, until its odd partner completes the byte
     __device__ __forceinline__ f32x4 first(const Ctx &cx, const f32x4 *out, int t) const { return accum ? out[t] : cx.bias4(bias_off + 16 * t); }
@@ -139,7 +170,7 @@ struct FwdEp {
         f32x4 o = act4(acc, slope);
         asm volatile("" : "+v"(o));     // pin: keep the finished tile from being sunk into the next layer
         out[t] = o;
-        if (save != nullptr) *reinterpret_cast<f32x4 *>(save + 16 * t) = o;
+        if constexpr (HAS_SAVE) *reinterpret_cast<f32x4 *>(save + 16 * t) = o;
         if (bsave != nullptr) {      // nibble t of this lane's sign word(s): bit r = value r of tile t is > 0; one byte store per tile pair
             uint32_t nib = 0u;
 #pragma unroll
@@ -151,10 +182,17 @@ struct FwdEp {
 };
 
 template <int KB0, int KB1, int NT, int NEXT>
-__device__ __forceinline__ void dense(Ctx &cx, const f32x4 *in0, const f32x4 *in1, f32x4 *out, int bias_off, bool accum, float slope,
-                                      float *save = nullptr, uint32_t *bsave = nullptr)
+__device__ __forceinline__ void dense(Ctx &cx, const f32x4 *in0, const f32x4 *in1, f32x4 *out, int bias_off, bool accum, float slope)
 {
-    FwdEp ep{bias_off, accum, slope, save, bsave, 0u};
+    FwdEp<false> ep{bias_off, accum, slope, nullptr, nullptr, 0u};
+    dense_ep<KB0, KB1, NT, NEXT>(cx, in0, in1, out, ep);
+}
+// SAVING: the launch keeps its activations -- every finished tile also goes to `save` (+ its signs to bsave, where given)
+template <bool SAVING, int KB0, int KB1, int NT, int NEXT>
+__device__ __forceinline__ void dense_sv(Ctx &cx, const f32x4 *in0, const f32x4 *in1, f32x4 *out, int bias_off, bool accum, float slope,
+                                         float *save, uint32_t *bsave = nullptr)
+{
+    FwdEp<SAVING> ep{bias_off, accum, slope, save, SAVING ? bsave : nullptr, 0u};
     dense_ep<KB0, KB1, NT, NEXT>(cx, in0, in1, out, ep);
 }
 

@@ -148,10 +148,11 @@ __global__ void __launch_bounds__(256) pack_bwd_stream_f32_kernel(const float *_
 
 // ---- the backward epilogue ------------------------------------------------------------------------------------------------------------
 // MASKED: the layer behind this gradient has a (leaky-)ReLU -- bit 4 (t & 7) + r of word t >> 3 of this lane's sign words says whether value
-// r of tile t was > 0 (derivative 1, else `slope`).  save: this lane's slot (row p, column 4 q) of the plane the tile is stored to, or null.
+// r of tile t was > 0 (derivative 1, else `slope`).  save (STORE): this lane's slot (row p, column 4 q) of the plane the tile is stored to.
 // accum: the tile continues the sum a previous layer left in out[] (d feat).
-template <bool MASKED>
+template <bool MASKED, bool STORE = true>
 struct BwdEpF {
+    static constexpr int kStores = STORE ? 1 : 0;      // (unconditional: lanes past the end redo the last sample and store the same values again)
     bool accum; float slope; uint32_t m[2]; float *save;
     __device__ __forceinline__ f32x4 first(const Ctx &, const f32x4 *out, int t) const { return accum ? out[t] : f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
     template <int NT> __device__ __forceinline__ void done(const f32x4 &acc, f32x4 *out, int t)
@@ -164,7 +165,7 @@ struct BwdEpF {
         }
         asm volatile("" : "+v"(o));     // pin: keep the finished tile from being sunk into the next layer
         out[t] = o;
-        if (save != nullptr) *reinterpret_cast<f32x4 *>(save + 16 * t) = o;      // (non-temporal: measured no gain here, 2.31 vs 2.30 ms per launch)
+        if constexpr (STORE) *reinterpret_cast<f32x4 *>(save + 16 * t) = o;      // (non-temporal: measured no gain here, 2.31 vs 2.30 ms per launch)
     }
 };
 
@@ -203,12 +204,11 @@ field_backward_chain_rad_f32_kernel(const float *__restrict__ stream, long P, co
     const long ntiles = (P + F32_PTS_PER_WG - 1) / F32_PTS_PER_WG;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long p_raw = tile * F32_PTS_PER_WG + cx.wave * F32_PTS_PER_WAVE + (cx.lane & 15);
-        const long p = p_raw < P ? p_raw : P - 1;      // lanes past the end redo the last sample and store nothing
-        const bool on = p_raw < P;
+        const long p = p_raw < P ? p_raw : P - 1;      // lanes past the end redo the last sample (and store its values again)
         long Pq = P;
         asm volatile("" : "+s"(Pq));                   // (the ~25 plane bases c * P are loop-invariant: keep them from being hoisted and spilled)
         const uint32_t sb_lane = (uint32_t)(p * 4 + q);
-#define DZ(c, w) (on ? dact + (long)(c) * Pq + p * (long)(w) + 4 * q : nullptr)
+#define DZ(c, w) (dact + (long)(c) * Pq + p * (long)(w) + 4 * q)
         auto ep128 = [&](int b, int c) {               // a 128-wide leaky-ReLU layer: one sign word per lane
             BwdEpF<true> e;
             e.accum = false; e.slope = 0.01f;
@@ -237,7 +237,7 @@ field_backward_chain_rad_f32_kernel(const float *__restrict__ stream, long P, co
             dense_ep<8, 0, 8, CHR(R_D1)>(cx, cB, nullptr, cA, e1);
             auto e0 = ep128(sbits::BR_C + 0, act::C + 0);
             dense_ep<8, 0, 8, CHR(R_GRIDF)>(cx, cA, nullptr, dC0, e0);
-            BwdEpF<false> eg{false, 1.0f, {0u, 0u}, on ? dgridf + p * 32 + 4 * q : nullptr};
+            BwdEpF<false> eg{false, 1.0f, {0u, 0u}, dgridf + p * 32 + 4 * q};
             f32x4 g2[2];
             dense_ep<8, 0, 2, CHR(R_SEGH)>(cx, dC0, nullptr, g2, eg);
         }
@@ -254,7 +254,7 @@ field_backward_chain_rad_f32_kernel(const float *__restrict__ stream, long P, co
         }
         f32x4 F[16], G[16];
         {   // d feat (no activation behind it)
-            BwdEpF<false> ea{false, 1.0f, {0u, 0u}, nullptr};
+            BwdEpF<false, false> ea{false, 1.0f, {0u, 0u}, nullptr};
             dense_ep<1, 0, 16, CHR(R_FEATB)>(cx, draw, nullptr, F, ea);
             BwdEpF<false> ef{true, 1.0f, {0u, 0u}, DZ(act::FEAT, 256)};
             dense_ep<8, 8, 16, CHR(R_FEAT)>(cx, dS0, dC0, F, ef);
@@ -271,7 +271,7 @@ field_backward_chain_rad_f32_kernel(const float *__restrict__ stream, long P, co
             }
             static_assert(CHR(R_T6) == CHR(R_T5) && CHR(R_T6) == CHR(R_T4) && CHR(R_T6) == CHR(R_T3IN), "rolled trunk layers");
             {
-                BwdEpF<false> ei{false, 1.0f, {0u, 0u}, on ? din_a + p * 96 + 4 * q : nullptr};
+                BwdEpF<false> ei{false, 1.0f, {0u, 0u}, din_a + p * 96 + 4 * q};
                 f32x4 d6[6];
                 dense_ep<16, 0, 6, CHR(R_T3)>(cx, G, nullptr, d6, ei);
             }
@@ -282,7 +282,7 @@ field_backward_chain_rad_f32_kernel(const float *__restrict__ stream, long P, co
             auto e0 = ep256(sbits::BR_T + 0, act::T + 0);
             dense_ep<16, 0, 16, CHR(R_T0IN)>(cx, G, nullptr, F, e0);
             {
-                BwdEpF<false> ei{false, 1.0f, {0u, 0u}, on ? din_b + p * 96 + 4 * q : nullptr};
+                BwdEpF<false> ei{false, 1.0f, {0u, 0u}, din_b + p * 96 + 4 * q};
                 f32x4 d6[6];
                 dense_ep<16, 0, 6, CHR(R_RGBH)>(cx, F, nullptr, d6, ei);
             }
@@ -315,7 +315,7 @@ field_backward_chain_def_f32_kernel(const float *__restrict__ stream, long P, co
             BwdEpF<true> e;
             e.accum = false; e.slope = 0.0f;
             e.m[0] = bits[(long)b * Pq + sb_lane]; e.m[1] = 0u;
-            e.save = on ? dact + (long)c * Pq + p * (long)w + 4 * q : nullptr;
+            e.save = dact + (long)c * Pq + p * (long)w + 4 * q;
             return e;
         };
         f32x4 hd_x[1], hd_w[1];

@@ -186,7 +186,7 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         long Psv = P;
         if constexpr (SAVE) asm volatile("" : "+s"(Psv));
 #define SVP(c, w) (actbuf + (long)(c) * Psv + p * (long)(w) + 4 * q)
-#define SV(c, w) (sv_on ? SVP(c, w) : nullptr)
+#define SV(c, w) SVP(c, w)      // (a layer's tile stores are unconditional: lanes past the end redo sample P - 1 and store the same values again -- f32_pipe.hpp: kStores)
         // sign-bit planes (sbits): this lane's NW = w / 128 (at least 1) words of plane b; a whole-network save holds [deformation | radiance] planes
         const bool sb_on = sv_on && bits != nullptr;
         uint32_t *const bits_r = bits + (MODE == FIELD_ALL ? (long)sbits::BD_WORDS * Psv : 0L);
@@ -224,23 +224,23 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         // ---- warp field: dx = tanh(MLP) (modules.py:371-390) ----
         {
             f32x4 h[8], hn[8];
-            dense<KB_XYZ, 0, 8, CHF(L_W1)>(cx, pe_x, nullptr, h, Ly[L_W0].bias_off, false, 0.0f, SV(act::WH, 128), SBD(sbits::BD_WH + 4 * (0), 128));
+            dense_sv<SAVE, KB_XYZ, 0, 8, CHF(L_W1)>(cx, pe_x, nullptr, h, Ly[L_W0].bias_off, false, 0.0f, SV(act::WH, 128), SBD(sbits::BD_WH + 4 * (0), 128));
             // W1..W3; the chunk after each is W2, W3, W4B.  One rolled loop where those have the same size (AudioFaceModel: 32 KB)
             constexpr int W_ROLLED = (CHF(L_W4B) == CHF(L_W2)) ? 3 : 2;
 #pragma unroll 1
             for (int l = 0; l < W_ROLLED; ++l) {
-                dense<8, 0, 8, CHF(L_W2)>(cx, h, nullptr, hn, Ly[L_W1].bias_off + 128 * l, false, 0.0f, SV(act::WH + 128 * (l + 1), 128), SBD(sbits::BD_WH + 4 * ((l + 1)), 128));
+                dense_sv<SAVE, 8, 0, 8, CHF(L_W2)>(cx, h, nullptr, hn, Ly[L_W1].bias_off + 128 * l, false, 0.0f, SV(act::WH + 128 * (l + 1), 128), SBD(sbits::BD_WH + 4 * ((l + 1)), 128));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) h[i] = hn[i];
             }
             if (W_ROLLED == 2) {
-                dense<8, 0, 8, CHF(L_W4B)>(cx, h, nullptr, hn, Ly[L_W3].bias_off, false, 0.0f, SV(act::WH + 128 * 3, 128), SBD(sbits::BD_WH + 4 * (3), 128));
+                dense_sv<SAVE, 8, 0, 8, CHF(L_W4B)>(cx, h, nullptr, hn, Ly[L_W3].bias_off, false, 0.0f, SV(act::WH + 128 * 3, 128), SBD(sbits::BD_WH + 4 * (3), 128));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) h[i] = hn[i];
             }
             dense<KB_XYZ, 0, 8, CHF(L_W4A)>(cx, pe_x, nullptr, hn, Ly[L_W4B].bias_off, false, 1.0f);
-            dense<8, 0, 8, CHF(L_W5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::WH + 4 * 128, 128), SBD(sbits::BD_WH + 4 * (4), 128));
-            dense<8, 0, 8, CHF(L_WF)>(cx, hn, nullptr, h, Ly[L_W5].bias_off, false, 0.0f, SV(act::WH + 5 * 128, 128), SBD(sbits::BD_WH + 4 * (5), 128));
+            dense_sv<SAVE, 8, 0, 8, CHF(L_W5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::WH + 4 * 128, 128), SBD(sbits::BD_WH + 4 * (4), 128));
+            dense_sv<SAVE, 8, 0, 8, CHF(L_WF)>(cx, hn, nullptr, h, Ly[L_W5].bias_off, false, 0.0f, SV(act::WH + 5 * 128, 128), SBD(sbits::BD_WH + 4 * (5), 128));
             f32x4 o[1];
             dense<8, 0, 1, CHF(L_H0)>(cx, h, nullptr, o, Ly[L_WF].bias_off, false, 1.0f);
             if (q == 0) {
@@ -255,22 +255,22 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         // ---- hyper sheet: ambient w (modules.py:444-462) ----
         {
             f32x4 h[4], hn[4];
-            dense<KB_XYZ, 0, 4, CHF(L_H1)>(cx, pe_x, nullptr, h, Ly[L_H0].bias_off, false, 0.0f, SV(act::HH, 64), SBD(sbits::BD_HH + 4 * (0), 64));
+            dense_sv<SAVE, KB_XYZ, 0, 4, CHF(L_H1)>(cx, pe_x, nullptr, h, Ly[L_H0].bias_off, false, 0.0f, SV(act::HH, 64), SBD(sbits::BD_HH + 4 * (0), 64));
             constexpr int H_ROLLED = (CHF(L_H4B) == CHF(L_H2)) ? 3 : 2;   // H1..H3 (next chunks: H2, H3, H4B)
 #pragma unroll 1
             for (int l = 0; l < H_ROLLED; ++l) {
-                dense<4, 0, 4, CHF(L_H2)>(cx, h, nullptr, hn, Ly[L_H1].bias_off + 64 * l, false, 0.0f, SV(act::HH + 64 * (l + 1), 64), SBD(sbits::BD_HH + 4 * ((l + 1)), 64));
+                dense_sv<SAVE, 4, 0, 4, CHF(L_H2)>(cx, h, nullptr, hn, Ly[L_H1].bias_off + 64 * l, false, 0.0f, SV(act::HH + 64 * (l + 1), 64), SBD(sbits::BD_HH + 4 * ((l + 1)), 64));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) h[i] = hn[i];
             }
             if (H_ROLLED == 2) {
-                dense<4, 0, 4, CHF(L_H4B)>(cx, h, nullptr, hn, Ly[L_H3].bias_off, false, 0.0f, SV(act::HH + 64 * 3, 64), SBD(sbits::BD_HH + 4 * (3), 64));
+                dense_sv<SAVE, 4, 0, 4, CHF(L_H4B)>(cx, h, nullptr, hn, Ly[L_H3].bias_off, false, 0.0f, SV(act::HH + 64 * 3, 64), SBD(sbits::BD_HH + 4 * (3), 64));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) h[i] = hn[i];
             }
             dense<KB_XYZ, 0, 4, CHF(L_H4A)>(cx, pe_x, nullptr, hn, Ly[L_H4B].bias_off, false, 1.0f);
-            dense<4, 0, 4, CHF(L_H5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::HH + 4 * 64, 64), SBD(sbits::BD_HH + 4 * (4), 64));
-            dense<4, 0, 4, CHF(L_HF)>(cx, hn, nullptr, h, Ly[L_H5].bias_off, false, 0.0f, SV(act::HH + 5 * 64, 64), SBD(sbits::BD_HH + 4 * (5), 64));
+            dense_sv<SAVE, 4, 0, 4, CHF(L_H5)>(cx, h, nullptr, hn, 0, true, 0.0f, SV(act::HH + 4 * 64, 64), SBD(sbits::BD_HH + 4 * (4), 64));
+            dense_sv<SAVE, 4, 0, 4, CHF(L_HF)>(cx, hn, nullptr, h, Ly[L_H5].bias_off, false, 0.0f, SV(act::HH + 5 * 64, 64), SBD(sbits::BD_HH + 4 * (5), 64));
             f32x4 o[1];
             dense<4, 0, 1, (MODE == FIELD_DEFORM ? CHF(L_FIRST) : CHF(L_T0))>(cx, h, nullptr, o, Ly[L_HF].bias_off, false, 1.0f);
             if (q == 0) {      // rows 0..AMB_DIM-1 of the one output tile
@@ -308,14 +308,14 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                     for (int b = 0; b < KB_XYZ + KB_AMB; ++b)
                         *reinterpret_cast<f32x4 *>(b < KB_XYZ ? SVP(act::PEX, 16 * KB_XYZ) + 16 * b : SVP(act::PEW, 16 * KB_AMB) + 16 * (b - KB_XYZ)) = in_tr[b];
                 }
-                dense<KB_XYZ, KB_AMB, 16, CHF(L_T1)>(cx, in_tr, in_tr + KB_XYZ, h, Ly[L_T0].bias_off, false, 0.01f, SV(act::T, 256), SBR(sbits::BR_T + 8 * (0), 256));
+                dense_sv<SAVE, KB_XYZ, KB_AMB, 16, CHF(L_T1)>(cx, in_tr, in_tr + KB_XYZ, h, Ly[L_T0].bias_off, false, 0.01f, SV(act::T, 256), SBR(sbits::BR_T + 8 * (0), 256));
             }
             if (dump) dsl[5] = h[0][0];
-            dense<16, 0, 16, CHF(L_T2)>(cx, h, nullptr, feat, Ly[L_T1].bias_off, false, 0.01f, SV(act::T + 256, 256), SBR(sbits::BR_T + 8 * (1), 256));
+            dense_sv<SAVE, 16, 0, 16, CHF(L_T2)>(cx, h, nullptr, feat, Ly[L_T1].bias_off, false, 0.01f, SV(act::T + 256, 256), SBR(sbits::BR_T + 8 * (1), 256));
             if (dump) dsl[6] = feat[0][0];
 #pragma unroll
             for (int i = 0; i < 16; ++i) h[i] = feat[i];
-            dense<16, 0, 16, CHF(L_T3B)>(cx, h, nullptr, feat, Ly[L_T2].bias_off, false, 0.01f, SV(act::T + 512, 256), SBR(sbits::BR_T + 8 * (2), 256));
+            dense_sv<SAVE, 16, 0, 16, CHF(L_T3B)>(cx, h, nullptr, feat, Ly[L_T2].bias_off, false, 0.01f, SV(act::T + 512, 256), SBR(sbits::BR_T + 8 * (2), 256));
             if (dump) dsl[7] = feat[0][0];
 #pragma unroll
             for (int i = 0; i < 16; ++i) h[i] = feat[i];
@@ -331,9 +331,9 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
                 dense<KB_XYZ, KB_AMB, 16, CHF(L_T3A)>(cx, in_tr, in_tr + KB_XYZ, feat, Ly[L_T3B].bias_off, false, 1.0f);
             }
 #if SAHS_MODEL == 0
-            dense<16, 0, 16, CHF(L_T4)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768, 256), SBR(sbits::BR_T + 8 * (3), 256));
+            dense_sv<SAVE, 16, 0, 16, CHF(L_T4)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768, 256), SBR(sbits::BR_T + 8 * (3), 256));
 #else           // 4-layer trunk: the skip layer is the last one, fc_feat follows
-            dense<16, 0, 16, CHF(L_FEAT)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768, 256), SBR(sbits::BR_T + 8 * (3), 256));
+            dense_sv<SAVE, 16, 0, 16, CHF(L_FEAT)>(cx, h, nullptr, feat, 0, true, 0.01f, SV(act::T + 768, 256), SBR(sbits::BR_T + 8 * (3), 256));
 #endif
             if (dump) dsl[8] = feat[0][0];
 #pragma unroll
@@ -341,13 +341,13 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
 #if SAHS_MODEL == 0
 #pragma unroll 1
             for (int l = 4; l <= 7; ++l) {     // T4..T7 (next chunks: T5, T6, T7, FEAT, all 32 KB)
-                dense<16, 0, 16, CHF(L_T5)>(cx, h, nullptr, feat, Ly[L_T4].bias_off + 256 * (l - 4), false, 0.01f, SV(act::T + 256 * l, 256), SBR(sbits::BR_T + 8 * (l), 256));
+                dense_sv<SAVE, 16, 0, 16, CHF(L_T5)>(cx, h, nullptr, feat, Ly[L_T4].bias_off + 256 * (l - 4), false, 0.01f, SV(act::T + 256 * l, 256), SBR(sbits::BR_T + 8 * (l), 256));
                 if (dump) dsl[5 + l] = feat[0][0];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) h[i] = feat[i];
             }
 #endif
-            dense<16, 0, 16, CHF(L_ALPHA)>(cx, h, nullptr, feat, Ly[L_FEAT].bias_off, false, 1.0f, SV(act::FEAT, 256));
+            dense_sv<SAVE, 16, 0, 16, CHF(L_ALPHA)>(cx, h, nullptr, feat, Ly[L_FEAT].bias_off, false, 1.0f, SV(act::FEAT, 256));
             if (dump) dsl[13] = feat[0][0];
         }
         dense<16, 0, 1, CHF(L_D0B)>(cx, feat, nullptr, fin, Ly[L_ALPHA].bias_off, false, 1.0f);
@@ -372,15 +372,15 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
             }
             f32x4 c[8], cn[8];
             dense<2, 2, 8, CHF(L_D0A)>(cx, in_d, in_d + 2, c, Ly[L_D0B].bias_off, false, 1.0f);
-            dense<16, 0, 8, CHF(L_D1)>(cx, feat, nullptr, c, 0, true, 0.01f, SV(act::C, 128), SBR(sbits::BR_C + 4 * (0), 128));
+            dense_sv<SAVE, 16, 0, 8, CHF(L_D1)>(cx, feat, nullptr, c, 0, true, 0.01f, SV(act::C, 128), SBR(sbits::BR_C + 4 * (0), 128));
             if (dump) dsl[14] = c[0][0];
 #pragma unroll 1
             for (int l = 0; l < 2; ++l) {      // D1, D2
-                dense<8, 0, 8, CHF(L_D2)>(cx, c, nullptr, cn, Ly[L_D1].bias_off + 128 * l, false, 0.01f, SV(act::C + 128 * (l + 1), 128), SBR(sbits::BR_C + 4 * ((l + 1)), 128));
+                dense_sv<SAVE, 8, 0, 8, CHF(L_D2)>(cx, c, nullptr, cn, Ly[L_D1].bias_off + 128 * l, false, 0.01f, SV(act::C + 128 * (l + 1), 128), SBR(sbits::BR_C + 4 * ((l + 1)), 128));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) c[i] = cn[i];
             }
-            dense<8, 0, 8, CHF(L_RGB)>(cx, c, nullptr, cn, Ly[L_D3].bias_off, false, 0.01f, SV(act::C + 384, 128), SBR(sbits::BR_C + 4 * (3), 128));
+            dense_sv<SAVE, 8, 0, 8, CHF(L_RGB)>(cx, c, nullptr, cn, Ly[L_D3].bias_off, false, 0.01f, SV(act::C + 384, 128), SBR(sbits::BR_C + 4 * (3), 128));
             if (dump) dsl[15] = cn[0][0];
             dense<8, 0, 1, CHF(L_S0)>(cx, cn, nullptr, fin, 0, true, 1.0f);
             if (dbg != nullptr && p_raw < P) *reinterpret_cast<f32x4 *>(dsl + 40 + 4 * q) = fin[0];
@@ -388,15 +388,15 @@ field_forward_f32_kernel(const float *__restrict__ packed, const float *__restri
         // ---- seg branch (modules.py:289-294) ----
         {
             f32x4 s[8], sn[8];
-            dense<16, 0, 8, CHF(L_S1)>(cx, feat, nullptr, s, Ly[L_S0].bias_off, false, 0.01f, SV(act::S, 128), SBR(sbits::BR_S + 4 * (0), 128));
+            dense_sv<SAVE, 16, 0, 8, CHF(L_S1)>(cx, feat, nullptr, s, Ly[L_S0].bias_off, false, 0.01f, SV(act::S, 128), SBR(sbits::BR_S + 4 * (0), 128));
             if (dump) dsl[16] = s[0][0];
 #pragma unroll 1
             for (int l = 0; l < 2; ++l) {      // S1, S2
-                dense<8, 0, 8, CHF(L_S2)>(cx, s, nullptr, sn, Ly[L_S1].bias_off + 128 * l, false, 0.01f, SV(act::S + 128 * (l + 1), 128), SBR(sbits::BR_S + 4 * ((l + 1)), 128));
+                dense_sv<SAVE, 8, 0, 8, CHF(L_S2)>(cx, s, nullptr, sn, Ly[L_S1].bias_off + 128 * l, false, 0.01f, SV(act::S + 128 * (l + 1), 128), SBR(sbits::BR_S + 4 * ((l + 1)), 128));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s[i] = sn[i];
             }
-            dense<8, 0, 8, CHF(L_SEG)>(cx, s, nullptr, sn, Ly[L_S3].bias_off, false, 0.01f, SV(act::S + 384, 128), SBR(sbits::BR_S + 4 * (3), 128));
+            dense_sv<SAVE, 8, 0, 8, CHF(L_SEG)>(cx, s, nullptr, sn, Ly[L_S3].bias_off, false, 0.01f, SV(act::S + 384, 128), SBR(sbits::BR_S + 4 * (3), 128));
             if (dump) dsl[17] = sn[0][0];
             dense<8, 0, 1, CHF(L_START)>(cx, sn, nullptr, fin, 0, true, 1.0f);
         }
