@@ -990,7 +990,8 @@ __global__ void __launch_bounds__(TN_THREADS) __attribute__((amdgpu_waves_per_eu
 // (4096 cycles) against 32 KB of operands -- not HBM.  Ring of four K-steps.
 constexpr int TF_DST = 4;
 constexpr int TF_LDS_BYTES = TF_DST * 2 * DTILE * 4;                           // 64 KB: two workgroups per CU
-constexpr int TFW_LDS_BYTES = TF_DST * TW_STAGE_FLOATS * 4;                    // 128 KB: one workgroup per CU
+constexpr int TFW_DST = 5;                                                     // the wide kernel's ring: all 160 KB of the CU, four K-steps in flight
+constexpr int TFW_LDS_BYTES = TFW_DST * TW_STAGE_FLOATS * 4;                   // 160 KB: one workgroup per CU
 __device__ __forceinline__ int swz_col(int col, int odd) { return (((col >> 2) ^ (odd << 2)) << 2) + (col & 3); }
 
 // One (up to) 128 x 128 tile of C += A^T B over the samples [k_lo, k_hi).  The tile's valid part is TR x TC 16 x 16 accumulators (a head's
@@ -1163,7 +1164,7 @@ __device__ __forceinline__ void tn_block256_f32(float *ring, int M, int N, const
     }
     const int dst_off = blk * DTILE + (wave & 1) * 4 * 256;
     auto issue = [&](int t) {
-        float *dstb = ring + (t % TF_DST) * TW_STAGE_FLOATS + dst_off;
+        float *dstb = ring + (t % TFW_DST) * TW_STAGE_FLOATS + dst_off;
         const long k0 = k_lo + (long)t * GK;
         const bool tail = k0 + GK > k_hi;
 #pragma unroll
@@ -1194,13 +1195,15 @@ __device__ __forceinline__ void tn_block256_f32(float *ring, int M, int N, const
     if (T > 0) issue(0);
     if (T > 1) issue(1);
     if (T > 2) issue(2);
+    if (T > 3) issue(3);
     for (int t = 0; t < T; ++t) {
-        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        if (t + 3 < T) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        else if (t + 2 < T) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
         else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        const float *stage = ring + (t % TF_DST) * TW_STAGE_FLOATS;
+        const float *stage = ring + (t % TFW_DST) * TW_STAGE_FLOATS;
         const bool rows_valid = 64 * wm < M;      // (a 128 x 256 layer: waves 4..7 -- the second wave of every SIMD -- own rows of the zero page)
-        if (!rows_valid && t + TF_DST - 1 < T) issue(t + TF_DST - 1);
+        if (!rows_valid && t + TFW_DST - 1 < T) issue(t + TFW_DST - 1);
         if (rows_valid) {
             // operands of sample group s4 + 1 are requested before the 32 MFMAs of group s4 (two register sets).  Measured MFMA busy 0.71 at
             // 2.35 GHz -- and the same launch time with the compiler's own read placement, with all four groups read up front and every
@@ -1220,7 +1223,7 @@ __device__ __forceinline__ void tn_block256_f32(float *ring, int M, int N, const
                     for (int j = 0; j < 8; ++j) b[(s4 + 1) & 1][j] = stage[(4 * (s4 + 1) + q) * GT + colB[j]];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (s4 == 1 && t + TF_DST - 1 < T) issue(t + TF_DST - 1);      // (behind the first quarter of the step's MFMAs: see tn_tile_f32)
+                if (s4 == 1 && t + TFW_DST - 1 < T) issue(t + TFW_DST - 1);      // (behind the first quarter of the step's MFMAs: see tn_tile_f32)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
