@@ -636,6 +636,63 @@ def test_two_stream_backward_matches_one_stream(arch, with_loss, weights_mod, mo
         off += n
 
 
+@pytest.mark.parametrize("prec,N", [("fp32", 2048), ("fp32", 1237), ("bf16x3", 2048)])
+def test_fused_walk_at_step_size_vs_per_layer(prec, N, weights_mod):
+    """The fused walk at the size of a training step (2,048 rays x (64 + 128) evaluations: 262,144 fine samples, every weight-gradient unit cut
+    into many ranges by the item plans, several items per workgroup; 1,237 rays: ranges that do not divide the samples) through the
+    autograd op, against the per-layer walk of the same arithmetic on the same forward: parameter and driving-input gradients within
+    2e-5 of scale in fp32 products (another order of sums), 1e-4 with split-bf16 operands."""
+    ops = pkg("ops")
+    dev = torch.device("cuda:0")
+    fw = weights_mod.flatten_state_dict(weights_mod.hash_state_dict(0, 2.0, 30.0, hdr=True))
+    gen = torch.Generator(device=dev).manual_seed(29)
+    nc, nf = 64, 64
+    drv = torch.randn(16, 29, device=dev, generator=gen)
+    pose = torch.from_numpy(np.concatenate([np.eye(3), [[0.0], [0.0], [0.8]]], 1).astype(np.float32)).to(dev)
+    rays = torch.zeros(N, 8, device=dev)
+    rays[:, 2] = 0.8
+    rays[:, 3:6] = torch.randn(N, 3, device=dev, generator=gen) * 0.15 + torch.tensor([0, 0, -1.0], device=dev)
+    rays[:, 6], rays[:, 7] = 0.483771, 1.083771
+    bg = torch.cat([torch.rand(N, 3, device=dev, generator=gen), torch.ones(N, 1, device=dev), torch.zeros(N, 11, device=dev)], 1)
+    t_rand, u = torch.rand(N, nc, device=dev, generator=gen), torch.rand(N, nf, device=dev, generator=gen)
+    noise_c, noise_f = torch.randn(N, nc, device=dev, generator=gen) * 0.1, torch.randn(N, nc + nf, device=dev, generator=gen) * 0.1
+    target = torch.rand(N, 3, device=dev, generator=gen)
+    mask = torch.zeros(N, 12, device=dev)
+    mask.scatter_(1, torch.randint(0, 12, (N, 1), device=dev, generator=gen), 1.0)
+    cw = pkg("training").sample_prob_weights(dev)
+    res = {}
+    try:
+        ops.backward_gemm_precision(prec)
+        for fused in (False, True):
+            ops.fused_backward(fused)
+            flat = torch.from_numpy(fw).to(dev).requires_grad_(True)
+            d = drv.clone().requires_grad_(True)
+            packed = ops.pack_weights(flat.detach())
+            outs = ops.RenderRaysFn.apply(flat, d, pose, rays, bg, t_rand, noise_c, u, noise_f, packed, nc, nf, False, False, "audio", target, mask, cw)
+            outs[8].backward()
+            torch.cuda.synchronize()
+            res[fused] = (flat.grad.clone(), d.grad.clone())
+    finally:
+        ops.backward_gemm_precision("bf16x3")
+        ops.fused_backward(True)
+    tol = 2e-5 if prec == "fp32" else 1e-4
+    worst = {}
+    off = 0
+    for name, shape in weights_mod.canonical_spec("audio"):      # per tensor: a small tensor must not hide behind the global scale
+        n = int(np.prod(shape))
+        a, b = res[True][0][off:off + n], res[False][0][off:off + n]
+        sc = float(b.abs().max())
+        if sc > 0:
+            worst[name] = float((a - b).abs().max()) / sc
+        else:
+            assert float(a.abs().max()) == 0.0, name
+        off += n
+    worst["driving input"] = float((res[True][1] - res[False][1]).abs().max()) / float(res[False][1].abs().max())
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print("fused vs per-layer walk at step size (%s, %d rays), worst |delta| / scale:" % (prec, N), ", ".join("%s %.2e" % kv for kv in top))
+    assert top[0][1] <= tol, top
+
+
 def test_fused_backward_vs_per_layer_walks(weights_mod):
     """The fused backward walk (one sample-major data-gradient chain + one weight-gradient launch per part, masks from the sign bits of
     the saving forward: include/sahs_nerf.h, sahs_model_field_backward_fused) against the per-layer walk on the SAME saved activations and
