@@ -1089,7 +1089,7 @@ __device__ __forceinline__ void tn_tile_f32(float *ring, int M, int N, const flo
                         if (i < ni && j < nj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (do_sum && tid < GT) {
+        if (do_sum && tid < GT) {      // (measured: the launch is as long without these sums, 0.650 vs 0.652 ms)
 #pragma unroll
             for (int k = 0; k < GK; ++k) cs += stage[k * GT + swz_col(tid, k & 1)];
         }
