@@ -1063,37 +1063,53 @@ __device__ __forceinline__ void tn_tile_f32(float *ring, int M, int N, const flo
     if (T > 0) issue(0);
     if (T > 1) issue(1);
     if (T > 2) issue(2);
-    for (int t = 0; t < T; ++t) {
-        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-        else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        const float *stage = ring + (t % TF_DST) * 2 * DTILE;
-        // K-step t + 3 goes into the stage every wave finished reading before the barrier above -- requested behind the first quarter of
-        // this step's MFMAs, not in front of them: its address arithmetic then runs beside the matrix pipe instead of holding it up
-        if (!(ni > 0 && nj > 0) && t + TF_DST - 1 < T) issue(t + TF_DST - 1);
-        if (ni > 0 && nj > 0) {
+    // The K loop, once per shape of the wave block (4, 2 or 1 row tiles by 2 column tiles; NI = 0: any other -- ragged widths -- with a uniform
+    // guard per accumulator): the dispatch is outside the loop, so the loop body is MFMAs and operand reads only (with the guards inside, the
+    // compiler put a vcc branch between any two of them)
+    auto kloop = [&]<int NI, int NJ>() {
+        for (int t = 0; t < T; ++t) {
+            if (t + 2 < T) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            else if (t + 1 < T) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            const float *stage = ring + (t % TF_DST) * 2 * DTILE;
+            // K-step t + 3 goes into the stage every wave finished reading before the barrier above -- requested behind the first quarter of
+            // this step's MFMAs, not in front of them: its address arithmetic then runs beside the matrix pipe instead of holding it up
+            const bool work = NI > 0 || (ni > 0 && nj > 0);
+            if (!work && t + TF_DST - 1 < T) issue(t + TF_DST - 1);
+            if (work) {
 #pragma unroll
-            for (int s4 = 0; s4 < GK / 4; ++s4) {
-                if (s4 == 1 && t + TF_DST - 1 < T) issue(t + TF_DST - 1);
-                float a[4], b[2];
+                for (int s4 = 0; s4 < GK / 4; ++s4) {
+                    if (s4 == 1 && t + TF_DST - 1 < T) issue(t + TF_DST - 1);
+                    const float *row = stage + (4 * s4 + q) * GT;
+                    if constexpr (NI > 0) {
+                        float a[NI], b[NJ];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < ni) a[i] = stage[(4 * s4 + q) * GT + colA[i]];
+                        for (int i = 0; i < NI; ++i) a[i] = row[colA[i]];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (j < nj) b[j] = stage[(4 * s4 + q) * GT + colB[j]];
+                        for (int j = 0; j < NJ; ++j) b[j] = row[colB[j]];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        if (i < ni && j < nj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                if (i < ni && j < nj) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[colA[i]], row[colB[j]], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+            if (do_sum && tid < GT) {      // (measured: the launch is as long without these sums, 0.650 vs 0.652 ms)
+#pragma unroll
+                for (int k = 0; k < GK; ++k) cs += stage[k * GT + swz_col(tid, k & 1)];
             }
         }
-        if (do_sum && tid < GT) {      // (measured: the launch is as long without these sums, 0.650 vs 0.652 ms)
-#pragma unroll
-            for (int k = 0; k < GK; ++k) cs += stage[k * GT + swz_col(tid, k & 1)];
-        }
-    }
+    };
+    if (nj == 2 && ni == 4) kloop.template operator()<4, 2>();
+    else if (nj == 2 && ni == 2) kloop.template operator()<2, 2>();
+    else if (nj == 2 && ni == 1) kloop.template operator()<1, 2>();
+    else kloop.template operator()<0, 0>();
     // accumulator (i, j) register r: row 16 (rt0 + i) + 4 q + r, column 16 (ct0 + j) + c16
 #pragma unroll
     for (int i = 0; i < 4; ++i)
