@@ -2210,7 +2210,7 @@ struct TnList {
         });
         if (ae != hipSuccess) return (int)ae;
         static const float c0w = getenv("SAHS_TNF_C0W") ? (float)atof(getenv("SAHS_TNF_C0W")) : 0.27f;      // (tuning aids: a K-step's fixed part in the two
-        static const float c0n = getenv("SAHS_TNF_C0N") ? (float)atof(getenv("SAHS_TNF_C0N")) : 1.3f;      //  cost models, items per workgroup of the narrow launch)
+        static const float c0n = getenv("SAHS_TNF_C0N") ? (float)atof(getenv("SAHS_TNF_C0N")) : 0.4f;      //  cost models, items per workgroup of the narrow launch)
         static const long rounds_n = getenv("SAHS_TNF_ROUNDS") ? atol(getenv("SAHS_TNF_ROUNDS")) : 3;
         if (nw > 0) {      // one 128-KB workgroup per CU, one item each
             TnPlan pl;
@@ -2234,8 +2234,8 @@ struct TnList {
                     for (int bx = 0; bx < nx; ++bx, ++nu) {
                         if (nu >= MAX_TN_UNITS) return (int)hipErrorOutOfMemory;
                         const int mt = b.j[i].M - by * GT < GT ? b.j[i].M - by * GT : GT, nt = b.j[i].N - bx * GT < GT ? b.j[i].N - bx * GT : GT;
-                        // a K-step: its fixed part (barrier, DMA issue, first LDS round trip; fitted on the training step, tools/sweep_tnf.sh: 0.72 / 0.69 /
-                        // 0.64 / 0.70 ms per launch at 0.55 / 0.9 / 1.3 / 2.0) + the tile's valid accumulators
+                        // a K-step: its fixed part (barrier, DMA issue, first LDS round trip; fitted on the training step, tools/sweep_tnf.sh: 0.54 / 0.54 /
+                        // 0.55 / 0.56 / 0.57 ms per launch at 0.4 / 0.7 / 1.0 / 1.3 / 1.8) + the tile's valid accumulators
                         cost[nu] = c0n + (float)(((mt + 15) / 16) * ((nt + 15) / 16)) / 64.0f;
                         pl.u[nu].job = (unsigned char)i; pl.u[nu].bx = (unsigned char)bx; pl.u[nu].by = (unsigned char)by; pl.u[nu].pad = 0;
                     }
