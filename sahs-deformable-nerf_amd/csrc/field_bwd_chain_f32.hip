@@ -169,6 +169,10 @@ struct BwdEpF {
     }
 };
 
+constexpr int RAD_MASK_WORDS = 2 * TR_LAYERS + 8, DEF_MASK_WORDS = 12;      // sign words per lane and sample tile
+static_assert(TR_LAYERS == 8, "slots 16.. of the radiance mask words follow the trunk's 16");
+constexpr int CHAIN_LDS_BYTES = 2 * LDS_BUF_FLOATS * 4 + (F32_THREADS / WAVE) * RAD_MASK_WORDS * WAVE * 4;      // the two weight-chunk buffers + the waves' mask words
+
 #define CHR(id) (kRad.layer[id].chunk)
 #define CHD(id) (kDef.layer[id].chunk)
 
@@ -209,18 +213,37 @@ field_backward_chain_rad_f32_kernel(const float *__restrict__ stream, long P, co
         asm volatile("" : "+s"(Pq));                   // (the ~25 plane bases c * P are loop-invariant: keep them from being hoisted and spilled)
         const uint32_t sb_lane = (uint32_t)(p * 4 + q);
 #define DZ(c, w) (dact + (long)(c) * Pq + p * (long)(w) + 4 * q)
-        auto ep128 = [&](int b, int c) {               // a 128-wide leaky-ReLU layer: one sign word per lane
+        // This lane's 24 sign words of the tile, fetched ONCE and parked in LDS (word k at mw[64 k]: trunk layer l -> 2 l, 2 l + 1; colour
+        // layer i -> 16 + i; seg layer i -> 20 + i).  Fetched where a layer needs them, each was an ordinary global load whose use the compiler
+        // guards with vmcnt(0) while LDS-DMA is in flight -- a full drain of the weight prefetch (and of the tile stores) in the middle of a
+        // chunk, 16 times per sample tile; from LDS the layers read them on the lgkm counter.
+        uint32_t *const mw = reinterpret_cast<uint32_t *>(lds_f + 2 * LDS_BUF_FLOATS) + cx.wave * (RAD_MASK_WORDS * WAVE) + cx.lane;
+        {
+            uint32_t w[RAD_MASK_WORDS];
+#pragma unroll
+            for (int l = 0; l < TR_LAYERS; ++l) {
+                const uint32_t *a = bits + (long)(sbits::BR_T + 8 * l) * Pq + sb_lane * 2u;
+                w[2 * l] = a[0]; w[2 * l + 1] = a[1];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w[16 + i] = bits[(long)(sbits::BR_C + 4 * i) * Pq + sb_lane];
+                w[20 + i] = bits[(long)(sbits::BR_S + 4 * i) * Pq + sb_lane];
+            }
+#pragma unroll
+            for (int k = 0; k < RAD_MASK_WORDS; ++k) mw[WAVE * k] = w[k];
+        }
+        auto ep128 = [&](int slot, int c) {            // a 128-wide leaky-ReLU layer: one sign word per lane
             BwdEpF<true> e;
             e.accum = false; e.slope = 0.01f;
-            e.m[0] = bits[(long)b * Pq + sb_lane]; e.m[1] = 0u;
+            e.m[0] = mw[WAVE * slot]; e.m[1] = 0u;
             e.save = DZ(c, 128);
             return e;
         };
-        auto ep256 = [&](int b, int c) {
+        auto ep256 = [&](int l, int c) {               // trunk layer l: two sign words
             BwdEpF<true> e;
             e.accum = false; e.slope = 0.01f;
-            const uint32_t *a = bits + (long)b * Pq + sb_lane * 2u;
-            e.m[0] = a[0]; e.m[1] = a[1];
+            e.m[0] = mw[WAVE * (2 * l)]; e.m[1] = mw[WAVE * (2 * l + 1)];
             e.save = DZ(c, 256);
             return e;
         };
@@ -229,13 +252,13 @@ field_backward_chain_rad_f32_kernel(const float *__restrict__ stream, long P, co
         f32x4 dC0[8], dS0[8];
         {   // colour branch: d_raw -> dC3 -> dC2 -> dC1 -> dC0 -> d grid features
             f32x4 cA[8], cB[8];
-            auto e3 = ep128(sbits::BR_C + 12, act::C + 384);
+            auto e3 = ep128(16 + 3, act::C + 384);
             dense_ep<1, 0, 8, CHR(R_D3)>(cx, draw, nullptr, cA, e3);
-            auto e2 = ep128(sbits::BR_C + 8, act::C + 256);
+            auto e2 = ep128(16 + 2, act::C + 256);
             dense_ep<8, 0, 8, CHR(R_D2)>(cx, cA, nullptr, cB, e2);
-            auto e1 = ep128(sbits::BR_C + 4, act::C + 128);
+            auto e1 = ep128(16 + 1, act::C + 128);
             dense_ep<8, 0, 8, CHR(R_D1)>(cx, cB, nullptr, cA, e1);
-            auto e0 = ep128(sbits::BR_C + 0, act::C + 0);
+            auto e0 = ep128(16 + 0, act::C + 0);
             dense_ep<8, 0, 8, CHR(R_GRIDF)>(cx, cA, nullptr, dC0, e0);
             BwdEpF<false> eg{false, 1.0f, {0u, 0u}, dgridf + p * 32 + 4 * q};
             f32x4 g2[2];
@@ -243,13 +266,13 @@ field_backward_chain_rad_f32_kernel(const float *__restrict__ stream, long P, co
         }
         {   // seg branch: d_raw -> dS3 -> dS2 -> dS1 -> dS0
             f32x4 sA[8], sB[8];
-            auto e3 = ep128(sbits::BR_S + 12, act::S + 384);
+            auto e3 = ep128(20 + 3, act::S + 384);
             dense_ep<1, 0, 8, CHR(R_S3)>(cx, draw, nullptr, sA, e3);
-            auto e2 = ep128(sbits::BR_S + 8, act::S + 256);
+            auto e2 = ep128(20 + 2, act::S + 256);
             dense_ep<8, 0, 8, CHR(R_S2)>(cx, sA, nullptr, sB, e2);
-            auto e1 = ep128(sbits::BR_S + 4, act::S + 128);
+            auto e1 = ep128(20 + 1, act::S + 128);
             dense_ep<8, 0, 8, CHR(R_S1)>(cx, sB, nullptr, sA, e1);
-            auto e0 = ep128(sbits::BR_S + 0, act::S + 0);
+            auto e0 = ep128(20 + 0, act::S + 0);
             dense_ep<8, 0, 8, CHR(R_FEATA)>(cx, sA, nullptr, dS0, e0);
         }
         f32x4 F[16], G[16];
@@ -260,11 +283,11 @@ field_backward_chain_rad_f32_kernel(const float *__restrict__ stream, long P, co
             dense_ep<8, 8, 16, CHR(R_FEAT)>(cx, dS0, dC0, F, ef);
         }
         {   // trunk: d feat -> dT7 -> ... -> dT3 (-> the encodings through the skip layer) -> dT2 -> dT1 -> dT0 (-> the encodings through layer 0)
-            auto e7 = ep256(sbits::BR_T + 8 * 7, act::T + 7 * 256);
+            auto e7 = ep256(7, act::T + 7 * 256);
             dense_ep<16, 0, 16, CHR(R_T7)>(cx, F, nullptr, G, e7);
 #pragma unroll 1
             for (int l = 6; l >= 3; --l) {             // layers T7..T4 (next chunks: T6, T5, T4, T3IN, all 32 KB) leave dT6..dT3
-                auto el = ep256(sbits::BR_T + 8 * l, act::T + l * 256);
+                auto el = ep256(l, act::T + l * 256);
                 dense_ep<16, 0, 16, CHR(R_T6)>(cx, G, nullptr, F, el);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) G[i] = F[i];
@@ -275,11 +298,11 @@ field_backward_chain_rad_f32_kernel(const float *__restrict__ stream, long P, co
                 f32x4 d6[6];
                 dense_ep<16, 0, 6, CHR(R_T3)>(cx, G, nullptr, d6, ei);
             }
-            auto e2 = ep256(sbits::BR_T + 8 * 2, act::T + 2 * 256);
+            auto e2 = ep256(2, act::T + 2 * 256);
             dense_ep<16, 0, 16, CHR(R_T2)>(cx, G, nullptr, F, e2);
-            auto e1 = ep256(sbits::BR_T + 8 * 1, act::T + 1 * 256);
+            auto e1 = ep256(1, act::T + 1 * 256);
             dense_ep<16, 0, 16, CHR(R_T1)>(cx, F, nullptr, G, e1);
-            auto e0 = ep256(sbits::BR_T + 0, act::T + 0);
+            auto e0 = ep256(0, act::T + 0);
             dense_ep<16, 0, 16, CHR(R_T0IN)>(cx, G, nullptr, F, e0);
             {
                 BwdEpF<false> ei{false, 1.0f, {0u, 0u}, din_b + p * 96 + 4 * q};
@@ -311,10 +334,22 @@ field_backward_chain_def_f32_kernel(const float *__restrict__ stream, long P, co
         long Pq = P;
         asm volatile("" : "+s"(Pq));
         const uint32_t sb_lane = (uint32_t)(p * 4 + q);
-        auto epr = [&](int b, int c, int w) {          // a ReLU layer of width w (64 or 128): one sign word per lane
+        // (this lane's 12 sign words, parked in LDS as in the radiance kernel: hyper-sheet layer i -> i, warp-field layer i -> 6 + i)
+        uint32_t *const mw = reinterpret_cast<uint32_t *>(lds_f + 2 * LDS_BUF_FLOATS) + cx.wave * (DEF_MASK_WORDS * WAVE) + cx.lane;
+        {
+            uint32_t w[DEF_MASK_WORDS];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                w[i] = bits[(long)(sbits::BD_HH + 4 * i) * Pq + sb_lane];
+                w[6 + i] = bits[(long)(sbits::BD_WH + 4 * i) * Pq + sb_lane];
+            }
+#pragma unroll
+            for (int k = 0; k < DEF_MASK_WORDS; ++k) mw[WAVE * k] = w[k];
+        }
+        auto epr = [&](int slot, int c, int w) {       // a ReLU layer of width w (64 or 128): one sign word per lane
             BwdEpF<true> e;
             e.accum = false; e.slope = 0.0f;
-            e.m[0] = bits[(long)b * Pq + sb_lane]; e.m[1] = 0u;
+            e.m[0] = mw[WAVE * slot]; e.m[1] = 0u;
             e.save = dact + (long)c * Pq + p * (long)w + 4 * q;
             return e;
         };
@@ -336,32 +371,32 @@ field_backward_chain_def_f32_kernel(const float *__restrict__ stream, long P, co
         }
         {   // hyper sheet: dw -> dG5 -> ... -> dG0
             f32x4 A[4], B[4];
-            auto e5 = epr(sbits::BD_HH + 4 * 5, act::HH + 64 * 5, 64);
+            auto e5 = epr(5, act::HH + 64 * 5, 64);
             dense_ep<1, 0, 4, CHD(D_H5)>(cx, hd_w, nullptr, A, e5);
 #pragma unroll 1
             for (int l = 4; l >= 1; --l) {             // layers H5..H2 (next chunks: H4, H3, H2, H1) leave dG4..dG1
-                auto el = epr(sbits::BD_HH + 4 * l, act::HH + 64 * l, 64);
+                auto el = epr(l, act::HH + 64 * l, 64);
                 dense_ep<4, 0, 4, CHD(D_H4)>(cx, A, nullptr, B, el);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) A[i] = B[i];
             }
             static_assert(CHD(D_H4) == CHD(D_H3) && CHD(D_H4) == CHD(D_H2) && CHD(D_H4) == CHD(D_H1), "rolled hyper-sheet layers");
-            auto e0 = epr(sbits::BD_HH + 0, act::HH + 0, 64);
+            auto e0 = epr(0, act::HH + 0, 64);
             dense_ep<4, 0, 4, CHD(D_WF)>(cx, A, nullptr, B, e0);
         }
         {   // warp field: dx' (1 - dx^2) -> dH5 -> ... -> dH0
             f32x4 A[8], B[8];
-            auto e5 = epr(sbits::BD_WH + 4 * 5, act::WH + 128 * 5, 128);
+            auto e5 = epr(6 + 5, act::WH + 128 * 5, 128);
             dense_ep<1, 0, 8, CHD(D_W5)>(cx, hd_x, nullptr, A, e5);
 #pragma unroll 1
             for (int l = 4; l >= 1; --l) {             // layers W5..W2 leave dH4..dH1
-                auto el = epr(sbits::BD_WH + 4 * l, act::WH + 128 * l, 128);
+                auto el = epr(6 + l, act::WH + 128 * l, 128);
                 dense_ep<8, 0, 8, CHD(D_W4)>(cx, A, nullptr, B, el);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) A[i] = B[i];
             }
             static_assert(CHD(D_W4) == CHD(D_W3) && CHD(D_W4) == CHD(D_W2) && CHD(D_W4) == CHD(D_W1), "rolled warp-field layers");
-            auto e0 = epr(sbits::BD_WH + 0, act::WH + 0, 128);
+            auto e0 = epr(6, act::WH + 0, 128);
             dense_ep<8, 0, 8, CHD(D_HF)>(cx, A, nullptr, B, e0);
         }
     }
@@ -389,7 +424,7 @@ static int launch_chain_f32(K kernel, long P, int num_cu, hipStream_t stream, A.
     if (P <= 0) return 0;
     const long ntiles = (P + F32_PTS_PER_WG - 1) / F32_PTS_PER_WG;
     const int grid = (int)(ntiles < num_cu ? ntiles : num_cu);
-    constexpr int LDS_BYTES = 2 * LDS_BUF_FLOATS * 4;      // the two weight-chunk buffers
+    constexpr int LDS_BYTES = CHAIN_LDS_BYTES;
     static sahs_once::Flags attr_set;       // (one per instantiation = per kernel)
     hipError_t ae = sahs_once::per_device(attr_set, [&]() {
         return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
